@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Benchmark of the ray-march hot path (BASELINE.json metric: Mrays/s + ms/frame at 1080p over a
+256^3 SDF volume, 1/2/4/8 MI355X).
+
+A "step" is one full frame.  With N ranks (one process per GPU, launched by torch.distributed.run)
+the frame is split into N contiguous row tiles; every rank marches its tile into device memory
+and the tiles are gathered onto rank 0 with one RCCL gather (torch.distributed backend "nccl")
+that overlaps with the next frame's march (two tile buffers).  Strong scaling: the frame is
+fixed, N only changes the tile height.
+
+Prints ONE JSON line on rank 0 (see the driver contract), extended with "roofline" and
+"cpu_baseline".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
+
+
+def build_workload(name: str):
+    """Returns (scene, width, height, max_steps, shadow, label)."""
+    import scenes
+
+    if name == "c3":
+        sc = scenes.bench_config3()
+        return sc, 1920, 1080, 255, True, "config3: 256^3 volume, 1920x1080, shadow ray on"
+    if name == "c3sdf":
+        sc = scenes.config3_torus(8, 256, distance=190.0)
+        return sc, 1920, 1080, 255, True, "config3 (analytic SDF variant): 256^3 torus SDF, 1920x1080, shadow ray on"
+    if name == "c2":
+        sc = scenes.config2_sphere(6, 256)
+        return sc, 1280, 720, 128, False, "config2: 64^3 SDF sphere, 1280x720, 128 max steps"
+    if name == "c4":
+        sc = scenes.bench_config3()
+        return sc, 3840, 2160, 255, True, "config4: 256^3 volume, 3840x2160, row tiles + RCCL gather"
+    if name == "c5":
+        sc = scenes.config5_instances(7, 256)
+        return sc, 1920, 1080, 255, True, "config5: 8 instanced 128^3 volumes + skybox, 1920x1080, AABB BVH"
+    raise SystemExit(f"unknown workload {name}")
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3sdf", "c4", "c5"])
+    ap.add_argument("--path", default="auto", choices=["auto", "dense", "brick", "lds"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import scenes
+    import volumetricraytracer_amd as v
+    from volumetricraytracer_amd import _abi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus={args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    sc, W, H, max_steps, shadow, label = build_workload(args.workload)
+    path = {"auto": _abi.PATH_AUTO, "dense": _abi.PATH_DENSE, "brick": _abi.PATH_BRICK, "lds": _abi.PATH_BRICK_LDS}[args.path]
+    p = v.default_params(W, H, scenes.min_cell(sc), max_steps, shadow=shadow, path=path)
+
+    r = v.VHipRenderer(devices=(local_rank,))
+    if not r.Start():
+        raise SystemExit("VHipRenderer.Start() failed")
+    r.SetSceneToRender(sc)
+    r.ResizeRenderOutput(W, H)
+    r.SyncWithScene()
+
+    rows_per = (H + world - 1) // world
+    row0 = min(rank * rows_per, H)
+    rows = max(0, min(rows_per, H - row0))
+    tiles = [torch.zeros((rows_per, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+    frames = None
+    if world > 1 and rank == 0:
+        frames = [torch.empty((world * rows_per, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+    pending = [None, None]
+    stream = torch.cuda.current_stream()
+
+    def step(i: int) -> None:
+        b = i & 1
+        if pending[b] is not None:
+            pending[b].wait()  # tile buffer b is free again (its gather finished)
+            pending[b] = None
+        r.render_rows(p, row0, rows, tiles[b].data_ptr(), stream.cuda_stream)
+        if world > 1:
+            glist = [frames[b][k * rows_per:(k + 1) * rows_per] for k in range(world)] if rank == 0 else None
+            pending[b] = dist.gather(tiles[b], glist, dst=0, async_op=True)
+
+    def drain() -> None:
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+        torch.cuda.synchronize()
+
+    def barrier() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    drain()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    t = r.last_timing()  # this rank's tile, last frame (every frame is identical)
+    kms = r.timing_history(min(args.steps, 200))
+    counts = torch.tensor([t["primary_rays"], t["shadow_rays"], t["primary_steps"], t["shadow_steps"], t["hits"]],
+                          dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    primary, shadow_rays, psteps, ssteps, hits = [float(x) for x in counts.tolist()]
+    rays_per_frame = primary + shadow_rays
+    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+    value = rays_per_frame * args.steps / elapsed / 1e6 if args.steps > 0 else 0.0
+
+    if rank == 0:
+        # roofline of the march kernel on THIS rank's tile: algorithmic bytes / mean
+        # kernel time from the hipEvent pairs recorded on the launch stream around every launch
+        alg_bytes = v.algorithmic_bytes(t)
+        k_ms = float(np.mean(kms)) if kms else float("nan")
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if kms else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload and tj.get("n_gpus") == world:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "kernel": "march_kernel", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+            "samples_per_launch": int(t["primary_steps"] + t["shadow_steps"]),
+        }
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(sc, p, args.cpu_seconds)
+        out = {
+            "metric": "Mrays/sec at 1080p, 256^3 SDF volume" if args.workload in ("c3", "c3sdf") else "Mrays/sec",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": label, "width": W, "height": H, "volume": f"{sc.volumes()[0].N - 1}^3 cells",
+                       "max_steps": max_steps, "shadow": bool(shadow), "data_path": args.path,
+                       "parallelism": f"row-tiles x{world}" + (" + RCCL gather" if world > 1 else ""),
+                       "rays_per_frame": int(rays_per_frame), "samples_per_ray": round((psteps + ssteps) / max(rays_per_frame, 1), 2)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+
+    r.Stop()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc, p, target_seconds: float):
+    """The scalar oracle (kind "port") on this host's cores, on a bounded sample of the same
+    workload: the same scene and parameters at reduced resolution (Mrays/s is
+    resolution-independent to first order)."""
+    from oracle.binding import OracleScene
+    from volumetricraytracer_amd import _abi
+
+    cores = os.cpu_count() or 1
+    o = OracleScene(sc)
+    q = _abi.vrt_params.from_buffer_copy(p)
+    # calibrate on 1/64 of the pixels, then size the sample to ~target_seconds
+    q.width, q.height = max(p.width // 8, 1), max(p.height // 8, 1)
+    t0 = time.perf_counter()
+    _, st = o.render(q, threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    rate = (st["primary_rays"] + st["shadow_rays"]) / dt
+    want = rate * target_seconds
+    scale = min(1.0, (want / max(p.width * p.height, 1)) ** 0.5)
+    q.width, q.height = max(int(p.width * scale), 1), max(int(p.height * scale), 1)
+    t0 = time.perf_counter()
+    _, st = o.render(q, threads=cores)
+    dt = time.perf_counter() - t0
+    rays = st["primary_rays"] + st["shadow_rays"]
+    t1 = time.perf_counter()
+    q1 = _abi.vrt_params.from_buffer_copy(q)
+    q1.width, q1.height = max(q.width // 4, 1), max(q.height // 4, 1)
+    _, st1 = o.render(q1, threads=1)
+    dt1 = time.perf_counter() - t1
+    return {
+        "value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": f"same scene and march parameters at {q.width}x{q.height} ({rays} rays, {dt:.1f} s on {cores} threads)",
+        "single_thread_value": round((st1["primary_rays"] + st1["shadow_rays"]) / dt1 / 1e6, 3),
+    }
+
+
+if __name__ == "__main__":
+    main()

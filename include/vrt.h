@@ -1,0 +1,217 @@
+/*
+ * vrt.h — C-ABI of the MI355X-native volumetric SDF ray-marcher.
+ *
+ * This is the drop-in boundary for the reference's renderer hot path.  Everything the
+ * reference's D3D12/DXR backend did behind `VRenderer` is reachable through these entry
+ * points; a C++ adaptor with the `VRenderer` shape (volumetricraytracer_amd/csrc/host/
+ * HipRenderer.h) is the only thing that calls them.  POD only, plain pointers and sizes.
+ *
+ * Reference interfaces replaced (paths relative to
+ * /root/reference/VolumetricRaytracer/VolumetricRaytracer/):
+ *   vrt_create / vrt_destroy        VDXRenderer::Start/Stop + SetupRenderer/DestroyRenderer
+ *                                   Renderer/DX/Private/DXRenderer.cpp:204-316, 68-100
+ *   vrt_volume_upload*              VDXVoxelVolume::UpdateFromVoxelVolume / UpdateVolumeTexture
+ *                                   Renderer/DX/Private/RDXVoxelVolume.cpp:33-60, 294-327
+ *   vrt_volume_set_material         VDXVoxelVolume::UpdateGeometryConstantBuffer  :368-397
+ *   vrt_volume_free                 VRDXScene::RemoveVoxelVolume  Renderer/DX/Private/RDXScene.cpp:663-701
+ *   vrt_env_upload                  VRDXScene::InitEnvironmentMap RDXScene.cpp:181-199
+ *   vrt_scene_set                   VRDXScene::SyncWithScene + PrepareForRendering
+ *                                   RDXScene.cpp:109-118, 150-174, 454-545, 703-755
+ *                                   VDXLevelObject::Update  Renderer/DX/Private/RDXLevelObject.cpp:29-48
+ *   vrt_render / vrt_render_rows    VDXRenderer::Render → DoRendering → DispatchRays(W,H,1)
+ *                                   DXRenderer.cpp:37-66, 827-867 (+ the HLSL entry points
+ *                                   Renderer/DX/Resources/Shaders/Raytracing.hlsl:26-455)
+ *   vrt_last_timing                 (no reference analogue; FPS counter Engine.cpp:250-262)
+ *
+ * Error convention: 0 = OK, negative = error.  The reference logs and returns early
+ * (DXRenderer.cpp:220-225); the adaptor maps negative codes onto that behaviour.
+ * Threading: not thread-safe per context (matches the reference's single engine-loop
+ * thread, Engine.cpp:201-227).  The caller owns all host buffers, the context owns all
+ * device memory.
+ */
+#ifndef VRT_H
+#define VRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRT_MAX_VOLUMES      20 /* MaxAllowedObjectData, Shaders/RaytracingHlsl.h:112 */
+#define VRT_MAX_POINT_LIGHTS 5  /* RaytracingHlsl.h:114 */
+#define VRT_MAX_SPOT_LIGHTS  5  /* RaytracingHlsl.h:113 */
+#define VRT_MAX_INSTANCES    64
+#define VRT_MAX_DEVICES      8
+
+enum vrt_status {
+    VRT_OK = 0,
+    VRT_ERR_INVALID = -1,     /* bad argument */
+    VRT_ERR_NO_DEVICE = -2,   /* no usable HIP device */
+    VRT_ERR_HIP = -3,         /* a HIP runtime call failed */
+    VRT_ERR_OOM = -4,
+    VRT_ERR_SLOT = -5,        /* volume slot out of range or empty */
+    VRT_ERR_NOT_READY = -6,   /* render without scene / volume */
+    VRT_ERR_UNSUPPORTED = -7  /* render mode not implemented (Cube* modes) */
+};
+
+/* EVRenderMode, Renderer/Public/Renderer.h:32-42 (same numeric values). */
+enum vrt_render_mode {
+    VRT_MODE_INTERP = 0,
+    VRT_MODE_INTERP_UNLIT = 1,
+    VRT_MODE_INTERP_NOTEX = 2,
+    VRT_MODE_INTERP_NOTEX_UNLIT = 3,
+    VRT_MODE_CUBE = 4,
+    VRT_MODE_CUBE_UNLIT = 5,
+    VRT_MODE_CUBE_NOTEX = 6,
+    VRT_MODE_CUBE_NOTEX_UNLIT = 7
+};
+
+/* Which device data path the march uses.  All paths produce bit-identical pixels. */
+enum vrt_data_path {
+    VRT_PATH_AUTO = 0,
+    VRT_PATH_DENSE = 1,       /* taps from the dense N^3 grid in global memory */
+    VRT_PATH_BRICK = 2,       /* taps from 4^3-cell (5^3-sample) bricks in global memory */
+    VRT_PATH_BRICK_LDS = 3    /* bricks staged through a per-wave LDS brick cache */
+};
+
+/* Host/disk layout of one voxel: VVoxel, Voxel/Public/Voxel.h:23-30 (8 bytes). */
+typedef struct vrt_voxel {
+    uint8_t material;
+    uint8_t pad_[3];
+    float density;
+} vrt_voxel;
+
+/* VMaterial scalars that reach the GPU: VGeometryConstantBuffer, RaytracingHlsl.h:86-100.
+ * Defaults Core/Public/Material.h:25-27: tint (0.8,0.8,0.8,1), roughness 0.8, metallic 0. */
+typedef struct vrt_material {
+    float tint[4];
+    float roughness;
+    float metallic;
+} vrt_material;
+
+/* One placed VVoxelObject: VDXLevelObject::Update, RDXLevelObject.cpp:29-48.
+ * rotation is a quaternion in x,y,z,w order (Eigen storage order, Core/Private/Quat.cpp:98-116).
+ * object→world is  p_w = scale ∘ (rotation · p_o) + position  (DirectXMath `rotation*scale*translation`). */
+typedef struct vrt_instance {
+    int32_t volume_slot;
+    float position[3];
+    float rotation[4];
+    float scale[3];
+} vrt_instance;
+
+/* VPointLightBuffer / VSpotLightBuffer, RaytracingHlsl.h:64-84; DXLightFactory.cpp:20-50. */
+typedef struct vrt_point_light {
+    float position[3];
+    float color[3];
+    float intensity;
+    float att_linear;
+    float att_exp;
+} vrt_point_light;
+
+typedef struct vrt_spot_light {
+    float position[3];
+    float forward[3];
+    float color[3];
+    float intensity;
+    float att_linear;
+    float att_exp;
+    float cos_angle;          /* cos(Angle/2) */
+    float cos_falloff_angle;  /* cos(FalloffAngle/2) */
+} vrt_spot_light;
+
+/* VSceneConstantBuffer + TLAS instance list: RaytracingHlsl.h:53-62, RDXScene.cpp:454-545,703-724. */
+typedef struct vrt_scene {
+    float cam_position[3];
+    float cam_rotation[4];   /* quaternion x,y,z,w; forward = q·(+X), up = q·(+Z)  (Core/Private/Vector.cpp:42-46) */
+    float cam_fov_deg;       /* vertical FOV, Scene/Public/Camera.h:29 (default 60) */
+    float cam_near;          /* :30 (0.01) — carried for completeness, unused by ray generation */
+    float cam_far;           /* :31 (125)  — idem */
+    float light_dir[3];      /* directional light: unit vector *towards* the light (RDXScene.cpp:720-723) */
+    float light_strength;
+    int32_t n_instances;
+    int32_t n_point_lights;
+    int32_t n_spot_lights;
+    int32_t pad_;
+    vrt_instance instances[VRT_MAX_INSTANCES];
+    vrt_point_light point_lights[VRT_MAX_POINT_LIGHTS];
+    vrt_spot_light spot_lights[VRT_MAX_SPOT_LIGHTS];
+} vrt_scene;
+
+/* Per-frame render parameters (DispatchRays dimensions + the march contract of DESIGN.md §3). */
+typedef struct vrt_params {
+    int32_t width;
+    int32_t height;
+    int32_t max_steps;    /* march budget per (ray, instance); reference budget: 255 (Raytracing.hlsl:229) */
+    int32_t shadow;       /* 1 = cast the directional-light shadow ray (Raytracing.hlsl:52-59) */
+    int32_t mode;         /* vrt_render_mode */
+    int32_t path;         /* vrt_data_path */
+    int32_t max_bounces;  /* mirror-reflection depth, 0..2 (MAX_RAY_RECURSION_DEPTH 3 = primary + 2) */
+    int32_t flags;        /* reserved, 0 */
+    float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
+    float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
+    float step_min;       /* lower bound of one march step (ray-parameter units) */
+    float k_relax;        /* sphere-trace relaxation factor, <= 1 */
+} vrt_params;
+
+typedef struct vrt_timing {
+    float kernel_ms;         /* march kernel, hipEvent pair on the launch stream */
+    float gather_ms;         /* multi-device tile gather (0 for one device) */
+    float total_ms;          /* launch → image available */
+    uint32_t width, height;
+    uint64_t primary_rays;
+    uint64_t shadow_rays;    /* shadow rays actually cast (all lights) */
+    uint64_t bounce_rays;    /* mirror-reflection rays actually cast */
+    uint64_t primary_steps;  /* trilinear samples taken by primary + bounce rays */
+    uint64_t shadow_steps;   /* trilinear samples taken by shadow rays */
+    uint64_t hits;           /* radiance hits (each costs 6 extra trilinear samples for the normal) */
+} vrt_timing;
+
+typedef struct vrt_ctx vrt_ctx;
+
+/* device_count >= 1; devices[i] are HIP ordinals.  One context may drive 1..8 devices: the
+ * framebuffer is split into contiguous row tiles, volumes are replicated. */
+int vrt_create(vrt_ctx** out, int device_count, const int* devices);
+int vrt_destroy(vrt_ctx* ctx);
+
+/* density: N^3 floats, N = 2^resolution + 1, index = x*N*N + z*N + y
+ * (Core/Private/MathHelpers (2).cpp:43-46).  material_or_null: N^3 bytes, same indexing. */
+int vrt_volume_upload(vrt_ctx* ctx, int slot, uint8_t resolution, float extent,
+                      const float* density, const uint8_t* material_or_null);
+/* Same, straight from VVoxelVolume's storage (std::vector<VVoxel>, 8 B records). */
+int vrt_volume_upload_voxels(vrt_ctx* ctx, int slot, uint8_t resolution, float extent,
+                             const vrt_voxel* voxels);
+int vrt_volume_set_material(vrt_ctx* ctx, int slot, const vrt_material* material);
+/* density_scale: object-space length of one density unit (1 for metric SDFs; the Voxelizer's
+ * extraction threshold for its shell volumes).  step_max: largest object-space step that is
+ * safe to take from any sample (<= 0: unbounded). */
+int vrt_volume_set_metric(vrt_ctx* ctx, int slot, float density_scale, float step_max);
+int vrt_volume_free(vrt_ctx* ctx, int slot);
+
+/* 6 faces (+X,-X,+Y,-Y,+Z,-Z), each face_size^2 RGBA8, row-major, D3D cube-face orientation.
+ * NULL / 0 removes the environment (misses read black, like an unbound SRV). */
+int vrt_env_upload(vrt_ctx* ctx, int face_size, const uint8_t* rgba8_faces);
+
+int vrt_scene_set(vrt_ctx* ctx, const vrt_scene* scene);
+
+/* Render the whole frame.  host_rgba_or_null: width*height float4 (RGBA, alpha 1), row-major. */
+int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null);
+/* Render rows [row0, row0+rows) of the frame on the context's first device into a caller-owned
+ * *device* buffer of rows*width float4, asynchronously on `hip_stream` (a hipStream_t, may be
+ * NULL).  No host synchronisation, no allocation: safe to capture into a hipGraph. */
+int vrt_render_rows(vrt_ctx* ctx, const vrt_params* params, int row0, int rows,
+                    void* device_rgba, void* hip_stream);
+
+int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out);
+/* Kernel durations (ms) of the last n vrt_render_rows/vrt_render launches, oldest first;
+ * returns how many were written (<= n), or a negative status. */
+int vrt_timing_history(vrt_ctx* ctx, int n, float* kernel_ms_out);
+
+const char* vrt_strerror(int status);
+/* "x.y.z gfx950" */
+const char* vrt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRT_H */

@@ -1,0 +1,145 @@
+"""ctypes binding of the CPU oracle (oracle/_build/libvrt_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg — never from volumetricraytracer_amd/.  PARITY UNPINNED by reference tests
+(the reference has none); see vrt_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Tuple
+
+import numpy as np
+
+from volumetricraytracer_amd import _abi
+from volumetricraytracer_amd.scene import VScene
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libvrt_oracle.so")
+
+
+class vrto_volume(C.Structure):
+    _fields_ = [
+        ("density", C.c_void_p),
+        ("resolution", C.c_int32),
+        ("extent", C.c_float),
+        ("density_scale", C.c_float),
+        ("step_max", C.c_float),
+        ("material", _abi.vrt_material),
+    ]
+
+
+class vrto_stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("primary_rays", "shadow_rays", "bounce_rays", "primary_steps", "shadow_steps", "hits")]
+
+
+_lib = None
+
+
+def build() -> None:
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        lib = C.CDLL(LIB_PATH)
+        lib.vrto_render.restype = C.c_int
+        lib.vrto_render.argtypes = [C.POINTER(_abi.vrt_scene), C.POINTER(vrto_volume), C.c_void_p, C.c_int,
+                                    C.POINTER(_abi.vrt_params), C.c_int, C.c_int, C.c_void_p,
+                                    C.POINTER(vrto_stats), C.c_int]
+        lib.vrto_trace.restype = C.c_int
+        lib.vrto_trace.argtypes = [C.POINTER(_abi.vrt_scene), C.POINTER(vrto_volume), C.POINTER(_abi.vrt_params),
+                                   C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float),
+                                   C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.vrto_camera_ray.restype = None
+        lib.vrto_camera_ray.argtypes = [C.POINTER(_abi.vrt_scene), C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.vrto_sample.restype = C.c_float
+        lib.vrto_sample.argtypes = [C.POINTER(vrto_volume), C.POINTER(C.c_float)]
+        lib.vrto_ref_hit_t.restype = C.c_int
+        lib.vrto_ref_hit_t.argtypes = [C.POINTER(vrto_volume), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                       C.POINTER(C.c_double)]
+        lib.vrto_env_lookup.restype = None
+        lib.vrto_env_lookup.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        _lib = lib
+    return _lib
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+class OracleScene:
+    """Holds the ctypes image of a VScene (+ keeps the numpy buffers alive)."""
+
+    def __init__(self, scene: VScene):
+        self.scene = scene
+        self.abi = scene.to_abi()
+        self.vols = (vrto_volume * _abi.VRT_MAX_VOLUMES)()
+        self._keep = []
+        for slot, v in enumerate(scene.volumes()):
+            d = np.ascontiguousarray(v.density, dtype=np.float32)
+            self._keep.append(d)
+            o = self.vols[slot]
+            o.density = d.ctypes.data
+            o.resolution = v.Resolution
+            o.extent = v.VolumeExtends
+            o.density_scale = v.density_scale
+            o.step_max = v.step_max
+            o.material = v.Material.to_abi()
+        self.env = None
+        self.env_size = 0
+        if scene.EnvironmentMap is not None:
+            self.env = np.ascontiguousarray(scene.EnvironmentMap, dtype=np.uint8)
+            self.env_size = int(self.env.shape[1])
+
+    def render(self, params: _abi.vrt_params, row0: int = 0, rows: Optional[int] = None,
+               threads: int = 1) -> Tuple[np.ndarray, dict]:
+        lib = load()
+        rows = params.height - row0 if rows is None else rows
+        out = np.empty((rows, params.width, 4), dtype=np.float32)
+        st = vrto_stats()
+        rc = lib.vrto_render(C.byref(self.abi), self.vols, self.env.ctypes.data if self.env is not None else None,
+                             self.env_size, C.byref(params), row0, rows, out.ctypes.data, C.byref(st), threads)
+        if rc != 0:
+            raise RuntimeError(f"vrto_render failed: {rc}")
+        return out, {n: getattr(st, n) for n, _ in st._fields_}
+
+    def trace(self, params: _abi.vrt_params, origin, direction, t_max: float = 10000.0):
+        lib = load()
+        t = C.c_float()
+        n = (C.c_float * 3)()
+        inst = C.c_int(-1)
+        steps = C.c_int()
+        hit = lib.vrto_trace(C.byref(self.abi), self.vols, C.byref(params), _f3(origin), _f3(direction), t_max,
+                             C.byref(t), n, C.byref(inst), C.byref(steps))
+        if hit < 0:
+            raise RuntimeError(f"vrto_trace failed: {hit}")
+        return bool(hit), t.value, np.array(list(n), dtype=np.float32), inst.value, steps.value
+
+    def camera_ray(self, width: int, height: int, px: int, py: int):
+        lib = load()
+        o, d = (C.c_float * 3)(), (C.c_float * 3)()
+        lib.vrto_camera_ray(C.byref(self.abi), width, height, px, py, o, d)
+        return np.array(list(o), dtype=np.float32), np.array(list(d), dtype=np.float32)
+
+    def sample(self, slot: int, p) -> float:
+        return float(load().vrto_sample(C.byref(self.vols[slot]), _f3(p)))
+
+    def ref_hit_t(self, slot: int, origin, direction):
+        t = C.c_double()
+        hit = load().vrto_ref_hit_t(C.byref(self.vols[slot]), _f3(origin), _f3(direction), C.byref(t))
+        return bool(hit), t.value
+
+
+def env_lookup(env: np.ndarray, direction) -> np.ndarray:
+    e = np.ascontiguousarray(env, dtype=np.uint8)
+    out = (C.c_float * 3)()
+    load().vrto_env_lookup(e.ctypes.data, int(e.shape[1]), _f3(direction), out)
+    return np.array(list(out), dtype=np.float32)

@@ -1,0 +1,797 @@
+/*
+ * vrt_oracle.cpp — scalar CPU restatement of the ray-march hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see vrt_oracle.h).  Plain C++17, no dependencies, fp32 with
+ * contraction disabled at compile time (-ffp-contract=off) and FMA written explicitly as
+ * fmaf() where the march contract says so.
+ *
+ * PARITY UNPINNED by reference tests (the reference has none); pinned by
+ * analytic ground truth and by vrto_ref_hit_t below.
+ *
+ * Reference lines each function follows (paths relative to
+ * /root/reference/VolumetricRaytracer/VolumetricRaytracer/, SH = Renderer/DX/Resources/Shaders):
+ *   quat_to_mat        Core/Private/Quat.cpp:28-33,91-95 (Eigen Quaternionf rotate, closed form)
+ *   camera_basis       Renderer/DX/Private/RDXScene.cpp:703-724 (XMMatrixLookToRH / PerspectiveFovRH)
+ *   camera_ray         SH/Include/Ray.hlsli:36-48 (+ normalisation, DESIGN.md §3 deviation)
+ *   build_instance     Renderer/DX/Private/RDXLevelObject.cpp:38-47 (rotation*scale*translation)
+ *   slab               SH/Include/Ray.hlsli:111-134
+ *   voxel indexing     Core/Private/MathHelpers (2).cpp:43-46, Voxel/Private/VoxelVolume.cpp:19-27,139-146
+ *   trilinear          SH/Include/Voxel.hlsli:607-684 (same interpolant, nested-lerp evaluation)
+ *   normal             SH/Include/Voxel.hlsli:783-804; entry-face normal SH/Raytracing.hlsl:198-226
+ *   march              replaces SH/Raytracing.hlsl:147-336 (sphere-trace per BASELINE.json north_star)
+ *   shade              SH/Raytracing_NoTex.hlsl:41-139, SH/Include/Lighting.hlsli:17-101, Constants.hlsli:15-17
+ *   env_lookup         SH/Raytracing.hlsl:444-449 (SampleLevel(dir.xzy), point sampler RDXScene.cpp:188-197)
+ *   tone-map           SH/Raytracing.hlsl:34-38
+ */
+#include "vrt_oracle.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct V3 {
+    float x, y, z;
+};
+
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline V3 normalize(V3 a) {
+    float inv = 1.0f / sqrtf(dot(a, a));
+    return a * inv;
+}
+inline float maxf(float a, float b) { return a > b ? a : b; }
+inline float minf(float a, float b) { return a < b ? a : b; }
+
+struct M3 {
+    float m[3][3];
+};
+inline V3 mul(const M3& M, V3 v) {
+    return v3((M.m[0][0] * v.x + M.m[0][1] * v.y) + M.m[0][2] * v.z,
+              (M.m[1][0] * v.x + M.m[1][1] * v.y) + M.m[1][2] * v.z,
+              (M.m[2][0] * v.x + M.m[2][1] * v.y) + M.m[2][2] * v.z);
+}
+
+/* Rotation matrix of a unit quaternion (x,y,z,w), column-vector convention v' = R v. */
+M3 quat_to_mat(const float q[4]) {
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    float xx = x * x, yy = y * y, zz = z * z;
+    float xy = x * y, xz = x * z, yz = y * z;
+    float wx = w * x, wy = w * y, wz = w * z;
+    M3 R;
+    R.m[0][0] = 1.0f - 2.0f * (yy + zz);
+    R.m[0][1] = 2.0f * (xy - wz);
+    R.m[0][2] = 2.0f * (xz + wy);
+    R.m[1][0] = 2.0f * (xy + wz);
+    R.m[1][1] = 1.0f - 2.0f * (xx + zz);
+    R.m[1][2] = 2.0f * (yz - wx);
+    R.m[2][0] = 2.0f * (xz - wy);
+    R.m[2][1] = 2.0f * (yz + wx);
+    R.m[2][2] = 1.0f - 2.0f * (xx + yy);
+    return R;
+}
+
+struct Camera {
+    V3 origin;
+    V3 r0, r1, r2; /* view-space x, y, z axes in world space (LookToRH rows) */
+    float cx, cy;  /* aspect*tan(fov/2), tan(fov/2) */
+};
+
+Camera camera_basis(const vrt_scene* s, int width, int height) {
+    Camera c;
+    M3 R = quat_to_mat(s->cam_rotation);
+    V3 fwd = v3(R.m[0][0], R.m[1][0], R.m[2][0]); /* R * (+X) */
+    V3 up = v3(R.m[0][2], R.m[1][2], R.m[2][2]);  /* R * (+Z) */
+    c.origin = v3(s->cam_position[0], s->cam_position[1], s->cam_position[2]);
+    c.r2 = normalize(v3(-fwd.x, -fwd.y, -fwd.z));
+    c.r0 = normalize(cross(up, c.r2));
+    c.r1 = cross(c.r2, c.r0);
+    float aspect = (float)width / (float)height;
+    float half = tanf(s->cam_fov_deg * (3.14159265358979323846f / 180.0f) * 0.5f);
+    c.cx = aspect * half;
+    c.cy = half;
+    return c;
+}
+
+inline void camera_ray(const Camera& c, int width, int height, int px, int py, V3& o, V3& d) {
+    float sx = (((float)px + 0.5f) / (float)width) * 2.0f - 1.0f;
+    float sy = (((float)py + 0.5f) / (float)height) * 2.0f - 1.0f;
+    float tx = sx * c.cx;
+    float ty = (-sy) * c.cy;
+    V3 dir = v3((tx * c.r0.x + ty * c.r1.x) - c.r2.x,
+                (tx * c.r0.y + ty * c.r1.y) - c.r2.y,
+                (tx * c.r0.z + ty * c.r1.z) - c.r2.z);
+    o = c.origin;
+    d = normalize(dir);
+}
+
+struct Volume {
+    const float* den;
+    int N;
+    float extent, cell, inv_cell, density_scale, step_max;
+    float tint[3], roughness, metallic, k;
+};
+
+struct Instance {
+    int slot;
+    M3 o2w;  /* S * R   */
+    M3 w2o;  /* R^T * S^-1 */
+    V3 pos;
+};
+
+struct Packed {
+    Camera cam;
+    Volume vol[VRT_MAX_VOLUMES];
+    Instance inst[VRT_MAX_INSTANCES];
+    int n_inst;
+    const uint8_t* env;
+    int env_size;
+    V3 light_dir;
+    float light_strength;
+    const vrt_scene* scene;
+    vrt_params prm;
+};
+
+Instance build_instance(const vrt_instance& in) {
+    Instance r;
+    M3 R = quat_to_mat(in.rotation);
+    for (int i = 0; i < 3; i++) {
+        float inv_sj[3] = {1.0f / in.scale[0], 1.0f / in.scale[1], 1.0f / in.scale[2]};
+        for (int j = 0; j < 3; j++) {
+            r.o2w.m[i][j] = in.scale[i] * R.m[i][j];
+            r.w2o.m[i][j] = R.m[j][i] * inv_sj[j];
+        }
+    }
+    r.pos = v3(in.position[0], in.position[1], in.position[2]);
+    r.slot = in.volume_slot;
+    return r;
+}
+
+bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env, int env_size,
+          const vrt_params* prm, Packed& P) {
+    if (!scene || !volumes || !prm) return false;
+    if (prm->width <= 0 || prm->height <= 0) return false;
+    if (scene->n_instances < 0 || scene->n_instances > VRT_MAX_INSTANCES) return false;
+    P.cam = camera_basis(scene, prm->width, prm->height);
+    for (int i = 0; i < VRT_MAX_VOLUMES; i++) {
+        Volume& v = P.vol[i];
+        const vrto_volume& s = volumes[i];
+        v.den = s.density;
+        if (!s.density) continue;
+        v.N = (1 << s.resolution) + 1;
+        v.extent = s.extent;
+        v.cell = (s.extent * 2.0f) / (float)(v.N - 1);
+        v.inv_cell = 1.0f / v.cell;
+        v.density_scale = s.density_scale;
+        v.step_max = s.step_max > 0.0f ? s.step_max : std::numeric_limits<float>::infinity();
+        v.tint[0] = s.material.tint[0];
+        v.tint[1] = s.material.tint[1];
+        v.tint[2] = s.material.tint[2];
+        v.roughness = minf(maxf(s.material.roughness, 0.0f), 1.0f);
+        v.metallic = minf(maxf(s.material.metallic, 0.0f), 1.0f);
+        float r1 = s.material.roughness + 1.0f;
+        v.k = (r1 * r1) / 8.0f; /* RDXVoxelVolume.cpp:383, from the unclamped roughness */
+    }
+    P.n_inst = scene->n_instances;
+    for (int i = 0; i < P.n_inst; i++) {
+        int slot = scene->instances[i].volume_slot;
+        if (slot < 0 || slot >= VRT_MAX_VOLUMES || !volumes[slot].density) return false;
+        P.inst[i] = build_instance(scene->instances[i]);
+    }
+    P.env = env;
+    P.env_size = env ? env_size : 0;
+    P.light_dir = v3(scene->light_dir[0], scene->light_dir[1], scene->light_dir[2]);
+    P.light_strength = scene->light_strength;
+    P.scene = scene;
+    P.prm = *prm;
+    return true;
+}
+
+inline float lerp1(float a, float b, float w) { return fmaf(w, b - a, a); }
+
+/* Trilinear interpolant of cell (cx,cy,cz) at fractional position (fx,fy,fz). */
+inline float trilinear(const Volume& v, int cx, int cy, int cz, float fx, float fy, float fz) {
+    const size_t N = (size_t)v.N;
+    const float* b0 = v.den + ((size_t)cx * N + (size_t)cz) * N + (size_t)cy; /* x0, z0 */
+    const float* b1 = b0 + N;                                                  /* x0, z1 */
+    const float* b2 = b0 + N * N;                                              /* x1, z0 */
+    const float* b3 = b2 + N;                                                  /* x1, z1 */
+    float a00 = lerp1(b0[0], b0[1], fy);
+    float a01 = lerp1(b1[0], b1[1], fy);
+    float a10 = lerp1(b2[0], b2[1], fy);
+    float a11 = lerp1(b3[0], b3[1], fy);
+    float c0 = lerp1(a00, a01, fz);
+    float c1 = lerp1(a10, a11, fz);
+    return lerp1(c0, c1, fx);
+}
+
+struct Stats {
+    uint64_t primary_rays = 0, shadow_rays = 0, bounce_rays = 0;
+    uint64_t primary_steps = 0, shadow_steps = 0, hits = 0;
+};
+
+struct HitRec {
+    float t;
+    int inst;
+    V3 n_world;
+};
+
+/* Ray-box slab test, box = [-e,+e]^3, inf-safe reciprocals. */
+inline bool slab(V3 o, V3 d, float e, float t_cur, float& t_enter, float& t_exit) {
+    const float inf = std::numeric_limits<float>::infinity();
+    float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    float tmin[3], tmax[3];
+    for (int a = 0; a < 3; a++) {
+        bool pos = dd[a] > 0.0f;
+        float inv = dd[a] != 0.0f ? 1.0f / dd[a] : (pos ? inf : -inf);
+        float lo = pos ? -e : e;
+        float hi = pos ? e : -e;
+        tmin[a] = (lo - oo[a]) * inv;
+        tmax[a] = (hi - oo[a]) * inv;
+    }
+    t_enter = maxf(maxf(tmin[0], tmin[1]), tmin[2]);
+    t_exit = minf(minf(tmax[0], tmax[1]), tmax[2]);
+    return t_exit > t_enter && t_exit >= 0.0f && t_enter <= t_cur;
+}
+
+/* March one instance.  Returns true on hit with t (ray parameter, shared with world space). */
+bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, bool want_normal,
+                    float& t_hit, V3& n_world, uint64_t& steps) {
+    const Instance& I = P.inst[ii];
+    const Volume& V = P.vol[I.slot];
+    V3 oo = mul(I.w2o, o - I.pos);
+    V3 od = mul(I.w2o, d);
+    float t_enter, t_exit;
+    if (!slab(oo, od, V.extent, t_cur, t_enter, t_exit)) return false;
+
+    float inv_len = 1.0f / sqrtf(dot(od, od));
+    float ds = V.density_scale * inv_len;
+    float smax = V.step_max * inv_len;
+    /* ray in voxel units */
+    V3 uo = v3((oo.x + V.extent) * V.inv_cell, (oo.y + V.extent) * V.inv_cell, (oo.z + V.extent) * V.inv_cell);
+    V3 ud = od * V.inv_cell;
+    const float cmax = (float)(V.N - 2);
+
+    float t = (t_enter > 0.0f ? t_enter : 0.0f) + P.prm.eps_in;
+    float t_end = minf(t_exit, t_cur);
+    for (int i = 0; i < P.prm.max_steps; i++) {
+        if (t > t_end) return false;
+        float ux = fmaf(ud.x, t, uo.x), uy = fmaf(ud.y, t, uo.y), uz = fmaf(ud.z, t, uo.z);
+        float cxf = minf(maxf(floorf(ux), 0.0f), cmax);
+        float cyf = minf(maxf(floorf(uy), 0.0f), cmax);
+        float czf = minf(maxf(floorf(uz), 0.0f), cmax);
+        float fx = ux - cxf, fy = uy - cyf, fz = uz - czf;
+        int cx = (int)cxf, cy = (int)cyf, cz = (int)czf;
+        float s = trilinear(V, cx, cy, cz, fx, fy, fz) * ds;
+        steps++;
+        if (s < P.prm.eps_hit) {
+            t_hit = t;
+            if (want_normal) {
+                V3 n;
+                if (i == 0 && t_enter >= 0.0f) {
+                    /* surface cut by the volume boundary: AABB-face normal (Raytracing.hlsl:198-226) */
+                    float tb = t_enter - 0.1f;
+                    V3 rp = v3(fmaf(od.x, tb, oo.x), fmaf(od.y, tb, oo.y), fmaf(od.z, tb, oo.z));
+                    float e = V.extent;
+                    n.x = rp.x > e ? 1.0f : (rp.x < -e ? -1.0f : 0.0f);
+                    n.y = rp.y > e ? 1.0f : (rp.y < -e ? -1.0f : 0.0f);
+                    n.z = rp.z > e ? 1.0f : (rp.z < -e ? -1.0f : 0.0f);
+                } else {
+                    int N2 = V.N - 2;
+                    int xp = cx + 1 > N2 ? N2 : cx + 1, xm = cx - 1 < 0 ? 0 : cx - 1;
+                    int yp = cy + 1 > N2 ? N2 : cy + 1, ym = cy - 1 < 0 ? 0 : cy - 1;
+                    int zp = cz + 1 > N2 ? N2 : cz + 1, zm = cz - 1 < 0 ? 0 : cz - 1;
+                    n.x = trilinear(V, xp, cy, cz, fx, fy, fz) - trilinear(V, xm, cy, cz, fx, fy, fz);
+                    n.y = trilinear(V, cx, yp, cz, fx, fy, fz) - trilinear(V, cx, ym, cz, fx, fy, fz);
+                    n.z = trilinear(V, cx, cy, zp, fx, fy, fz) - trilinear(V, cx, cy, zm, fx, fy, fz);
+                }
+                float l2 = dot(n, n);
+                if (!(l2 > 0.0f)) { /* zero or NaN gradient → (0,0,0) (Voxel.hlsli:794-798) */
+                    n = v3(0.0f, 0.0f, 0.0f);
+                } else {
+                    n = n * (1.0f / sqrtf(l2));
+                }
+                n_world = mul(I.o2w, n);
+            }
+            return true;
+        }
+        float adv = s * P.prm.k_relax;
+        adv = adv > smax ? smax : adv;
+        adv = adv < P.prm.step_min ? P.prm.step_min : adv;
+        t = t + adv;
+    }
+    return false;
+}
+
+/* Closest hit over all instances (ascending index; strict '<' keeps the lower index on ties). */
+bool trace_closest(const Packed& P, V3 o, V3 d, float t_max, HitRec& h, uint64_t& steps) {
+    bool any = false;
+    float best = t_max;
+    for (int i = 0; i < P.n_inst; i++) {
+        float t;
+        V3 n;
+        if (march_instance(P, i, o, d, best, true, t, n, steps)) {
+            if (!any || t < best) {
+                any = true;
+                best = t;
+                h.t = t;
+                h.inst = i;
+                h.n_world = n;
+            }
+        }
+    }
+    return any;
+}
+
+bool trace_any(const Packed& P, V3 o, V3 d, float t_max, uint64_t& steps) {
+    for (int i = 0; i < P.n_inst; i++) {
+        float t;
+        V3 n;
+        if (march_instance(P, i, o, d, t_max, false, t, n, steps)) return true;
+    }
+    return false;
+}
+
+void env_lookup(const uint8_t* env, int S, V3 dir, float rgb[3]) {
+    if (!env || S <= 0) {
+        rgb[0] = rgb[1] = rgb[2] = 0.0f;
+        return;
+    }
+    /* SampleLevel(dir.xzy) */
+    float vx = dir.x, vy = dir.z, vz = dir.y;
+    float ax = fabsf(vx), ay = fabsf(vy), az = fabsf(vz);
+    int face;
+    float sc, tc, ma;
+    if (ax >= ay && ax >= az) {
+        ma = ax;
+        if (vx >= 0.0f) { face = 0; sc = -vz; tc = -vy; }
+        else            { face = 1; sc = vz;  tc = -vy; }
+    } else if (ay >= az) {
+        ma = ay;
+        if (vy >= 0.0f) { face = 2; sc = vx; tc = vz; }
+        else            { face = 3; sc = vx; tc = -vz; }
+    } else {
+        ma = az;
+        if (vz >= 0.0f) { face = 4; sc = vx;  tc = -vy; }
+        else            { face = 5; sc = -vx; tc = -vy; }
+    }
+    float u = (sc / ma + 1.0f) * 0.5f;
+    float v = (tc / ma + 1.0f) * 0.5f;
+    int ix = (int)floorf(u * (float)S);
+    int iy = (int)floorf(v * (float)S);
+    ix = ix < 0 ? 0 : (ix > S - 1 ? S - 1 : ix);
+    iy = iy < 0 ? 0 : (iy > S - 1 ? S - 1 : iy);
+    const uint8_t* px = env + (((size_t)face * S + iy) * S + ix) * 4;
+    const float k = 1.0f / 255.0f;
+    rgb[0] = (float)px[0] * k;
+    rgb[1] = (float)px[1] * k;
+    rgb[2] = (float)px[2] * k;
+}
+
+const float PI_REF = 3.141592f; /* Constants.hlsli:15 */
+
+/* Radiance(), Lighting.hlsli:50-101 (note F enters twice: inside cook and as its multiplier). */
+void radiance(V3 Li, V3 wi, V3 wo, V3 n, V3 albedo, float rough, float metal, float k, V3& out) {
+    V3 hv = wi + wo;
+    V3 h = normalize(hv);
+    V3 f0 = v3(0.04f + (albedo.x - 0.04f) * metal, 0.04f + (albedo.y - 0.04f) * metal, 0.04f + (albedo.z - 0.04f) * metal);
+    float a2 = rough * rough;
+    float ndoth = maxf(dot(n, h), 0.0f);
+    float c = (ndoth * ndoth) * (a2 - 1.0f) + 1.0f;
+    float D = a2 / maxf((PI_REF * c) * c, 0.001f);
+    float wdoth = maxf(dot(wo, h), 0.0f);
+    float m = maxf(-wdoth + 1.0f, 0.0f);
+    float m2 = m * m;
+    float m5 = (m2 * m2) * m;
+    V3 F = v3(f0.x + (-f0.x + 1.0f) * m5, f0.y + (-f0.y + 1.0f) * m5, f0.z + (-f0.z + 1.0f) * m5);
+    float dwo = maxf(dot(n, wo), 0.0f);
+    float dwi = maxf(dot(n, wi), 0.0f);
+    float G = (dwo / (dwo * (1.0f - k) + k)) * (dwi / (dwi * (1.0f - k) + k));
+    float den = maxf((4.0f * dwo) * dwi, 0.0001f);
+    V3 cook = v3(((D * F.x) * G) / den, ((D * F.y) * G) / den, ((D * F.z) * G) / den);
+    float km = 1.0f - metal;
+    V3 kd = v3((1.0f - F.x) * km, (1.0f - F.y) * km, (1.0f - F.z) * km);
+    V3 brdf = v3((albedo.x / PI_REF) * kd.x + cook.x * F.x,
+                 (albedo.y / PI_REF) * kd.y + cook.y * F.y,
+                 (albedo.z / PI_REF) * kd.z + cook.z * F.z);
+    float ndwi = dot(n, wi);
+    out = v3((brdf.x * Li.x) * ndwi, (brdf.y * Li.y) * ndwi, (brdf.z * Li.z) * ndwi);
+}
+
+const int MAX_DEPTH = 3; /* MAX_RAY_RECURSION_DEPTH, RaytracingHlsl.h:32 */
+
+/* TraceRadianceRay + VRClosestHit / VRMiss, level = 1 for the primary ray. */
+V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, Stats& st) {
+    HitRec h;
+    uint64_t steps = 0;
+    bool hit = trace_closest(P, o, d, 10000.0f, h, steps);
+    st.primary_steps += steps;
+    if (!hit) {
+        float rgb[3];
+        env_lookup(P.env, P.env_size, d, rgb);
+        return v3(rgb[0], rgb[1], rgb[2]);
+    }
+    st.hits++;
+    const Volume& V = P.vol[P.inst[h.inst].slot];
+    V3 albedo = v3(V.tint[0], V.tint[1], V.tint[2]);
+    int mode = P.prm.mode;
+    if (mode == VRT_MODE_INTERP_UNLIT || mode == VRT_MODE_INTERP_NOTEX_UNLIT) return albedo;
+
+    V3 hit_pos = v3(fmaf(d.x, h.t, o.x), fmaf(d.y, h.t, o.y), fmaf(d.z, h.t, o.z));
+    V3 so = v3(hit_pos.x - d.x * 0.1f, hit_pos.y - d.y * 0.1f, hit_pos.z - d.z * 0.1f);
+    V3 wo = v3(-d.x, -d.y, -d.z);
+    V3 n = h.n_world;
+    bool shadows = level < MAX_DEPTH; /* TraceShadowRay's recursion guard, Ray.hlsli:83-86 */
+    V3 diffuse = v3(0.0f, 0.0f, 0.0f); /* SHADOW_BRIGHTNESS */
+
+    if (V.roughness < 0.3f && level <= P.prm.max_bounces && level < MAX_DEPTH) {
+        float dn = dot(d, n);
+        V3 rd = normalize(v3(d.x - (2.0f * dn) * n.x, d.y - (2.0f * dn) * n.y, d.z - (2.0f * dn) * n.z));
+        st.bounce_rays++;
+        V3 rc = radiance_ray(P, so, rd, level + 1, st);
+        float fade = V.roughness * 2.2f;
+        rc = v3(maxf(0.0f, rc.x + (0.0f - rc.x) * fade), maxf(0.0f, rc.y + (0.0f - rc.y) * fade),
+                maxf(0.0f, rc.z + (0.0f - rc.z) * fade));
+        V3 r;
+        radiance(rc, rd, wo, n, albedo, V.roughness, V.metallic, V.k, r);
+        diffuse = diffuse + r;
+    }
+
+    bool shadowed = false;
+    if (P.prm.shadow && shadows) {
+        st.shadow_rays++;
+        uint64_t ss = 0;
+        shadowed = trace_any(P, so, P.light_dir, 5000.0f, ss);
+        st.shadow_steps += ss;
+    }
+    if (!shadowed) {
+        V3 r;
+        V3 Li = v3(P.light_strength, P.light_strength, P.light_strength);
+        radiance(Li, P.light_dir, wo, n, albedo, V.roughness, V.metallic, V.k, r);
+        diffuse = diffuse + r;
+    }
+
+    const vrt_scene* S = P.scene;
+    int npl = S->n_point_lights < VRT_MAX_POINT_LIGHTS ? S->n_point_lights : VRT_MAX_POINT_LIGHTS;
+    for (int i = 0; i < npl; i++) {
+        const vrt_point_light& L = S->point_lights[i];
+        V3 lp = v3(L.position[0], L.position[1], L.position[2]);
+        V3 dl = lp - so;
+        float dist = sqrtf(dot(dl, dl));
+        float inten = L.intensity / ((1.0f + L.att_linear * dist) + (L.att_exp * dist) * dist);
+        if (inten > 0.005f) {
+            V3 ld = dl * (1.0f / dist);
+            bool sh = false;
+            if (P.prm.shadow && shadows) {
+                st.shadow_rays++;
+                uint64_t ss = 0;
+                sh = trace_any(P, so, ld, dist, ss);
+                st.shadow_steps += ss;
+            }
+            if (!sh) {
+                V3 r;
+                radiance(v3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo,
+                         V.roughness, V.metallic, V.k, r);
+                diffuse = diffuse + r;
+            }
+        }
+    }
+    int nsl = S->n_spot_lights < VRT_MAX_SPOT_LIGHTS ? S->n_spot_lights : VRT_MAX_SPOT_LIGHTS;
+    for (int i = 0; i < nsl; i++) {
+        const vrt_spot_light& L = S->spot_lights[i];
+        V3 lp = v3(L.position[0], L.position[1], L.position[2]);
+        V3 dl = lp - so;
+        float dist = sqrtf(dot(dl, dl));
+        /* ComputeSpotLightIntensity, Lighting.hlsli:30-48 */
+        V3 sd = v3(-dl.x, -dl.y, -dl.z) * (1.0f / dist);
+        float cs = dot(v3(L.forward[0], L.forward[1], L.forward[2]), sd);
+        float inten = 0.0f;
+        if (cs >= 0.0f && cs > L.cos_angle) {
+            float delta = (cs - L.cos_angle) / (L.cos_falloff_angle - L.cos_angle);
+            float fall = minf(delta, 1.0f);
+            float base = L.intensity * fall;
+            inten = base / ((1.0f + L.att_linear * dist) + (L.att_exp * dist) * dist);
+        }
+        if (inten > 0.01f) {
+            V3 ld = dl * (1.0f / dist);
+            bool sh = false;
+            if (P.prm.shadow && shadows) {
+                st.shadow_rays++;
+                uint64_t ss = 0;
+                sh = trace_any(P, so, ld, dist, ss);
+                st.shadow_steps += ss;
+            }
+            if (!sh) {
+                V3 r;
+                radiance(v3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo,
+                         V.roughness, V.metallic, V.k, r);
+                diffuse = diffuse + r;
+            }
+        }
+    }
+    return diffuse;
+}
+
+inline float tonemap(float c) {
+    c = c > 0.0f ? c : 0.0f; /* negative / NaN → 0, what the UNORM render target keeps */
+    c = c / (c + 1.0f);
+    return powf(c, 1.0f / 2.2f);
+}
+
+void render_rows(const Packed& P, int y0, int y1, int row0, float* out, Stats& st) {
+    int W = P.prm.width, H = P.prm.height;
+    for (int y = y0; y < y1; y++) {
+        for (int x = 0; x < W; x++) {
+            V3 o, d;
+            camera_ray(P.cam, W, H, x, y, o, d);
+            st.primary_rays++;
+            V3 c = radiance_ray(P, o, d, 1, st);
+            float* px = out + ((size_t)(y - row0) * W + x) * 4;
+            px[0] = tonemap(c.x);
+            px[1] = tonemap(c.y);
+            px[2] = tonemap(c.z);
+            px[3] = 1.0f;
+        }
+    }
+}
+
+bool mode_supported(int mode) { return mode >= VRT_MODE_INTERP && mode <= VRT_MODE_INTERP_NOTEX_UNLIT; }
+
+}  // namespace
+
+extern "C" {
+
+int vrto_render(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env_rgba8, int env_face_size,
+                const vrt_params* params, int row0, int rows, float* out_rgba, vrto_stats* stats_or_null,
+                int threads) {
+    Packed* P = new Packed;
+    if (!pack(scene, volumes, env_rgba8, env_face_size, params, *P) || !out_rgba) {
+        delete P;
+        return VRT_ERR_INVALID;
+    }
+    if (!mode_supported(params->mode)) {
+        delete P;
+        return VRT_ERR_UNSUPPORTED;
+    }
+    if (row0 < 0 || rows < 0 || row0 + rows > params->height) {
+        delete P;
+        return VRT_ERR_INVALID;
+    }
+    if (threads < 1) threads = 1;
+    if (threads > rows && rows > 0) threads = rows;
+    std::vector<Stats> st((size_t)threads);
+    if (threads == 1) {
+        render_rows(*P, row0, row0 + rows, row0, out_rgba, st[0]);
+    } else {
+        /* interleaved 4-row strips so that sky rows and object rows spread over the threads */
+        std::vector<std::thread> th;
+        for (int k = 0; k < threads; k++) {
+            th.emplace_back([&, k]() {
+                for (int y = row0 + k * 4; y < row0 + rows; y += threads * 4) {
+                    int ye = y + 4 < row0 + rows ? y + 4 : row0 + rows;
+                    render_rows(*P, y, ye, row0, out_rgba, st[(size_t)k]);
+                }
+            });
+        }
+        for (auto& t : th) t.join();
+    }
+    if (stats_or_null) {
+        vrto_stats s;
+        memset(&s, 0, sizeof s);
+        for (auto& a : st) {
+            s.primary_rays += a.primary_rays;
+            s.shadow_rays += a.shadow_rays;
+            s.bounce_rays += a.bounce_rays;
+            s.primary_steps += a.primary_steps;
+            s.shadow_steps += a.shadow_steps;
+            s.hits += a.hits;
+        }
+        *stats_or_null = s;
+    }
+    delete P;
+    return VRT_OK;
+}
+
+int vrto_trace(const vrt_scene* scene, const vrto_volume* volumes, const vrt_params* params, const float origin[3],
+               const float dir[3], float t_max, float* t_out, float normal_out[3], int* instance_out,
+               int* steps_out) {
+    Packed* P = new Packed;
+    vrt_params prm = *params;
+    if (prm.width <= 0) prm.width = 1;
+    if (prm.height <= 0) prm.height = 1;
+    if (!pack(scene, volumes, nullptr, 0, &prm, *P)) {
+        delete P;
+        return VRT_ERR_INVALID;
+    }
+    V3 o = v3(origin[0], origin[1], origin[2]);
+    V3 d = normalize(v3(dir[0], dir[1], dir[2]));
+    HitRec h;
+    uint64_t steps = 0;
+    bool hit = trace_closest(*P, o, d, t_max, h, steps);
+    if (steps_out) *steps_out = (int)steps;
+    if (hit) {
+        if (t_out) *t_out = h.t;
+        if (normal_out) {
+            normal_out[0] = h.n_world.x;
+            normal_out[1] = h.n_world.y;
+            normal_out[2] = h.n_world.z;
+        }
+        if (instance_out) *instance_out = h.inst;
+    }
+    delete P;
+    return hit ? 1 : 0;
+}
+
+void vrto_camera_ray(const vrt_scene* scene, int width, int height, int px, int py, float origin[3], float dir[3]) {
+    Camera c = camera_basis(scene, width, height);
+    V3 o, d;
+    camera_ray(c, width, height, px, py, o, d);
+    origin[0] = o.x; origin[1] = o.y; origin[2] = o.z;
+    dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;
+}
+
+float vrto_sample(const vrto_volume* vol, const float p[3]) {
+    Volume V;
+    V.den = vol->density;
+    V.N = (1 << vol->resolution) + 1;
+    V.extent = vol->extent;
+    V.cell = (vol->extent * 2.0f) / (float)(V.N - 1);
+    V.inv_cell = 1.0f / V.cell;
+    float cmax = (float)(V.N - 2);
+    float u[3], cf[3], f[3];
+    for (int a = 0; a < 3; a++) {
+        u[a] = (p[a] + V.extent) * V.inv_cell;
+        cf[a] = minf(maxf(floorf(u[a]), 0.0f), cmax);
+        f[a] = u[a] - cf[a];
+    }
+    return trilinear(V, (int)cf[0], (int)cf[1], (int)cf[2], f[0], f[1], f[2]);
+}
+
+void vrto_env_lookup(const uint8_t* env_rgba8, int face_size, const float dir[3], float rgb_out[3]) {
+    env_lookup(env_rgba8, face_size, v3(dir[0], dir[1], dir[2]), rgb_out);
+}
+
+/* ---- reference-algorithm cross-check (double precision) -------------------------------- */
+
+namespace {
+inline double tap(const vrto_volume* vol, int N, int x, int y, int z) {
+    return (double)vol->density[((size_t)x * N + (size_t)z) * N + (size_t)y];
+}
+inline double cubic(double A, double B, double C, double D, double s) { return ((A * s + B) * s + C) * s + D; }
+
+/* first root of the cubic in [s0,1] given f(s0) > 0, or -1 */
+double first_root(double A, double B, double C, double D, double s0) {
+    /* split [s0,1] at the derivative's roots, then bisect the first bracketing piece */
+    double cuts[4];
+    int nc = 0;
+    cuts[nc++] = s0;
+    double dA = 3.0 * A, dB = 2.0 * B, dC = C;
+    double e[2];
+    int ne = 0;
+    if (fabs(dA) > 1e-300) {
+        double disc = dB * dB - 4.0 * dA * dC;
+        if (disc >= 0.0) {
+            double sq = sqrt(disc);
+            e[ne++] = (-dB - sq) / (2.0 * dA);
+            e[ne++] = (-dB + sq) / (2.0 * dA);
+        }
+    } else if (fabs(dB) > 1e-300) {
+        e[ne++] = -dC / dB;
+    }
+    if (ne == 2 && e[0] > e[1]) { double t = e[0]; e[0] = e[1]; e[1] = t; }
+    for (int i = 0; i < ne; i++)
+        if (e[i] > s0 && e[i] < 1.0) cuts[nc++] = e[i];
+    cuts[nc++] = 1.0;
+    for (int i = 0; i + 1 < nc; i++) {
+        double a = cuts[i], b = cuts[i + 1];
+        double fa = cubic(A, B, C, D, a), fb = cubic(A, B, C, D, b);
+        if (fa <= 0.0) return a;
+        if (fb <= 0.0) {
+            for (int it = 0; it < 200; it++) {
+                double m = 0.5 * (a + b);
+                double fm = cubic(A, B, C, D, m);
+                if (fm > 0.0) a = m; else b = m;
+            }
+            return 0.5 * (a + b);
+        }
+    }
+    return -1.0;
+}
+}  // namespace
+
+int vrto_ref_hit_t(const vrto_volume* vol, const float origin[3], const float dir[3], double* t_out) {
+    const int N = (1 << vol->resolution) + 1;
+    const double E = vol->extent, cell = 2.0 * E / (N - 1);
+    double o[3] = {origin[0], origin[1], origin[2]}, d[3] = {dir[0], dir[1], dir[2]};
+    /* slab (Ray.hlsli:111-134) */
+    double t_enter = -1e300, t_exit = 1e300;
+    for (int a = 0; a < 3; a++) {
+        if (d[a] != 0.0) {
+            double t0 = (-E - o[a]) / d[a], t1 = (E - o[a]) / d[a];
+            if (t0 > t1) { double s = t0; t0 = t1; t1 = s; }
+            if (t0 > t_enter) t_enter = t0;
+            if (t1 < t_exit) t_exit = t1;
+        } else if (o[a] < -E || o[a] > E) {
+            return 0;
+        }
+    }
+    if (!(t_exit > t_enter) || t_exit < 0.0) return 0;
+    double t = t_enter > 0.0 ? t_enter : 0.0;
+    /* cell walk: at each step find the cell containing the midpoint of the next segment */
+    for (int guard = 0; guard < 8 * N; guard++) {
+        if (t >= t_exit) return 0;
+        double eps = 1e-9 * (1.0 + fabs(t));
+        double pm[3];
+        int c[3];
+        for (int a = 0; a < 3; a++) {
+            pm[a] = o[a] + d[a] * (t + eps);
+            int ci = (int)floor((pm[a] + E) / cell);
+            c[a] = ci < 0 ? 0 : (ci > N - 2 ? N - 2 : ci);
+        }
+        /* exit of this cell (GoToNextVoxel, Voxel.hlsli:80-128, without the +0.1 nudge) */
+        double t_out_cell = t_exit;
+        for (int a = 0; a < 3; a++) {
+            if (d[a] != 0.0) {
+                double face = -E + cell * (c[a] + (d[a] > 0.0 ? 1 : 0));
+                double tf = (face - o[a]) / d[a];
+                if (tf > t && tf < t_out_cell) t_out_cell = tf;
+            }
+        }
+        if (!(t_out_cell > t)) t_out_cell = t + 1e-7 * (1.0 + fabs(t));
+        /* corner values, VCell corner order of GetDensityPolynomial (v1..v8: x fastest, then y, then z) */
+        double v[8];
+        bool neg = false, pos = false;
+        for (int k = 0; k < 8; k++) {
+            v[k] = tap(vol, N, c[0] + (k & 1), c[1] + ((k >> 1) & 1), c[2] + ((k >> 2) & 1));
+            if (v[k] < 0.0) neg = true;
+            if (v[k] > 0.0) pos = true;
+            if (v[k] == 0.0) { neg = true; pos = true; }
+        }
+        if (neg) { /* HasIsoSurfaceInsideCell or solid cell (Voxel.hlsli:497-538) */
+            /* a = cell-space position at tIn, b = delta to tOut (GetDensityPolynomial, :552-605) */
+            double a1[3], a0[3], b1[3], b0[3];
+            for (int a = 0; a < 3; a++) {
+                double pin = o[a] + d[a] * t, pout = o[a] + d[a] * t_out_cell;
+                double origin_cell = -E + cell * c[a];
+                a1[a] = (pin - origin_cell) / cell;
+                a0[a] = 1.0 - a1[a];
+                b1[a] = (pout - origin_cell) / cell - a1[a];
+                b0[a] = -b1[a];
+            }
+            double A = 0, B = 0, C = 0, D = 0;
+            for (int k = 0; k < 8; k++) {
+                const double* ax = (k & 1) ? a1 : a0;
+                const double* ay = ((k >> 1) & 1) ? a1 : a0;
+                const double* az = ((k >> 2) & 1) ? a1 : a0;
+                const double* bx = (k & 1) ? b1 : b0;
+                const double* by = ((k >> 1) & 1) ? b1 : b0;
+                const double* bz = ((k >> 2) & 1) ? b1 : b0;
+                A += bx[0] * by[1] * bz[2] * v[k];
+                D += ax[0] * ay[1] * az[2] * v[k];
+                B += (ax[0] * by[1] * bz[2] + bx[0] * ay[1] * bz[2] + bx[0] * by[1] * az[2]) * v[k];
+                C += (bx[0] * ay[1] * az[2] + ax[0] * by[1] * az[2] + ax[0] * ay[1] * bz[2]) * v[k];
+            }
+            if (!pos || D <= 0.0) { /* start inside: reference reports tIn (:704-708) */
+                *t_out = t;
+                return 1;
+            }
+            double s = first_root(A, B, C, D, 0.0);
+            if (s >= 0.0) {
+                *t_out = t + (t_out_cell - t) * s;
+                return 1;
+            }
+        }
+        t = t_out_cell;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+/*
+ * vrt_oracle.h — C interface of the scalar CPU oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (volumetricraytracer_amd/, the C-ABI
+ * library) may include, link or call this.  Allowed users: tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg.
+ *
+ * Parity status: PARITY UNPINNED by the reference's own tests — the reference
+ * (Elyptos/VolumetricRaytracer) ships no tests, golden images or known-answer vectors
+ *  and its hot path (HLSL/DXR + D3D12) cannot be built or run here.
+ * The oracle is therefore pinned by analytic ground truth (ray∩sphere, plane, box) and by
+ * a restatement of the reference's own per-cell cubic iso-surface solve (vrto_ref_hit_t,
+ * Voxel.hlsli:552-605,691-781) — see tests/test_oracle_*.py.
+ */
+#ifndef VRT_ORACLE_H
+#define VRT_ORACLE_H
+
+#include <stdint.h>
+#include "../include/vrt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vrto_volume {
+    const float* density;     /* N^3, index x*N*N + z*N + y; NULL = empty slot */
+    int32_t resolution;       /* N = 2^resolution + 1 */
+    float extent;
+    float density_scale;
+    float step_max;           /* <= 0: unbounded */
+    vrt_material material;
+} vrto_volume;
+
+typedef struct vrto_stats {
+    uint64_t primary_rays, shadow_rays, bounce_rays;
+    uint64_t primary_steps, shadow_steps, hits;
+} vrto_stats;
+
+/* Renders rows [row0,row0+rows) of the width x height frame into out_rgba (rows*width float4).
+ * volumes: array of VRT_MAX_VOLUMES slots.  env: 6*face^2 RGBA8 or NULL.  threads >= 1. */
+int vrto_render(const vrt_scene* scene, const vrto_volume* volumes,
+                const uint8_t* env_rgba8, int env_face_size,
+                const vrt_params* params, int row0, int rows,
+                float* out_rgba, vrto_stats* stats_or_null, int threads);
+
+/* Single-ray probes used by the analytic pins (world-space ray, direction is normalised
+ * internally; returns 1 on hit and writes t / world normal / instance index). */
+int vrto_trace(const vrt_scene* scene, const vrto_volume* volumes, const vrt_params* params,
+               const float origin[3], const float dir[3], float t_max,
+               float* t_out, float normal_out[3], int* instance_out, int* steps_out);
+
+/* Camera ray of pixel (px,py): writes origin[3], dir[3] (normalised). */
+void vrto_camera_ray(const vrt_scene* scene, int width, int height, int px, int py,
+                     float origin[3], float dir[3]);
+
+/* Trilinear sample of a volume at object-space position p (clamped to the grid). */
+float vrto_sample(const vrto_volume* vol, const float p[3]);
+
+/* Restatement of the REFERENCE's hit search for one object-space ray against one volume:
+ * cell-by-cell DDA + closed-form cubic of the trilinear interpolant along the ray
+ * (Shaders/Include/Voxel.hlsli:552-605, 691-781; loop Raytracing.hlsl:228-323 without the
+ * octree skip).  Double precision.  Returns 1 and the ray parameter of the first zero
+ * crossing, or 0.  Used to check that the sphere-trace converges to the reference's surface. */
+int vrto_ref_hit_t(const vrto_volume* vol, const float origin[3], const float dir[3], double* t_out);
+
+/* Cube-map lookup used by the miss path (dir is a world direction; returns rgb). */
+void vrto_env_lookup(const uint8_t* env_rgba8, int face_size, const float dir[3], float rgb_out[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,58 @@
+"""Deterministic scenes shared by the tests, smoke() and bench.py (no RNG, no files).
+They are the BASELINE.json configs at test-friendly sizes; sizes are arguments."""
+from __future__ import annotations
+
+import math
+
+import volumetricraytracer_amd as v
+
+
+def config2_sphere(resolution: int = 6, env: int = 64) -> v.VScene:
+    """BASELINE config 2: one r=6 sphere volume (radius 40, extent 100), camera (300,0,0) looking -X,
+    demo directional light (RendererEngineInstance.cpp:232-316)."""
+    vol = v.sphere_volume(resolution, 100.0, 40.0, v.VMaterial((1.0, 0.0, 0.0, 1.0), 0.8, 0.0))
+    return v.VScene(Camera=v.look_minus_x_camera(300.0), DirectionalLight=v.demo_light(),
+                    Objects=[v.VVoxelObject(Volume=vol)], EnvironmentMap=v.procedural_skybox(env))
+
+
+def config3_torus(resolution: int = 8, env: int = 256, distance: float = 260.0) -> v.VScene:
+    """BASELINE config 3 (analytic variant): exact torus SDF on a 2^r grid, close camera so the
+    object fills the frame, shadow ray meaningful (torus shadows itself)."""
+    vol = v.torus_volume(resolution, 100.0, 55.0, 22.0, v.VMaterial((0.8, 0.6, 0.2, 1.0), 0.8, 0.0))
+    cam = v.VCamera(Position=(distance * math.cos(math.radians(35.0)), 0.0, distance * math.sin(math.radians(35.0))),
+                    Rotation=tuple(v.quat_mul(v.quat_from_axis_angle(v.UP, math.pi),
+                                              v.quat_from_axis_angle(v.RIGHT, math.radians(35.0)))),
+                    FOVAngle=60.0)
+    return v.VScene(Camera=cam, DirectionalLight=v.demo_light(), Objects=[v.VVoxelObject(Volume=vol)],
+                    EnvironmentMap=v.procedural_skybox(env))
+
+
+def config5_instances(resolution: int = 7, env: int = 64, distinct_volumes: bool = False) -> v.VScene:
+    """BASELINE config 5: 8 instances of an r=7 CSG volume on a 2x2x2 lattice, varied yaw/scale."""
+    mats = [v.VMaterial((0.9, 0.3, 0.3, 1), 0.8, 0.0), v.VMaterial((0.3, 0.9, 0.3, 1), 0.6, 0.2)]
+    base = v.csg_volume(resolution, 100.0, mats[0])
+    vols = [base]
+    if distinct_volumes:
+        vols = [v.csg_volume(resolution, 100.0, mats[i % 2]) for i in range(8)]
+    objs = []
+    k = 0
+    for ix in (-1, 1):
+        for iy in (-1, 1):
+            for iz in (-1, 1):
+                s = (0.75, 1.0, 1.25)[k % 3]
+                yaw = math.radians(20.0 * k)
+                objs.append(v.VVoxelObject(Position=(ix * 150.0, iy * 150.0, iz * 150.0),
+                                           Rotation=tuple(v.quat_from_axis_angle(v.UP, yaw)), Scale=(s, s, s),
+                                           Volume=vols[k % len(vols)]))
+                k += 1
+    cam = v.look_minus_x_camera(900.0, 0.0)
+    return v.VScene(Camera=cam, DirectionalLight=v.demo_light(), Objects=objs, EnvironmentMap=v.procedural_skybox(env))
+
+
+def min_cell(scene: v.VScene) -> float:
+    return min(vol.GetCellSize() for vol in scene.volumes())
+
+
+def bench_config3() -> v.VScene:
+    """bench.py workload for BASELINE config 3 (1080p, 256^3 volume, shadow ray on)."""
+    return config3_torus(8, 256, distance=190.0)

@@ -1,0 +1,245 @@
+"""GPU parity: the HIP path through the C-ABI against the CPU oracle (and the frozen golden
+images) on identical inputs.  Tolerance: 1e-4 per channel (BASELINE.json north_star); in
+practice the march is bit-identical and only powf differs in the last ulp.  Ray / step
+counters must agree exactly (integers)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+import volumetricraytracer_amd as v
+from oracle.binding import OracleScene
+from volumetricraytracer_amd import _abi
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+STAT_KEYS = ("primary_rays", "shadow_rays", "bounce_rays", "primary_steps", "shadow_steps", "hits")
+
+
+def gpu_render(r, sc, p):
+    r.SetSceneToRender(sc)
+    r.ResizeRenderOutput(p.width, p.height)
+    r.params_override = p
+    r.SetRendererMode(p.mode)
+    img = r.Render()
+    return img, r.last_timing()
+
+
+def assert_parity(r, sc, p, check_stats=True):
+    img, t = gpu_render(r, sc, p)
+    ref, st = OracleScene(sc).render(p, threads=8)
+    err = np.abs(img - ref)
+    assert not np.isnan(img).any()
+    assert err.max() <= TOL, f"max abs err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+    if check_stats:
+        assert {k: t[k] for k in STAT_KEYS} == {k: st[k] for k in STAT_KEYS}
+    return img, t
+
+
+@pytest.mark.parametrize("path", [_abi.PATH_DENSE, _abi.PATH_BRICK, _abi.PATH_BRICK_LDS, _abi.PATH_AUTO])
+def test_config2_sphere_parity(renderer, oracle_lib, path):
+    sc = scenes.config2_sphere()
+    p = v.default_params(320, 180, scenes.min_cell(sc), 128, path=path)
+    assert_parity(renderer, sc, p)
+
+
+def test_config2_full_size(renderer, oracle_lib):
+    sc = scenes.config2_sphere()
+    p = v.default_params(1280, 720, scenes.min_cell(sc), 128)
+    img, t = assert_parity(renderer, sc, p)
+    assert t["primary_rays"] == 1280 * 720
+
+
+@pytest.mark.parametrize("shadow", [False, True])
+@pytest.mark.parametrize("path", [_abi.PATH_DENSE, _abi.PATH_BRICK])
+def test_config3_torus_parity(renderer, oracle_lib, shadow, path):
+    sc = scenes.config3_torus(7, 64)
+    p = v.default_params(480, 270, scenes.min_cell(sc), 255, shadow=shadow, path=path)
+    assert_parity(renderer, sc, p)
+
+
+def test_config3_at_256_cubed(renderer, oracle_lib):
+    sc = scenes.config3_torus(8, 256)
+    p = v.default_params(640, 360, scenes.min_cell(sc), 255, shadow=True)
+    assert_parity(renderer, sc, p)
+
+
+@pytest.mark.parametrize("distinct", [False, True])
+def test_config5_instances_bvh_parity(renderer, oracle_lib, distinct):
+    sc = scenes.config5_instances(6, 32, distinct_volumes=distinct)
+    p = v.default_params(480, 270, scenes.min_cell(sc), 255, shadow=True)
+    # the BVH visits instances in a different order than the oracle's brute-force loop, so the
+    # per-instance march budget is spent differently: images must agree, step counters need not
+    img, t = assert_parity(renderer, sc, p, check_stats=False)
+    ref, st = OracleScene(sc).render(p, threads=8)
+    assert t["hits"] == st["hits"] and t["shadow_rays"] == st["shadow_rays"]
+
+
+def test_unlit_mode_and_modes_without_textures_agree(renderer, oracle_lib):
+    sc = scenes.config3_torus(6, 16)
+    cell = scenes.min_cell(sc)
+    lit = {}
+    for mode in (_abi.MODE_INTERP, _abi.MODE_INTERP_NOTEX, _abi.MODE_INTERP_UNLIT, _abi.MODE_INTERP_NOTEX_UNLIT):
+        p = v.default_params(192, 108, cell, 255, shadow=True, mode=mode)
+        lit[mode], _ = assert_parity(renderer, sc, p)
+    assert np.array_equal(lit[_abi.MODE_INTERP], lit[_abi.MODE_INTERP_NOTEX])
+    assert np.array_equal(lit[_abi.MODE_INTERP_UNLIT], lit[_abi.MODE_INTERP_NOTEX_UNLIT])
+    p = v.default_params(192, 108, cell, 255, mode=_abi.MODE_CUBE)
+    renderer.params_override = p
+    renderer.SetRendererMode(p.mode)
+    with pytest.raises(_abi.VrtError) as e:
+        renderer.Render()
+    assert e.value.status == _abi.VRT_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("name", ["config2_64x36", "config3_96x54", "config5_96x54"])
+def test_against_frozen_golden_images(renderer, name):
+    from golden.make_golden import CASES, build_case
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sc, p = build_case(CASES[name])
+    img, t = gpu_render(renderer, sc, p)
+    assert np.abs(img - g["image"]).max() <= TOL
+    if name != "config5_96x54":
+        assert [t[k] for k in ("primary_rays", "shadow_rays", "primary_steps", "shadow_steps", "hits")] == [int(x) for x in g["stats"]]
+
+
+def test_edge_cases(renderer, oracle_lib):
+    # ragged frame sizes (not multiples of the 16x16 workgroup tile), 1x1, tall and wide
+    sc = scenes.config2_sphere(5, 8)
+    cell = scenes.min_cell(sc)
+    for (w, h) in [(1, 1), (17, 9), (33, 47), (250, 3), (3, 250)]:
+        assert_parity(renderer, sc, v.default_params(w, h, cell, 64))
+    # camera inside the volume (tEnter < 0), inside the solid, and looking away
+    for pos in [(60.0, 0.0, 0.0), (10.0, 5.0, 0.0), (-300.0, 0.0, 0.0)]:
+        sc.Camera = v.VCamera(Position=pos, Rotation=sc.Camera.Rotation)
+        assert_parity(renderer, sc, v.default_params(96, 54, cell, 64, shadow=True))
+    # max_steps = 0 and a 1-step budget: everything misses / only entry hits
+    sc = scenes.config2_sphere(5, 8)
+    assert_parity(renderer, sc, v.default_params(64, 36, cell, 0))
+    assert_parity(renderer, sc, v.default_params(64, 36, cell, 1))
+    # smallest grids: resolution 0 (one cell) and 1
+    for r in (0, 1, 2):
+        vol = v.VVoxelVolume(r, 50.0).fill(lambda X, Y, Z: np.sqrt(X * X + Y * Y + Z * Z) - 30.0)
+        s2 = v.VScene(Camera=v.look_minus_x_camera(200.0), DirectionalLight=v.demo_light(), Objects=[v.VVoxelObject(Volume=vol)])
+        assert_parity(renderer, s2, v.default_params(64, 36, vol.GetCellSize(), 64, shadow=True))
+    # empty scene: every ray reads the environment (or black without one)
+    s3 = v.VScene(Camera=v.look_minus_x_camera(200.0), EnvironmentMap=v.procedural_skybox(8))
+    assert_parity(renderer, s3, v.default_params(64, 36, 1.0, 64))
+    s3.EnvironmentMap = None
+    img, _ = assert_parity(renderer, s3, v.default_params(64, 36, 1.0, 64))
+    assert (img[..., :3] == 0).all() and (img[..., 3] == 1).all()
+
+
+def test_shell_volume_with_step_clamp(renderer, oracle_lib):
+    """Non-metric density (Voxelizer-style shell): density_scale and step_max drive the march."""
+    vol = v.VVoxelVolume(6, 100.0)
+    thr = vol.GetCellSize() * np.sqrt(3.0)
+
+    def shell(X, Y, Z):  # unsigned distance to a sphere surface, in units of thr, minus 0.5; clamped background
+        d = np.abs(np.sqrt(X * X + Y * Y + Z * Z) - 50.0) / thr - 0.5
+        return np.where(d < 1.0, d, 200.0)
+
+    vol.fill(shell)
+    vol.density_scale = float(thr)
+    vol.step_max = float(0.5 * thr)
+    sc = v.VScene(Camera=v.look_minus_x_camera(250.0), DirectionalLight=v.demo_light(), Objects=[v.VVoxelObject(Volume=vol)],
+                  EnvironmentMap=v.procedural_skybox(8))
+    img, t = assert_parity(renderer, sc, v.default_params(320, 180, vol.GetCellSize(), 255, shadow=True))
+    assert t["primary_steps"] / t["primary_rays"] > 10  # the clamp makes this a long march
+
+
+def test_row_tiles_into_device_memory(renderer, oracle_lib):
+    """vrt_render_rows: asynchronous tile render into caller-owned device memory (torch tensor)."""
+    import torch
+
+    sc = scenes.config3_torus(6, 16)
+    p = v.default_params(200, 120, scenes.min_cell(sc), 255, shadow=True)
+    renderer.SetSceneToRender(sc)
+    renderer.SyncWithScene()
+    ref, st = OracleScene(sc).render(p, threads=8)
+    full = torch.empty((120, 200, 4), dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    steps = 0
+    for row0, rows in [(0, 37), (37, 50), (87, 33)]:
+        tile = full[row0:row0 + rows]
+        renderer.render_rows(p, row0, rows, tile.data_ptr(), stream)
+        torch.cuda.synchronize()
+        t = renderer.last_timing()
+        steps += t["primary_steps"]
+        assert t["primary_rays"] == rows * 200 and t["kernel_ms"] > 0
+    assert np.abs(full.cpu().numpy() - ref).max() <= TOL
+    assert steps == st["primary_steps"]
+    hist = renderer.timing_history(3)
+    assert len(hist) == 3 and all(h > 0 for h in hist)
+
+
+def test_multi_tile_context_on_one_gpu(oracle_lib):
+    """A context with two logical devices (the same ordinal twice) exercises the row-tile split
+    and the gather into device 0's frame that an 8-GPU context uses."""
+    sc = scenes.config5_instances(5, 16)
+    p = v.default_params(160, 90, scenes.min_cell(sc), 255, shadow=True)
+    r2 = v.VHipRenderer(devices=(0, 0, 0))
+    assert r2.Start()
+    try:
+        img, t = gpu_render(r2, sc, p)
+        ref, st = OracleScene(sc).render(p, threads=8)
+        assert np.abs(img - ref).max() <= TOL
+        assert t["primary_rays"] == 160 * 90 and t["hits"] == st["hits"]
+    finally:
+        r2.Stop()
+
+
+def test_voxel_record_upload_and_volume_lifecycle(renderer, oracle_lib):
+    lib = _abi.load()
+    sc = scenes.config2_sphere(5, 8)
+    p = v.default_params(96, 54, scenes.min_cell(sc), 128, shadow=True)
+    ref, _ = OracleScene(sc).render(p, threads=4)
+    renderer.SetSceneToRender(sc)
+    renderer.ResizeRenderOutput(96, 54)
+    renderer.params_override = p
+    renderer.SetRendererMode(p.mode)
+    renderer.SyncWithScene()
+    vol = sc.volumes()[0]
+    renderer.upload_volume(0, vol, as_voxels=True)  # straight from VVoxel records
+    img = renderer.Render()
+    assert np.abs(img - ref).max() <= TOL
+    ctx = renderer._ctx
+    assert lib.vrt_volume_free(ctx, 7) == _abi.VRT_ERR_SLOT
+    assert lib.vrt_volume_free(ctx, 99) == _abi.VRT_ERR_SLOT
+    assert lib.vrt_volume_upload(ctx, 25, 3, 1.0, None, None) == _abi.VRT_ERR_INVALID
+    assert lib.vrt_volume_free(ctx, 0) == _abi.VRT_OK
+    pp = renderer.make_params()
+    assert lib.vrt_render(ctx, C.byref(pp), None) == _abi.VRT_ERR_NOT_READY  # scene referenced the freed slot
+    renderer._uploaded.clear()
+    img = renderer.Render()  # re-sync uploads again
+    assert np.abs(img - ref).max() <= TOL
+
+
+def test_full_size_properties_1080p_256(renderer):
+    """BASELINE size (1920x1080, 256^3): size-independent properties instead of a CPU re-run —
+    determinism, row-tile seamlessness, unlit pixels ∈ {tone-mapped tint, environment}, and the
+    image symmetry of a symmetric scene."""
+    import torch
+
+    sc = scenes.config3_torus(8, 64)
+    sc.Camera = v.look_minus_x_camera(320.0)  # torus around Z seen edge-on: mirror-symmetric in image y ↔ -y
+    p = v.default_params(1920, 1080, scenes.min_cell(sc), 255, shadow=False, mode=_abi.MODE_INTERP_NOTEX_UNLIT)
+    a, t = gpu_render(renderer, sc, p)
+    b, _ = gpu_render(renderer, sc, p)
+    assert np.array_equal(a, b)
+    assert t["primary_rays"] == 1920 * 1080 and t["hits"] > 50000
+    tint = np.array(sc.Objects[0].Volume.Material.AlbedoColor[:3], dtype=np.float32)
+    tm = (tint / (tint + 1)) ** (1 / 2.2)
+    hit = np.abs(a[..., :3] - tm).max(-1) < 1e-5
+    assert hit.sum() == t["hits"]
+    # hit mask is symmetric under a vertical flip (camera on the torus' symmetry plane)
+    assert (hit != hit[::-1]).sum() <= 0.002 * hit.sum()
+    full = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda:0")
+    for g in range(8):
+        renderer.render_rows(p, g * 135, 135, full[g * 135:(g + 1) * 135].data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(full.cpu().numpy(), a)

@@ -1,0 +1,801 @@
+/*
+ * vrt_api.hip — host runtime behind the C-ABI of include/vrt.h.
+ *
+ * Owns every device allocation, mirrors the caller's scene into flat device structs
+ * (the job VRDXScene / VDXVoxelVolume / VDXLevelObject did with D3D12 resources:
+ * Renderer/DX/Private/RDXScene.cpp:109-174,454-545,703-755, RDXVoxelVolume.cpp:33-60,294-397,
+ * RDXLevelObject.cpp:29-48), builds the small AABB BVH the DXR driver used to build
+ * (DXRenderer.cpp:809-825), and launches the march kernel (DXRenderer.cpp:827-867).
+ *
+ * There is no CPU fallback: every entry point fails with a negative status when HIP does.
+ */
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <limits>
+#include <new>
+#include <vector>
+
+#include "../../include/vrt.h"
+#include "vrt_device.h"
+#include "vrt_launch.h"
+
+using namespace vrt;
+
+namespace {
+
+constexpr int kRing = 256; /* per-launch event pairs + stat slots kept for vrt_timing_history */
+
+struct HostVolume {
+    bool used = false;
+    int resolution = 0, N = 0, nb = 0;
+    float extent = 0.f;
+    float density_scale = 1.f;
+    float step_max = 0.f; /* <= 0: unbounded */
+    vrt_material mat = {{0.8f, 0.8f, 0.8f, 1.0f}, 0.8f, 0.0f};
+};
+
+struct DeviceVolume {
+    float* dense = nullptr;
+    float* bricks = nullptr;
+    uint8_t* material = nullptr;
+};
+
+struct DeviceState {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    DeviceVolume vol[VRT_MAX_VOLUMES];
+    DVolume* d_vols = nullptr;
+    DInstance* d_inst = nullptr;
+    DBvhNode* d_nodes = nullptr;
+    DPointLight* d_point = nullptr;
+    DSpotLight* d_spot = nullptr;
+    uint8_t* d_env = nullptr;
+    float* fb = nullptr;
+    size_t fb_bytes = 0;
+    unsigned long long* d_stats = nullptr; /* kRing x kStatWords */
+    hipEvent_t ev0[kRing];
+    hipEvent_t ev1[kRing];
+    bool events_ok = false;
+};
+
+}  // namespace
+
+struct vrt_ctx {
+    std::vector<DeviceState> dev;
+    HostVolume vol[VRT_MAX_VOLUMES];
+    int env_size = 0;
+    bool have_scene = false;
+    vrt_scene scene;
+    DInstance inst[VRT_MAX_INSTANCES];
+    DBvhNode nodes[kMaxBvhNodes];
+    int n_nodes = 0;
+    DPointLight point[VRT_MAX_POINT_LIGHTS];
+    DSpotLight spot[VRT_MAX_SPOT_LIGHTS];
+    /* launch history */
+    uint64_t launches = 0;
+    int last_devices = 0; /* how many devices took part in the last launch */
+    uint32_t last_w = 0, last_h = 0;
+    float last_gather_ms = 0.f, last_total_ms = 0.f;
+    float* gather = nullptr; /* full frame on device 0 (multi-device only) */
+    size_t gather_bytes = 0;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "[vrt] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, \
+                    __LINE__);                                                                     \
+            return e_ == hipErrorOutOfMemory ? VRT_ERR_OOM : VRT_ERR_HIP;                           \
+        }                                                                                          \
+    } while (0)
+
+struct H3 {
+    float x, y, z;
+};
+inline H3 h3(float x, float y, float z) { return H3{x, y, z}; }
+inline float hdot(H3 a, H3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline H3 hcross(H3 a, H3 b) { return h3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline H3 hnormalize(H3 a) {
+    float inv = 1.0f / sqrtf(hdot(a, a));
+    return h3(a.x * inv, a.y * inv, a.z * inv);
+}
+
+/* Unit quaternion (x,y,z,w) → rotation matrix, v' = R v (Eigen's Quaternionf::toRotationMatrix). */
+void quat_to_mat(const float q[4], float R[3][3]) {
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    float xx = x * x, yy = y * y, zz = z * z;
+    float xy = x * y, xz = x * z, yz = y * z;
+    float wx = w * x, wy = w * y, wz = w * z;
+    R[0][0] = 1.0f - 2.0f * (yy + zz);
+    R[0][1] = 2.0f * (xy - wz);
+    R[0][2] = 2.0f * (xz + wy);
+    R[1][0] = 2.0f * (xy + wz);
+    R[1][1] = 1.0f - 2.0f * (xx + zz);
+    R[1][2] = 2.0f * (yz - wx);
+    R[2][0] = 2.0f * (xz - wy);
+    R[2][1] = 2.0f * (yz + wx);
+    R[2][2] = 1.0f - 2.0f * (xx + yy);
+}
+
+/* View basis of XMMatrixLookToRH(eye, forward, up) and the two projection scalars of
+ * XMMatrixPerspectiveFovRH that survive GenerateCameraRay (RDXScene.cpp:703-724, Ray.hlsli:36-48). */
+void pack_camera(const vrt_scene& s, int width, int height, DFrame& F) {
+    float R[3][3];
+    quat_to_mat(s.cam_rotation, R);
+    H3 fwd = h3(R[0][0], R[1][0], R[2][0]);
+    H3 up = h3(R[0][2], R[1][2], R[2][2]);
+    H3 r2 = hnormalize(h3(-fwd.x, -fwd.y, -fwd.z));
+    H3 r0 = hnormalize(hcross(up, r2));
+    H3 r1 = hcross(r2, r0);
+    F.cam_o[0] = s.cam_position[0];
+    F.cam_o[1] = s.cam_position[1];
+    F.cam_o[2] = s.cam_position[2];
+    F.r0[0] = r0.x; F.r0[1] = r0.y; F.r0[2] = r0.z;
+    F.r1[0] = r1.x; F.r1[1] = r1.y; F.r1[2] = r1.z;
+    F.r2[0] = r2.x; F.r2[1] = r2.y; F.r2[2] = r2.z;
+    float aspect = (float)width / (float)height; /* DXRenderer.cpp:47 */
+    float half = tanf(s.cam_fov_deg * (3.14159265358979323846f / 180.0f) * 0.5f);
+    F.cx = aspect * half;
+    F.cy = half;
+}
+
+/* object→world = S·R (+T), world→object = R^T·S^-1 (RDXLevelObject.cpp:38-47). */
+void pack_instance(const vrt_instance& in, DInstance& out) {
+    float R[3][3];
+    quat_to_mat(in.rotation, R);
+    float inv_s[3] = {1.0f / in.scale[0], 1.0f / in.scale[1], 1.0f / in.scale[2]};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            out.o2w[i * 3 + j] = in.scale[i] * R[i][j];
+            out.w2o[i * 3 + j] = R[j][i] * inv_s[j];
+        }
+    out.pos[0] = in.position[0];
+    out.pos[1] = in.position[1];
+    out.pos[2] = in.position[2];
+    out.slot = in.volume_slot;
+    out.pad_[0] = out.pad_[1] = 0.f;
+}
+
+struct Box {
+    float lo[3], hi[3];
+};
+
+Box instance_box(const DInstance& I, float extent) {
+    Box b;
+    for (int a = 0; a < 3; a++) {
+        b.lo[a] = std::numeric_limits<float>::infinity();
+        b.hi[a] = -std::numeric_limits<float>::infinity();
+    }
+    for (int k = 0; k < 8; k++) {
+        float c[3] = {(k & 1) ? extent : -extent, (k & 2) ? extent : -extent, (k & 4) ? extent : -extent};
+        for (int a = 0; a < 3; a++) {
+            float w = I.o2w[a * 3 + 0] * c[0] + I.o2w[a * 3 + 1] * c[1] + I.o2w[a * 3 + 2] * c[2] + I.pos[a];
+            b.lo[a] = std::min(b.lo[a], w);
+            b.hi[a] = std::max(b.hi[a], w);
+        }
+    }
+    /* pad by a relative epsilon so the (exact) object-space slab test never sees a ray the
+       world-space box culled by rounding */
+    for (int a = 0; a < 3; a++) {
+        float pad = 1e-4f * (1.0f + std::max(fabsf(b.lo[a]), fabsf(b.hi[a])));
+        b.lo[a] -= pad;
+        b.hi[a] += pad;
+    }
+    return b;
+}
+
+/* Median-split BVH over instance boxes; ≤ 20 leaves in the reference's scenes, ≤ 64 here. */
+int build_bvh(std::vector<int>& ids, int begin, int end, const std::vector<Box>& boxes, DBvhNode* nodes, int& n_nodes) {
+    int me = n_nodes++;
+    DBvhNode& nd = nodes[me];
+    Box b;
+    for (int a = 0; a < 3; a++) {
+        b.lo[a] = std::numeric_limits<float>::infinity();
+        b.hi[a] = -std::numeric_limits<float>::infinity();
+    }
+    for (int i = begin; i < end; i++)
+        for (int a = 0; a < 3; a++) {
+            b.lo[a] = std::min(b.lo[a], boxes[ids[i]].lo[a]);
+            b.hi[a] = std::max(b.hi[a], boxes[ids[i]].hi[a]);
+        }
+    for (int a = 0; a < 3; a++) {
+        nd.lo[a] = b.lo[a];
+        nd.hi[a] = b.hi[a];
+    }
+    if (end - begin == 1) {
+        nd.left = -(ids[begin] + 1);
+        nd.right = 0;
+        return me;
+    }
+    int axis = 0;
+    float best = -1.f;
+    for (int a = 0; a < 3; a++) {
+        float lo = std::numeric_limits<float>::infinity(), hi = -lo;
+        for (int i = begin; i < end; i++) {
+            float c = 0.5f * (boxes[ids[i]].lo[a] + boxes[ids[i]].hi[a]);
+            lo = std::min(lo, c);
+            hi = std::max(hi, c);
+        }
+        if (hi - lo > best) {
+            best = hi - lo;
+            axis = a;
+        }
+    }
+    int mid = (begin + end) / 2;
+    std::nth_element(ids.begin() + begin, ids.begin() + mid, ids.begin() + end, [&](int l, int r) {
+        float cl = boxes[l].lo[axis] + boxes[l].hi[axis], cr = boxes[r].lo[axis] + boxes[r].hi[axis];
+        return cl < cr || (cl == cr && l < r);
+    });
+    int l = build_bvh(ids, begin, mid, boxes, nodes, n_nodes);
+    int r = build_bvh(ids, mid, end, boxes, nodes, n_nodes);
+    nodes[me].left = l;
+    nodes[me].right = r;
+    return me;
+}
+
+void fill_dvolume(const HostVolume& h, const DeviceVolume& d, DVolume& out) {
+    memset(&out, 0, sizeof out);
+    if (!h.used) return;
+    out.dense = d.dense;
+    out.bricks = d.bricks;
+    out.N = h.N;
+    out.nb = h.nb;
+    out.extent = h.extent;
+    float cell = (h.extent * 2.0f) / (float)(h.N - 1); /* RDXVoxelVolume.cpp:386 */
+    out.inv_cell = 1.0f / cell;
+    out.density_scale = h.density_scale;
+    out.step_max = h.step_max > 0.0f ? h.step_max : std::numeric_limits<float>::infinity();
+    out.tint[0] = h.mat.tint[0];
+    out.tint[1] = h.mat.tint[1];
+    out.tint[2] = h.mat.tint[2];
+    out.roughness = std::min(std::max(h.mat.roughness, 0.0f), 1.0f);
+    out.metallic = std::min(std::max(h.mat.metallic, 0.0f), 1.0f);
+    float r1 = h.mat.roughness + 1.0f;
+    out.k = (r1 * r1) / 8.0f; /* RDXVoxelVolume.cpp:383 */
+}
+
+int sync_volume_table(vrt_ctx* ctx) {
+    DVolume table[VRT_MAX_VOLUMES];
+    for (auto& D : ctx->dev) {
+        for (int i = 0; i < VRT_MAX_VOLUMES; i++) fill_dvolume(ctx->vol[i], D.vol[i], table[i]);
+        HIP_TRY(hipSetDevice(D.ordinal));
+        HIP_TRY(hipMemcpy(D.d_vols, table, sizeof table, hipMemcpyHostToDevice));
+    }
+    return VRT_OK;
+}
+
+int free_device_volume(DeviceState& D, int slot) {
+    HIP_TRY(hipSetDevice(D.ordinal));
+    DeviceVolume& v = D.vol[slot];
+    if (v.dense) HIP_TRY(hipFree(v.dense));
+    if (v.bricks) HIP_TRY(hipFree(v.bricks));
+    if (v.material) HIP_TRY(hipFree(v.material));
+    v = DeviceVolume();
+    return VRT_OK;
+}
+
+int init_device(DeviceState& D, int ordinal) {
+    D.ordinal = ordinal;
+    HIP_TRY(hipSetDevice(ordinal));
+    HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&D.d_vols, sizeof(DVolume) * VRT_MAX_VOLUMES));
+    HIP_TRY(hipMemset(D.d_vols, 0, sizeof(DVolume) * VRT_MAX_VOLUMES));
+    HIP_TRY(hipMalloc(&D.d_inst, sizeof(DInstance) * VRT_MAX_INSTANCES));
+    HIP_TRY(hipMalloc(&D.d_nodes, sizeof(DBvhNode) * kMaxBvhNodes));
+    HIP_TRY(hipMalloc(&D.d_point, sizeof(DPointLight) * VRT_MAX_POINT_LIGHTS));
+    HIP_TRY(hipMalloc(&D.d_spot, sizeof(DSpotLight) * VRT_MAX_SPOT_LIGHTS));
+    HIP_TRY(hipMalloc(&D.d_stats, sizeof(unsigned long long) * kStatWords * kRing));
+    HIP_TRY(hipMemset(D.d_stats, 0, sizeof(unsigned long long) * kStatWords * kRing));
+    for (int i = 0; i < kRing; i++) {
+        HIP_TRY(hipEventCreate(&D.ev0[i]));
+        HIP_TRY(hipEventCreate(&D.ev1[i]));
+    }
+    D.events_ok = true;
+    return VRT_OK;
+}
+
+void destroy_device(DeviceState& D) {
+    if (hipSetDevice(D.ordinal) != hipSuccess) return;
+    for (int i = 0; i < VRT_MAX_VOLUMES; i++) {
+        if (D.vol[i].dense) (void)hipFree(D.vol[i].dense);
+        if (D.vol[i].bricks) (void)hipFree(D.vol[i].bricks);
+        if (D.vol[i].material) (void)hipFree(D.vol[i].material);
+    }
+    if (D.d_vols) (void)hipFree(D.d_vols);
+    if (D.d_inst) (void)hipFree(D.d_inst);
+    if (D.d_nodes) (void)hipFree(D.d_nodes);
+    if (D.d_point) (void)hipFree(D.d_point);
+    if (D.d_spot) (void)hipFree(D.d_spot);
+    if (D.d_env) (void)hipFree(D.d_env);
+    if (D.fb) (void)hipFree(D.fb);
+    if (D.d_stats) (void)hipFree(D.d_stats);
+    if (D.events_ok)
+        for (int i = 0; i < kRing; i++) {
+            (void)hipEventDestroy(D.ev0[i]);
+            (void)hipEventDestroy(D.ev1[i]);
+        }
+    if (D.stream) (void)hipStreamDestroy(D.stream);
+}
+
+bool valid_slot(int slot) { return slot >= 0 && slot < VRT_MAX_VOLUMES; }
+
+/* Uploads N^3 densities (already on the host as fp32, or as VVoxel records) to every device,
+ * then re-tiles them into bricks on the device. */
+int upload_volume(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, const float* density,
+                  const uint8_t* material, const vrt_voxel* voxels) {
+    if (!ctx) return VRT_ERR_INVALID;
+    if (!valid_slot(slot)) return VRT_ERR_SLOT;
+    if (resolution > 10 || !(extent > 0.0f) || (!density && !voxels)) return VRT_ERR_INVALID;
+    const int N = (1 << resolution) + 1; /* VoxelVolume.cpp:23 */
+    const int nb = (N - 1 + kBrickCells - 1) / kBrickCells;
+    const size_t count = (size_t)N * N * N;
+    for (auto& D : ctx->dev) {
+        int rc = free_device_volume(D, slot);
+        if (rc != VRT_OK) return rc;
+        HIP_TRY(hipSetDevice(D.ordinal));
+        DeviceVolume& v = D.vol[slot];
+        HIP_TRY(hipMalloc(&v.dense, count * sizeof(float)));
+        HIP_TRY(hipMalloc(&v.material, count));
+        HIP_TRY(hipMalloc(&v.bricks, (size_t)nb * nb * nb * kBrickFloats * sizeof(float)));
+        if (voxels) {
+            void* staging = nullptr;
+            HIP_TRY(hipMalloc(&staging, count * sizeof(vrt_voxel)));
+            hipError_t e = hipMemcpyAsync(staging, voxels, count * sizeof(vrt_voxel), hipMemcpyHostToDevice, D.stream);
+            if (e == hipSuccess) e = launch_split_voxels(staging, v.dense, v.material, count, D.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(D.stream);
+            (void)hipFree(staging);
+            HIP_TRY(e);
+        } else {
+            HIP_TRY(hipMemcpyAsync(v.dense, density, count * sizeof(float), hipMemcpyHostToDevice, D.stream));
+            if (material)
+                HIP_TRY(hipMemcpyAsync(v.material, material, count, hipMemcpyHostToDevice, D.stream));
+            else
+                HIP_TRY(hipMemsetAsync(v.material, 0, count, D.stream));
+        }
+        HIP_TRY(launch_retile(v.dense, v.bricks, N, nb, D.stream));
+        HIP_TRY(hipStreamSynchronize(D.stream));
+    }
+    HostVolume& h = ctx->vol[slot];
+    const bool was_used = h.used;
+    h.used = true;
+    h.resolution = resolution;
+    h.N = N;
+    h.nb = nb;
+    h.extent = extent;
+    if (!was_used) {
+        h.density_scale = 1.0f;
+        h.step_max = 0.0f;
+        h.mat = vrt_material{{0.8f, 0.8f, 0.8f, 1.0f}, 0.8f, 0.0f};
+    }
+    return sync_volume_table(ctx);
+}
+
+int pack_scene(vrt_ctx* ctx) {
+    const vrt_scene& s = ctx->scene;
+    std::vector<Box> boxes((size_t)s.n_instances);
+    for (int i = 0; i < s.n_instances; i++) {
+        pack_instance(s.instances[i], ctx->inst[i]);
+        boxes[(size_t)i] = instance_box(ctx->inst[i], ctx->vol[s.instances[i].volume_slot].extent);
+    }
+    ctx->n_nodes = 0;
+    if (s.n_instances > 0) {
+        std::vector<int> ids((size_t)s.n_instances);
+        for (int i = 0; i < s.n_instances; i++) ids[(size_t)i] = i;
+        build_bvh(ids, 0, s.n_instances, boxes, ctx->nodes, ctx->n_nodes);
+    }
+    const int npl = std::min(s.n_point_lights, VRT_MAX_POINT_LIGHTS);
+    for (int i = 0; i < npl; i++) {
+        const vrt_point_light& L = s.point_lights[i];
+        DPointLight& o = ctx->point[i];
+        memset(&o, 0, sizeof o);
+        memcpy(o.pos, L.position, sizeof o.pos);
+        memcpy(o.color, L.color, sizeof o.color);
+        o.intensity = L.intensity;
+        o.att_linear = L.att_linear;
+        o.att_exp = L.att_exp;
+    }
+    const int nsl = std::min(s.n_spot_lights, VRT_MAX_SPOT_LIGHTS);
+    for (int i = 0; i < nsl; i++) {
+        const vrt_spot_light& L = s.spot_lights[i];
+        DSpotLight& o = ctx->spot[i];
+        memset(&o, 0, sizeof o);
+        memcpy(o.pos, L.position, sizeof o.pos);
+        memcpy(o.fwd, L.forward, sizeof o.fwd);
+        memcpy(o.color, L.color, sizeof o.color);
+        o.intensity = L.intensity;
+        o.att_linear = L.att_linear;
+        o.att_exp = L.att_exp;
+        o.cos_angle = L.cos_angle;
+        o.cos_falloff = L.cos_falloff_angle;
+    }
+    for (auto& D : ctx->dev) {
+        HIP_TRY(hipSetDevice(D.ordinal));
+        if (s.n_instances > 0) {
+            HIP_TRY(hipMemcpy(D.d_inst, ctx->inst, sizeof(DInstance) * (size_t)s.n_instances, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(D.d_nodes, ctx->nodes, sizeof(DBvhNode) * (size_t)ctx->n_nodes, hipMemcpyHostToDevice));
+        }
+        if (npl > 0) HIP_TRY(hipMemcpy(D.d_point, ctx->point, sizeof(DPointLight) * (size_t)npl, hipMemcpyHostToDevice));
+        if (nsl > 0) HIP_TRY(hipMemcpy(D.d_spot, ctx->spot, sizeof(DSpotLight) * (size_t)nsl, hipMemcpyHostToDevice));
+    }
+    return VRT_OK;
+}
+
+int check_params(const vrt_ctx* ctx, const vrt_params* p) {
+    if (!ctx || !p) return VRT_ERR_INVALID;
+    if (p->width <= 0 || p->height <= 0 || p->width > 16384 || p->height > 16384) return VRT_ERR_INVALID;
+    if (p->max_steps < 0 || p->max_bounces < 0 || p->max_bounces > 2) return VRT_ERR_INVALID;
+    if (!(p->eps_hit == p->eps_hit) || !(p->step_min > 0.0f) || !(p->k_relax > 0.0f) || !(p->eps_in >= 0.0f))
+        return VRT_ERR_INVALID;
+    if (p->mode < VRT_MODE_INTERP || p->mode > VRT_MODE_CUBE_NOTEX_UNLIT) return VRT_ERR_INVALID;
+    if (p->mode >= VRT_MODE_CUBE) return VRT_ERR_UNSUPPORTED; /* Cube* modes: SURVEY §8f */
+    if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_BRICK_LDS) return VRT_ERR_INVALID;
+    if (!ctx->have_scene) return VRT_ERR_NOT_READY;
+    if (p->max_bounces > 0 || ctx->scene.n_point_lights > 0 || ctx->scene.n_spot_lights > 0)
+        return VRT_ERR_UNSUPPORTED; /* full closest-hit: SURVEY §8f-2 (next) */
+    return VRT_OK;
+}
+
+int resolve_path(int path) {
+    if (path == VRT_PATH_AUTO) return VRT_PATH_BRICK;
+    if (path == VRT_PATH_BRICK_LDS) return VRT_PATH_BRICK; /* TODO(round 1): LDS brick cache */
+    return path;
+}
+
+void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, int row0, int rows, float* out,
+                 unsigned long long* stats, DFrame& F) {
+    memset(&F, 0, sizeof F);
+    pack_camera(ctx->scene, p->width, p->height, F);
+    F.light_dir[0] = ctx->scene.light_dir[0];
+    F.light_dir[1] = ctx->scene.light_dir[1];
+    F.light_dir[2] = ctx->scene.light_dir[2];
+    F.light_strength = ctx->scene.light_strength;
+    F.eps_hit = p->eps_hit;
+    F.eps_in = p->eps_in;
+    F.step_min = p->step_min;
+    F.k_relax = p->k_relax;
+    F.max_steps = p->max_steps;
+    F.shadow = p->shadow ? 1 : 0;
+    F.unlit = (p->mode == VRT_MODE_INTERP_UNLIT || p->mode == VRT_MODE_INTERP_NOTEX_UNLIT) ? 1 : 0;
+    F.max_bounces = p->max_bounces;
+    F.width = p->width;
+    F.height = p->height;
+    F.row0 = row0;
+    F.rows = rows;
+    F.tiles_x = (p->width + 15) / 16;
+    F.tiles_y = (rows + 15) / 16;
+    F.n_inst = ctx->scene.n_instances;
+    F.n_nodes = ctx->n_nodes;
+    F.n_point = std::min(ctx->scene.n_point_lights, VRT_MAX_POINT_LIGHTS);
+    F.n_spot = std::min(ctx->scene.n_spot_lights, VRT_MAX_SPOT_LIGHTS);
+    F.vols = D.d_vols;
+    F.inst = D.d_inst;
+    F.nodes = D.d_nodes;
+    F.point = D.d_point;
+    F.spot = D.d_spot;
+    F.env = ctx->env_size > 0 ? D.d_env : nullptr;
+    F.env_size = ctx->env_size;
+    F.out = out;
+    F.stats = stats;
+}
+
+/* Enqueue one tile on one device.  No allocation, no host sync. */
+int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, int row0, int rows, float* out, hipStream_t stream,
+                 int ring) {
+    unsigned long long* stats = D.d_stats + (size_t)ring * kStatWords;
+    DFrame F;
+    build_frame(ctx, D, p, row0, rows, out, stats, F);
+    HIP_TRY(hipMemsetAsync(stats, 0, sizeof(unsigned long long) * kStatWords, stream));
+    HIP_TRY(hipEventRecord(D.ev0[ring], stream));
+    HIP_TRY(launch_march(F, resolve_path(p->path), ctx->scene.n_instances == 1, stream));
+    HIP_TRY(hipEventRecord(D.ev1[ring], stream));
+    return VRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vrt_create(vrt_ctx** out, int device_count, const int* devices) {
+    if (!out || device_count < 1 || device_count > VRT_MAX_DEVICES) return VRT_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return VRT_ERR_NO_DEVICE;
+    for (int i = 0; i < device_count; i++) {
+        int ord = devices ? devices[i] : i;
+        if (ord < 0 || ord >= n) return VRT_ERR_NO_DEVICE;
+    }
+    vrt_ctx* ctx = new (std::nothrow) vrt_ctx;
+    if (!ctx) return VRT_ERR_OOM;
+    memset(&ctx->scene, 0, sizeof ctx->scene);
+    ctx->dev.resize((size_t)device_count);
+    for (int i = 0; i < device_count; i++) {
+        int rc = init_device(ctx->dev[(size_t)i], devices ? devices[i] : i);
+        if (rc != VRT_OK) {
+            for (auto& D : ctx->dev) destroy_device(D);
+            delete ctx;
+            return rc;
+        }
+    }
+    /* peer access for the tile gather (xGMI); failure is not fatal, hipMemcpyPeer still works */
+    for (int i = 1; i < device_count; i++) {
+        if (ctx->dev[(size_t)i].ordinal == ctx->dev[0].ordinal) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, ctx->dev[(size_t)i].ordinal, ctx->dev[0].ordinal) == hipSuccess && can) {
+            (void)hipSetDevice(ctx->dev[(size_t)i].ordinal);
+            (void)hipDeviceEnablePeerAccess(ctx->dev[0].ordinal, 0);
+            (void)hipGetLastError();
+        }
+    }
+    *out = ctx;
+    return VRT_OK;
+}
+
+int vrt_destroy(vrt_ctx* ctx) {
+    if (!ctx) return VRT_ERR_INVALID;
+    for (auto& D : ctx->dev) {
+        if (hipSetDevice(D.ordinal) == hipSuccess) (void)hipDeviceSynchronize();
+    }
+    if (ctx->gather && !ctx->dev.empty() && hipSetDevice(ctx->dev[0].ordinal) == hipSuccess) (void)hipFree(ctx->gather);
+    for (auto& D : ctx->dev) destroy_device(D);
+    delete ctx;
+    return VRT_OK;
+}
+
+int vrt_volume_upload(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, const float* density,
+                      const uint8_t* material_or_null) {
+    if (!ctx || !density) return VRT_ERR_INVALID;
+    return upload_volume(ctx, slot, resolution, extent, density, material_or_null, nullptr);
+}
+
+int vrt_volume_upload_voxels(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, const vrt_voxel* voxels) {
+    if (!ctx || !voxels) return VRT_ERR_INVALID;
+    return upload_volume(ctx, slot, resolution, extent, nullptr, nullptr, voxels);
+}
+
+int vrt_volume_set_material(vrt_ctx* ctx, int slot, const vrt_material* material) {
+    if (!ctx || !material) return VRT_ERR_INVALID;
+    if (!valid_slot(slot) || !ctx->vol[slot].used) return VRT_ERR_SLOT;
+    ctx->vol[slot].mat = *material;
+    return sync_volume_table(ctx);
+}
+
+int vrt_volume_set_metric(vrt_ctx* ctx, int slot, float density_scale, float step_max) {
+    if (!ctx || !(density_scale > 0.0f)) return VRT_ERR_INVALID;
+    if (!valid_slot(slot) || !ctx->vol[slot].used) return VRT_ERR_SLOT;
+    ctx->vol[slot].density_scale = density_scale;
+    ctx->vol[slot].step_max = step_max;
+    return sync_volume_table(ctx);
+}
+
+int vrt_volume_free(vrt_ctx* ctx, int slot) {
+    if (!ctx) return VRT_ERR_INVALID;
+    if (!valid_slot(slot) || !ctx->vol[slot].used) return VRT_ERR_SLOT;
+    if (ctx->have_scene)
+        for (int i = 0; i < ctx->scene.n_instances; i++)
+            if (ctx->scene.instances[i].volume_slot == slot) ctx->have_scene = false; /* scene must be re-set */
+    for (auto& D : ctx->dev) {
+        HIP_TRY(hipSetDevice(D.ordinal));
+        HIP_TRY(hipDeviceSynchronize());
+        int rc = free_device_volume(D, slot);
+        if (rc != VRT_OK) return rc;
+    }
+    ctx->vol[slot] = HostVolume();
+    return sync_volume_table(ctx);
+}
+
+int vrt_env_upload(vrt_ctx* ctx, int face_size, const uint8_t* rgba8_faces) {
+    if (!ctx || face_size < 0 || face_size > 8192) return VRT_ERR_INVALID;
+    if (face_size > 0 && !rgba8_faces) return VRT_ERR_INVALID;
+    const size_t bytes = (size_t)6 * face_size * face_size * 4;
+    for (auto& D : ctx->dev) {
+        HIP_TRY(hipSetDevice(D.ordinal));
+        HIP_TRY(hipDeviceSynchronize());
+        if (D.d_env) {
+            HIP_TRY(hipFree(D.d_env));
+            D.d_env = nullptr;
+        }
+        if (face_size > 0) {
+            HIP_TRY(hipMalloc(&D.d_env, bytes));
+            HIP_TRY(hipMemcpy(D.d_env, rgba8_faces, bytes, hipMemcpyHostToDevice));
+        }
+    }
+    ctx->env_size = face_size;
+    return VRT_OK;
+}
+
+int vrt_scene_set(vrt_ctx* ctx, const vrt_scene* scene) {
+    if (!ctx || !scene) return VRT_ERR_INVALID;
+    if (scene->n_instances < 0 || scene->n_instances > VRT_MAX_INSTANCES) return VRT_ERR_INVALID;
+    if (scene->n_point_lights < 0 || scene->n_spot_lights < 0) return VRT_ERR_INVALID;
+    for (int i = 0; i < scene->n_instances; i++) {
+        const vrt_instance& I = scene->instances[i];
+        if (!valid_slot(I.volume_slot) || !ctx->vol[I.volume_slot].used) return VRT_ERR_SLOT;
+        if (I.scale[0] == 0.0f || I.scale[1] == 0.0f || I.scale[2] == 0.0f) return VRT_ERR_INVALID;
+    }
+    ctx->scene = *scene;
+    ctx->have_scene = false;
+    int rc = pack_scene(ctx);
+    if (rc != VRT_OK) return rc;
+    ctx->have_scene = true;
+    return VRT_OK;
+}
+
+int vrt_render_rows(vrt_ctx* ctx, const vrt_params* params, int row0, int rows, void* device_rgba, void* hip_stream) {
+    int rc = check_params(ctx, params);
+    if (rc != VRT_OK) return rc;
+    if (row0 < 0 || rows < 0 || row0 + rows > params->height || (!device_rgba && rows > 0)) return VRT_ERR_INVALID;
+    DeviceState& D = ctx->dev[0];
+    HIP_TRY(hipSetDevice(D.ordinal));
+    const int ring = (int)(ctx->launches % kRing);
+    rc = enqueue_rows(ctx, D, params, row0, rows, static_cast<float*>(device_rgba), static_cast<hipStream_t>(hip_stream), ring);
+    if (rc != VRT_OK) return rc;
+    ctx->launches++;
+    ctx->last_devices = 1;
+    ctx->last_w = (uint32_t)params->width;
+    ctx->last_h = (uint32_t)rows;
+    ctx->last_gather_ms = 0.f;
+    ctx->last_total_ms = 0.f;
+    return VRT_OK;
+}
+
+int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null) {
+    int rc = check_params(ctx, params);
+    if (rc != VRT_OK) return rc;
+    const int n = (int)ctx->dev.size();
+    const int W = params->width, H = params->height;
+    const size_t row_bytes = (size_t)W * 4 * sizeof(float);
+    auto t0 = std::chrono::steady_clock::now();
+
+    /* contiguous row tiles, GPU g renders rows [g*H/n, (g+1)*H/n)   */
+    std::vector<int> r0((size_t)n + 1);
+    for (int g = 0; g <= n; g++) r0[(size_t)g] = (int)(((long long)g * H) / n);
+
+    for (int g = 0; g < n; g++) {
+        DeviceState& D = ctx->dev[(size_t)g];
+        const int rows = r0[(size_t)g + 1] - r0[(size_t)g];
+        const size_t need = std::max<size_t>((size_t)rows * row_bytes, 16);
+        HIP_TRY(hipSetDevice(D.ordinal));
+        if (D.fb_bytes < need) {
+            if (D.fb) HIP_TRY(hipFree(D.fb));
+            D.fb = nullptr;
+            D.fb_bytes = 0;
+            HIP_TRY(hipMalloc(&D.fb, need));
+            D.fb_bytes = need;
+        }
+    }
+    if (n > 1) {
+        const size_t need = (size_t)H * row_bytes;
+        HIP_TRY(hipSetDevice(ctx->dev[0].ordinal));
+        if (ctx->gather_bytes < need) {
+            if (ctx->gather) HIP_TRY(hipFree(ctx->gather));
+            ctx->gather = nullptr;
+            ctx->gather_bytes = 0;
+            HIP_TRY(hipMalloc(&ctx->gather, need));
+            ctx->gather_bytes = need;
+        }
+    }
+
+    const int ring = (int)(ctx->launches % kRing);
+    for (int g = 0; g < n; g++) {
+        DeviceState& D = ctx->dev[(size_t)g];
+        HIP_TRY(hipSetDevice(D.ordinal));
+        rc = enqueue_rows(ctx, D, params, r0[(size_t)g], r0[(size_t)g + 1] - r0[(size_t)g], D.fb, D.stream, ring);
+        if (rc != VRT_OK) return rc;
+    }
+    ctx->launches++;
+    ctx->last_devices = n;
+    ctx->last_w = (uint32_t)W;
+    ctx->last_h = (uint32_t)H;
+
+    float gather_ms = 0.f;
+    if (n > 1) {
+        /* wait for the kernels, then gather every tile into device 0's full frame over the
+           peer links (one point-to-point copy per source GPU, all concurrent) */
+        for (int g = 0; g < n; g++) {
+            HIP_TRY(hipSetDevice(ctx->dev[(size_t)g].ordinal));
+            HIP_TRY(hipStreamSynchronize(ctx->dev[(size_t)g].stream));
+        }
+        auto g0 = std::chrono::steady_clock::now();
+        for (int g = 0; g < n; g++) {
+            DeviceState& D = ctx->dev[(size_t)g];
+            const size_t bytes = (size_t)(r0[(size_t)g + 1] - r0[(size_t)g]) * row_bytes;
+            if (bytes == 0) continue;
+            HIP_TRY(hipSetDevice(D.ordinal));
+            char* dst = reinterpret_cast<char*>(ctx->gather) + (size_t)r0[(size_t)g] * row_bytes;
+            HIP_TRY(hipMemcpyPeerAsync(dst, ctx->dev[0].ordinal, D.fb, D.ordinal, bytes, D.stream));
+        }
+        for (int g = 0; g < n; g++) {
+            HIP_TRY(hipSetDevice(ctx->dev[(size_t)g].ordinal));
+            HIP_TRY(hipStreamSynchronize(ctx->dev[(size_t)g].stream));
+        }
+        gather_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - g0).count();
+        if (host_rgba_or_null) {
+            HIP_TRY(hipSetDevice(ctx->dev[0].ordinal));
+            HIP_TRY(hipMemcpy(host_rgba_or_null, ctx->gather, (size_t)H * row_bytes, hipMemcpyDeviceToHost));
+        }
+    } else {
+        DeviceState& D = ctx->dev[0];
+        HIP_TRY(hipSetDevice(D.ordinal));
+        if (host_rgba_or_null)
+            HIP_TRY(hipMemcpyAsync(host_rgba_or_null, D.fb, (size_t)H * row_bytes, hipMemcpyDeviceToHost, D.stream));
+        HIP_TRY(hipStreamSynchronize(D.stream));
+    }
+    ctx->last_gather_ms = gather_ms;
+    ctx->last_total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return VRT_OK;
+}
+
+int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out) {
+    if (!ctx || !out) return VRT_ERR_INVALID;
+    if (ctx->launches == 0) return VRT_ERR_NOT_READY;
+    memset(out, 0, sizeof *out);
+    const int ring = (int)((ctx->launches - 1) % kRing);
+    unsigned long long tot[kStatWords] = {0, 0, 0, 0, 0, 0};
+    float kernel_ms = 0.f;
+    for (int g = 0; g < ctx->last_devices; g++) {
+        DeviceState& D = ctx->dev[(size_t)g];
+        HIP_TRY(hipSetDevice(D.ordinal));
+        HIP_TRY(hipEventSynchronize(D.ev1[ring]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, D.ev0[ring], D.ev1[ring]));
+        kernel_ms = std::max(kernel_ms, ms);
+        unsigned long long s[kStatWords];
+        HIP_TRY(hipMemcpy(s, D.d_stats + (size_t)ring * kStatWords, sizeof s, hipMemcpyDeviceToHost));
+        for (int k = 0; k < kStatWords; k++) tot[k] += s[k];
+    }
+    out->kernel_ms = kernel_ms;
+    out->gather_ms = ctx->last_gather_ms;
+    out->total_ms = ctx->last_total_ms;
+    out->width = ctx->last_w;
+    out->height = ctx->last_h;
+    out->primary_rays = tot[0];
+    out->shadow_rays = tot[1];
+    out->bounce_rays = tot[2];
+    out->primary_steps = tot[3];
+    out->shadow_steps = tot[4];
+    out->hits = tot[5];
+    return VRT_OK;
+}
+
+int vrt_timing_history(vrt_ctx* ctx, int n, float* kernel_ms_out) {
+    if (!ctx || n < 0 || (n > 0 && !kernel_ms_out)) return VRT_ERR_INVALID;
+    const uint64_t have = std::min<uint64_t>(ctx->launches, (uint64_t)kRing);
+    const int m = (int)std::min<uint64_t>(have, (uint64_t)n);
+    DeviceState& D = ctx->dev[0];
+    HIP_TRY(hipSetDevice(D.ordinal));
+    for (int i = 0; i < m; i++) {
+        const uint64_t launch = ctx->launches - (uint64_t)m + (uint64_t)i;
+        const int ring = (int)(launch % kRing);
+        HIP_TRY(hipEventSynchronize(D.ev1[ring]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, D.ev0[ring], D.ev1[ring]));
+        kernel_ms_out[i] = ms;
+    }
+    return m;
+}
+
+const char* vrt_strerror(int status) {
+    switch (status) {
+        case VRT_OK: return "ok";
+        case VRT_ERR_INVALID: return "invalid argument";
+        case VRT_ERR_NO_DEVICE: return "no usable HIP device";
+        case VRT_ERR_HIP: return "HIP runtime call failed";
+        case VRT_ERR_OOM: return "out of device memory";
+        case VRT_ERR_SLOT: return "volume slot out of range or empty";
+        case VRT_ERR_NOT_READY: return "scene or volume not set";
+        case VRT_ERR_UNSUPPORTED: return "render mode / feature not implemented";
+        default: return "unknown status";
+    }
+}
+
+const char* vrt_version(void) { return "0.1.0 gfx950"; }
+
+}  // extern "C"

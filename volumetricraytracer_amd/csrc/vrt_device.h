@@ -1,0 +1,110 @@
+/*
+ * vrt_device.h — flat device-side structs shared by the host runtime (vrt_api.hip) and the
+ * gfx950 kernels (vrt_kernels.hip).  These are what the reference kept in D3D12 constant
+ * buffers / the TLAS (Shaders/RaytracingHlsl.h:53-100, RDXScene.cpp:454-545), re-laid for
+ * scalar (SGPR) loads from the kernarg segment and small read-only global arrays.
+ */
+#pragma once
+#include <stdint.h>
+
+namespace vrt {
+
+constexpr int kBrickCells = 4;                 /* cells per brick edge */
+constexpr int kBrickSamples = 5;               /* samples per brick edge (cells + 1 apron) */
+constexpr int kBrickFloats = 128;              /* 125 samples padded to 512 B = 4 x 128-B lines */
+constexpr int kTile = 8;                       /* one wave = 8x8 pixels */
+constexpr int kBlockThreads = 256;             /* 4 waves = 16x16 pixels */
+constexpr int kMaxBvhNodes = 2 * 64 - 1;
+constexpr int kStatWords = 6;
+
+/* Per-volume record (VGeometryConstantBuffer analogue). */
+struct DVolume {
+    const float* dense;    /* N^3 fp32, index x*N*N + z*N + y */
+    const float* bricks;   /* nb^3 bricks x 128 floats, brick (bx,bz,by) major like the dense grid,
+                              in-brick index lx*25 + lz*5 + ly */
+    int32_t N;
+    int32_t nb;
+    float extent;
+    float inv_cell;
+    float density_scale;
+    float step_max;        /* +inf when unbounded */
+    float tint[3];
+    float roughness;       /* clamped to [0,1] */
+    float metallic;        /* clamped to [0,1] */
+    float k;               /* (roughness+1)^2 / 8 from the unclamped roughness */
+    float pad_[2];
+};
+
+struct DInstance {
+    float w2o[9];          /* R^T * S^-1, row-major */
+    float o2w[9];          /* S * R, row-major */
+    float pos[3];
+    int32_t slot;
+    float pad_[2];
+};
+
+/* Flat AABB BVH over instance world boxes.  Leaf: left = -(instance+1). */
+struct DBvhNode {
+    float lo[3];
+    int32_t left;
+    float hi[3];
+    int32_t right;
+};
+
+struct DPointLight {
+    float pos[3];
+    float intensity;
+    float color[3];
+    float att_linear;
+    float att_exp;
+    float pad_[3];
+};
+
+struct DSpotLight {
+    float pos[3];
+    float intensity;
+    float fwd[3];
+    float att_linear;
+    float color[3];
+    float att_exp;
+    float cos_angle;
+    float cos_falloff;
+    float pad_[2];
+};
+
+/* Everything a launch needs; passed by value (kernarg segment → scalar loads). */
+struct DFrame {
+    /* camera */
+    float cam_o[3];
+    float r0[3], r1[3], r2[3];
+    float cx, cy;
+    /* directional light */
+    float light_dir[3];
+    float light_strength;
+    /* march contract */
+    float eps_hit, eps_in, step_min, k_relax;
+    int32_t max_steps;
+    int32_t shadow;
+    int32_t unlit;
+    int32_t max_bounces;
+    /* frame geometry */
+    int32_t width, height;
+    int32_t row0, rows;        /* this launch renders rows [row0,row0+rows) */
+    int32_t tiles_x, tiles_y;  /* 16x16-pixel blocks covering width x rows */
+    /* scene arrays */
+    int32_t n_inst, n_nodes;
+    int32_t n_point, n_spot;
+    const DVolume* vols;
+    const DInstance* inst;
+    const DBvhNode* nodes;
+    const DPointLight* point;
+    const DSpotLight* spot;
+    const uint8_t* env;        /* 6 x S x S RGBA8 or null */
+    int32_t env_size;
+    int32_t pad_;
+    float* out;                /* rows x width float4 */
+    unsigned long long* stats; /* kStatWords counters: primary_rays, shadow_rays, bounce_rays,
+                                  primary_steps, shadow_steps, hits */
+};
+
+}  // namespace vrt

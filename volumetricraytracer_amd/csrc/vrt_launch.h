@@ -1,0 +1,17 @@
+/* vrt_launch.h — host-callable launch wrappers implemented in vrt_kernels.hip. */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/vrt.h"
+#include "vrt_device.h"
+
+namespace vrt {
+
+/* path: VRT_PATH_DENSE / VRT_PATH_BRICK / VRT_PATH_BRICK_LDS (already resolved, never AUTO). */
+hipError_t launch_march(const DFrame& frame, int path, bool single_instance, hipStream_t stream);
+hipError_t launch_retile(const float* dense, float* bricks, int N, int nb, hipStream_t stream);
+hipError_t launch_split_voxels(const void* voxels, float* density, uint8_t* material, size_t count,
+                               hipStream_t stream);
+
+}  // namespace vrt

@@ -1,0 +1,172 @@
+"""Python host wrapper over the C-ABI: the `VRenderer` surface of the reference
+(Renderer/Public/Renderer.h:44-66 — Start/Stop/IsActive/SetSceneToRender/Render/
+ResizeRenderOutput/SetRendererMode) for the HIP backend.  Used by tests and bench.py; the C++
+adaptor with the same shape is csrc/host/HipRenderer.h.
+
+Everything here calls into libvrt_hip.so.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from .scene import VScene, VVoxelVolume, default_params
+
+
+class VHipRenderer:
+    def __init__(self, devices: Sequence[int] = (0,)):
+        self._lib = _abi.load()
+        self._devices = list(devices)
+        self._ctx = C.c_void_p()
+        self._scene: Optional[VScene] = None
+        self._slots: List[VVoxelVolume] = []
+        self._uploaded: Dict[int, int] = {}  # slot -> id(volume) currently on the device
+        self.RenderMode = _abi.MODE_INTERP
+        self.Width, self.Height = 1024, 576  # default window, UI/Win/Private/Win32Window.cpp:218-219
+        self.params_override: Optional[_abi.vrt_params] = None
+        self.DataPath = _abi.PATH_AUTO
+        self.Shadows = True
+        self.MaxSteps = 255  # Raytracing.hlsl:229
+        self._env_id = None
+
+    # -- VRenderer surface -------------------------------------------------------------------
+    def Start(self) -> bool:
+        """VDXRenderer::Start: bring the device up; False (after logging) on failure."""
+        if self._ctx:
+            return True
+        arr = (C.c_int * len(self._devices))(*self._devices)
+        rc = self._lib.vrt_create(C.byref(self._ctx), len(self._devices), arr)
+        if rc != _abi.VRT_OK:
+            print(f"[VHipRenderer] Start failed: {self._lib.vrt_strerror(rc).decode()}")
+            self._ctx = C.c_void_p()
+            return False
+        return True
+
+    def Stop(self) -> None:
+        if self._ctx:
+            self._lib.vrt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+            self._uploaded.clear()
+            self._env_id = None
+
+    def IsActive(self) -> bool:
+        return bool(self._ctx)
+
+    def SetSceneToRender(self, scene: VScene) -> None:
+        self._scene = scene
+
+    def SetRendererMode(self, mode: int) -> None:
+        self.RenderMode = int(mode)
+
+    def ResizeRenderOutput(self, width: int, height: int) -> None:
+        self.Width, self.Height = int(width), int(height)
+
+    def Render(self) -> np.ndarray:
+        """One frame: sync scene → device, march, return the float RGBA image [H, W, 4]."""
+        self._require()
+        self.SyncWithScene()
+        p = self.make_params()
+        out = np.empty((p.height, p.width, 4), dtype=np.float32)
+        _abi.check(self._lib.vrt_render(self._ctx, C.byref(p), out.ctypes.data_as(C.c_void_p)), "vrt_render")
+        return out
+
+    # -- scene mirroring (VRDXScene::SyncWithScene) --------------------------------------------
+    def SyncWithScene(self) -> None:
+        self._require()
+        sc = self._scene
+        if sc is None:
+            raise RuntimeError("SetSceneToRender was not called")
+        vols = sc.volumes()
+        for slot, vol in enumerate(vols):
+            if self._uploaded.get(slot) != id(vol) or vol.dirty:
+                self.upload_volume(slot, vol)
+        for slot in [s for s in self._uploaded if s >= len(vols)]:
+            _abi.check(self._lib.vrt_volume_free(self._ctx, slot), "vrt_volume_free")
+            del self._uploaded[slot]
+        env = sc.EnvironmentMap
+        if env is None:
+            if self._env_id is not None:
+                _abi.check(self._lib.vrt_env_upload(self._ctx, 0, None), "vrt_env_upload")
+                self._env_id = None
+        elif self._env_id != id(env):
+            e = np.ascontiguousarray(env, dtype=np.uint8)
+            if e.ndim != 4 or e.shape[0] != 6 or e.shape[1] != e.shape[2] or e.shape[3] != 4:
+                raise ValueError("EnvironmentMap must be uint8 [6, S, S, 4]")
+            _abi.check(self._lib.vrt_env_upload(self._ctx, e.shape[1], e.ctypes.data_as(C.c_void_p)), "vrt_env_upload")
+            self._env_id = id(env)
+        abi_scene = sc.to_abi()
+        _abi.check(self._lib.vrt_scene_set(self._ctx, C.byref(abi_scene)), "vrt_scene_set")
+
+    def upload_volume(self, slot: int, vol: VVoxelVolume, as_voxels: bool = False) -> None:
+        self._require()
+        if as_voxels:
+            rec = vol.voxel_records()
+            rc = self._lib.vrt_volume_upload_voxels(self._ctx, slot, vol.Resolution, vol.VolumeExtends,
+                                                    rec.ctypes.data_as(C.c_void_p))
+        else:
+            d = np.ascontiguousarray(vol.density, dtype=np.float32)
+            m = np.ascontiguousarray(vol.material_id, dtype=np.uint8)
+            rc = self._lib.vrt_volume_upload(self._ctx, slot, vol.Resolution, vol.VolumeExtends,
+                                             d.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p))
+        _abi.check(rc, "vrt_volume_upload")
+        mat = vol.Material.to_abi()
+        _abi.check(self._lib.vrt_volume_set_material(self._ctx, slot, C.byref(mat)), "vrt_volume_set_material")
+        _abi.check(self._lib.vrt_volume_set_metric(self._ctx, slot, float(vol.density_scale), float(vol.step_max)),
+                   "vrt_volume_set_metric")
+        self._uploaded[slot] = id(vol)
+        vol.dirty = False
+
+    # -- parameters / raw launches ---------------------------------------------------------------
+    def make_params(self) -> _abi.vrt_params:
+        if self.params_override is not None:
+            p = _abi.vrt_params.from_buffer_copy(self.params_override)
+        else:
+            cell = min((v.GetCellSize() for v in self._scene.volumes()), default=1.0) if self._scene else 1.0
+            p = default_params(self.Width, self.Height, cell, max_steps=self.MaxSteps, shadow=self.Shadows)
+        p.width, p.height = self.Width, self.Height
+        p.mode = self.RenderMode
+        if self.params_override is None:
+            p.path = self.DataPath
+        return p
+
+    def render_rows(self, params: _abi.vrt_params, row0: int, rows: int, device_ptr: int, stream: int = 0) -> None:
+        """Asynchronous tile render into caller-owned device memory (vrt_render_rows)."""
+        self._require()
+        _abi.check(self._lib.vrt_render_rows(self._ctx, C.byref(params), row0, rows, C.c_void_p(device_ptr),
+                                             C.c_void_p(stream)), "vrt_render_rows")
+
+    def last_timing(self) -> dict:
+        self._require()
+        t = _abi.vrt_timing()
+        _abi.check(self._lib.vrt_last_timing(self._ctx, C.byref(t)), "vrt_last_timing")
+        return {name: getattr(t, name) for name, _ in t._fields_}
+
+    def timing_history(self, n: int) -> List[float]:
+        self._require()
+        buf = (C.c_float * max(n, 1))()
+        m = self._lib.vrt_timing_history(self._ctx, n, buf)
+        if m < 0:
+            _abi.check(m, "vrt_timing_history")
+        return [buf[i] for i in range(m)]
+
+    def _require(self) -> None:
+        if not self._ctx:
+            raise RuntimeError("renderer is not active (Start() not called or failed)")
+
+    def __enter__(self):
+        if not self.Start():
+            raise RuntimeError("VHipRenderer.Start() failed — no HIP device or library error")
+        return self
+
+    def __exit__(self, *exc):
+        self.Stop()
+        return False
+
+
+def algorithmic_bytes(t: dict, bytes_per_pixel: int = 16) -> int:
+    """32 B per trilinear sample, 6 samples per hit normal, framebuffer store."""
+    samples = t["primary_steps"] + t["shadow_steps"]
+    return 32 * samples + 32 * 6 * t["hits"] + bytes_per_pixel * t["width"] * t["height"]
