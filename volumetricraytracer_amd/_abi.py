@@ -156,6 +156,22 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libv
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7 /
+    libhsa-runtime64; if ours (from /opt/rocm) is loaded first and torch's second, the second
+    ROCr instance finds no GPU.  Both have the soname libamdhip64.so.7, so importing torch
+    first makes the dynamic loader resolve our DT_NEEDED entry to the copy torch already
+    mapped.  Without torch installed this is a no-op and the system ROCm runtime is used."""
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("VRT_NO_TORCH_PRELOAD") == "1":
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def load(path: str | None = None) -> C.CDLL:
     """Load libvrt_hip.so and bind every entry point.  Raises if it is not built."""
     global _lib
@@ -168,6 +184,7 @@ def load(path: str | None = None) -> C.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` (or volumetricraytracer_amd/csrc/build.sh). "
             "There is no CPU fallback."
         )
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(p)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
