@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile_bench.sh output directory into a small text + JSON summary that
+is copied into profiles/ (tracked).  HBM traffic follows MI355X_MICROARCH.md §HBM: FETCH_SIZE
+and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced
+reads — both the raw and the x2-corrected read figure are recorded."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+summary = {"tag": tag}
+lines = []
+
+stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    lines.append("== rocprofv3 --kernel-trace --stats (kernel_stats.csv) ==")
+    for r in rows[:12]:
+        lines.append("  ".join(f"{k}={r[k]}" for k in r))
+    for r in rows:
+        if "march_kernel" in r.get("Name", ""):
+            summary["march_kernel"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                       "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]),
+                                       "total_ns": float(r["TotalDurationNs"]), "pct": float(r["Percentage"])}
+trace = glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True)
+if trace:
+    rows = [r for r in csv.DictReader(open(trace[0])) if "march_kernel" in r.get("Kernel_Name", "")]
+    if rows:
+        r = rows[-1]
+        summary["march_kernel_dispatch"] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
+        lines.append("== last march_kernel dispatch ==")
+        lines.append(json.dumps(summary["march_kernel_dispatch"]))
+
+for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    files = glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        continue
+    per = defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        if "march_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == key:
+            per[r.get("Dispatch_Id")].append(float(r["Counter_Value"]))
+    vals = [sum(v) for v in per.values()]
+    if vals:
+        mean_kib = sum(vals) / len(vals)
+        summary[key + "_KiB_per_launch"] = mean_kib
+        lines.append(f"== {key}: mean over {len(vals)} march_kernel dispatches = {mean_kib:.1f} KiB per launch ==")
+
+for b in ("bench_trace.json", "bench_fetch.json", "bench_write.json"):
+    p = os.path.join(out, b)
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+        try:
+            summary[b] = json.loads(open(p).read().strip().splitlines()[-1])
+        except Exception:
+            pass
+
+if "FETCH_SIZE_KiB_per_launch" in summary and "WRITE_SIZE_KiB_per_launch" in summary:
+    rd = summary["FETCH_SIZE_KiB_per_launch"] * 1024
+    wr = summary["WRITE_SIZE_KiB_per_launch"] * 1024
+    summary["hbm_bytes_per_launch_raw"] = rd + wr
+    summary["hbm_bytes_per_launch"] = 2 * rd + wr  # gfx950: FETCH_SIZE reads half (guide §HBM)
+    lines.append(f"== HBM traffic per launch: read {rd/1e6:.2f} MB raw ({2*rd/1e6:.2f} MB x2-corrected), write {wr/1e6:.2f} MB ==")
+
+open(os.path.join(out, f"summary_{tag}.txt"), "w").write("\n".join(lines) + "\n")
+json.dump(summary, open(os.path.join(out, f"summary_{tag}.json"), "w"), indent=1)
+print("\n".join(lines))

@@ -58,7 +58,8 @@ struct DeviceState {
     uint8_t* d_env = nullptr;
     float* fb = nullptr;
     size_t fb_bytes = 0;
-    unsigned long long* d_stats = nullptr; /* kRing x kStatWords */
+    unsigned* d_stats = nullptr; /* kMaxBlocks x kStatRecord: per-workgroup records of the last launch */
+    int last_blocks = 0;
     hipEvent_t ev0[kRing];
     hipEvent_t ev1[kRing];
     bool events_ok = false;
@@ -293,8 +294,7 @@ int init_device(DeviceState& D, int ordinal) {
     HIP_TRY(hipMalloc(&D.d_nodes, sizeof(DBvhNode) * kMaxBvhNodes));
     HIP_TRY(hipMalloc(&D.d_point, sizeof(DPointLight) * VRT_MAX_POINT_LIGHTS));
     HIP_TRY(hipMalloc(&D.d_spot, sizeof(DSpotLight) * VRT_MAX_SPOT_LIGHTS));
-    HIP_TRY(hipMalloc(&D.d_stats, sizeof(unsigned long long) * kStatWords * kRing));
-    HIP_TRY(hipMemset(D.d_stats, 0, sizeof(unsigned long long) * kStatWords * kRing));
+    HIP_TRY(hipMalloc(&D.d_stats, sizeof(unsigned) * kStatRecord * (size_t)kMaxBlocks));
     for (int i = 0; i < kRing; i++) {
         HIP_TRY(hipEventCreate(&D.ev0[i]));
         HIP_TRY(hipEventCreate(&D.ev1[i]));
@@ -451,7 +451,7 @@ int resolve_path(int path) {
 }
 
 void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, int row0, int rows, float* out,
-                 unsigned long long* stats, DFrame& F) {
+                 unsigned* stats, DFrame& F) {
     memset(&F, 0, sizeof F);
     pack_camera(ctx->scene, p->width, p->height, F);
     F.light_dir[0] = ctx->scene.light_dir[0];
@@ -490,10 +490,10 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
 /* Enqueue one tile on one device.  No allocation, no host sync. */
 int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, int row0, int rows, float* out, hipStream_t stream,
                  int ring) {
-    unsigned long long* stats = D.d_stats + (size_t)ring * kStatWords;
     DFrame F;
-    build_frame(ctx, D, p, row0, rows, out, stats, F);
-    HIP_TRY(hipMemsetAsync(stats, 0, sizeof(unsigned long long) * kStatWords, stream));
+    build_frame(ctx, D, p, row0, rows, out, D.d_stats, F);
+    if ((long long)F.tiles_x * F.tiles_y > kMaxBlocks) return VRT_ERR_INVALID;
+    D.last_blocks = F.tiles_x * F.tiles_y;
     HIP_TRY(hipEventRecord(D.ev0[ring], stream));
     HIP_TRY(launch_march(F, resolve_path(p->path), ctx->scene.n_instances == 1, stream));
     HIP_TRY(hipEventRecord(D.ev1[ring], stream));
@@ -747,9 +747,11 @@ int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, D.ev0[ring], D.ev1[ring]));
         kernel_ms = std::max(kernel_ms, ms);
-        unsigned long long s[kStatWords];
-        HIP_TRY(hipMemcpy(s, D.d_stats + (size_t)ring * kStatWords, sizeof s, hipMemcpyDeviceToHost));
-        for (int k = 0; k < kStatWords; k++) tot[k] += s[k];
+        std::vector<unsigned> rec((size_t)D.last_blocks * kStatRecord);
+        if (D.last_blocks > 0)
+            HIP_TRY(hipMemcpy(rec.data(), D.d_stats, rec.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        for (int blk = 0; blk < D.last_blocks; blk++)
+            for (int k = 0; k < kStatWords; k++) tot[k] += rec[(size_t)blk * kStatRecord + k];
     }
     out->kernel_ms = kernel_ms;
     out->gather_ms = ctx->last_gather_ms;

@@ -16,6 +16,8 @@ constexpr int kTile = 8;                       /* one wave = 8x8 pixels */
 constexpr int kBlockThreads = 256;             /* 4 waves = 16x16 pixels */
 constexpr int kMaxBvhNodes = 2 * 64 - 1;
 constexpr int kStatWords = 6;
+constexpr int kStatRecord = 8;                 /* words per workgroup record (32 B) */
+constexpr int kMaxBlocks = 1 << 20;            /* 16x16-pixel workgroups per launch (e.g. 16384 x 16384) */
 
 /* Per-volume record (VGeometryConstantBuffer analogue). */
 struct DVolume {
@@ -103,8 +105,8 @@ struct DFrame {
     int32_t env_size;
     int32_t pad_;
     float* out;                /* rows x width float4 */
-    unsigned long long* stats; /* kStatWords counters: primary_rays, shadow_rays, bounce_rays,
-                                  primary_steps, shadow_steps, hits */
+    unsigned* stats;           /* one 8-word record per workgroup: primary_rays, shadow_rays,
+                                  bounce_rays, primary_steps, shadow_steps, hits, 0, 0 */
 };
 
 }  // namespace vrt

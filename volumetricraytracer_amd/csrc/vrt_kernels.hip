@@ -440,20 +440,30 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
         reinterpret_cast<float4*>(F.out)[(size_t)pyl * F.width + px] = outp;
     }
 
-    /* per-wave statistics → 6 atomics per wave (algorithmic-byte accounting) */
+    /* Statistics (algorithmic-byte accounting): wave shuffle-reduce → LDS → one
+       32-byte record per workgroup, plain stores.  No atomics: 6 same-address atomics per wave
+       serialise at ~12 ns each at the memory side and cost more than the march itself. */
     n_primary = wave_sum(n_primary);
     n_shadow = wave_sum(n_shadow);
     n_bounce = wave_sum(n_bounce);
     s_primary = wave_sum(s_primary);
     s_shadow = wave_sum(s_shadow);
     n_hits = wave_sum(n_hits);
-    if (lane == 0 && F.stats != nullptr) {
-        atomicAdd(F.stats + 0, (unsigned long long)n_primary);
-        atomicAdd(F.stats + 1, (unsigned long long)n_shadow);
-        atomicAdd(F.stats + 2, (unsigned long long)n_bounce);
-        atomicAdd(F.stats + 3, (unsigned long long)s_primary);
-        atomicAdd(F.stats + 4, (unsigned long long)s_shadow);
-        atomicAdd(F.stats + 5, (unsigned long long)n_hits);
+    __shared__ unsigned red[4][kStatWords];
+    if (lane == 0) {
+        red[wave][0] = n_primary;
+        red[wave][1] = n_shadow;
+        red[wave][2] = n_bounce;
+        red[wave][3] = s_primary;
+        red[wave][4] = s_shadow;
+        red[wave][5] = n_hits;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && F.stats != nullptr) {
+        unsigned v = 0;
+        if (threadIdx.x < kStatWords)
+            v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        F.stats[(size_t)b * 8 + threadIdx.x] = v;
     }
 }
 
