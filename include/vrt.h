@@ -147,11 +147,15 @@ typedef struct vrt_params {
     int32_t mode;         /* vrt_render_mode */
     int32_t path;         /* vrt_data_path */
     int32_t max_bounces;  /* mirror-reflection depth, 0..2 (MAX_RAY_RECURSION_DEPTH 3 = primary + 2) */
-    int32_t flags;        /* reserved, 0 */
+    int32_t flags;        /* bits 0-1: blockIdx→tile map, 0 supertile (default) / 1 XCD band / 2 linear;
+                             speed only, never results.  Other bits reserved, 0 */
     float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
     float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
     float step_min;       /* lower bound of one march step (ray-parameter units) */
     float k_relax;        /* sphere-trace relaxation factor, <= 1 */
+    float cone_eps;       /* pixel-footprint termination: the hit threshold at ray parameter t is
+                             eps_hit + cone_eps * t (0 = constant threshold).  Typically the angular
+                             radius of a pixel, tan(fov/2)/height */
 } vrt_params;
 
 typedef struct vrt_timing {

@@ -272,7 +272,7 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, bool want_
         int cx = (int)cxf, cy = (int)cyf, cz = (int)czf;
         float s = trilinear(V, cx, cy, cz, fx, fy, fz) * ds;
         steps++;
-        if (s < P.prm.eps_hit) {
+        if (s < fmaf(t, P.prm.cone_eps, P.prm.eps_hit)) {
             t_hit = t;
             if (want_normal) {
                 V3 n;

@@ -113,6 +113,7 @@ class vrt_params(C.Structure):
         ("eps_in", C.c_float),
         ("step_min", C.c_float),
         ("k_relax", C.c_float),
+        ("cone_eps", C.c_float),
     ]
 
 

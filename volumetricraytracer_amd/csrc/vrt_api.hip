@@ -433,11 +433,13 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
     if (!ctx || !p) return VRT_ERR_INVALID;
     if (p->width <= 0 || p->height <= 0 || p->width > 16384 || p->height > 16384) return VRT_ERR_INVALID;
     if (p->max_steps < 0 || p->max_bounces < 0 || p->max_bounces > 2) return VRT_ERR_INVALID;
-    if (!(p->eps_hit == p->eps_hit) || !(p->step_min > 0.0f) || !(p->k_relax > 0.0f) || !(p->eps_in >= 0.0f))
+    if (!(p->eps_hit == p->eps_hit) || !(p->step_min > 0.0f) || !(p->k_relax > 0.0f) || !(p->eps_in >= 0.0f) ||
+        !(p->cone_eps >= 0.0f))
         return VRT_ERR_INVALID;
     if (p->mode < VRT_MODE_INTERP || p->mode > VRT_MODE_CUBE_NOTEX_UNLIT) return VRT_ERR_INVALID;
     if (p->mode >= VRT_MODE_CUBE) return VRT_ERR_UNSUPPORTED; /* Cube* modes: SURVEY §8f */
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_BRICK_LDS) return VRT_ERR_INVALID;
+    if ((p->flags & ~3) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
     if (!ctx->have_scene) return VRT_ERR_NOT_READY;
     if (p->max_bounces > 0 || ctx->scene.n_point_lights > 0 || ctx->scene.n_spot_lights > 0)
         return VRT_ERR_UNSUPPORTED; /* full closest-hit: SURVEY §8f-2 (next) */
@@ -462,6 +464,7 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.eps_in = p->eps_in;
     F.step_min = p->step_min;
     F.k_relax = p->k_relax;
+    F.cone_eps = p->cone_eps;
     F.max_steps = p->max_steps;
     F.shadow = p->shadow ? 1 : 0;
     F.unlit = (p->mode == VRT_MODE_INTERP_UNLIT || p->mode == VRT_MODE_INTERP_NOTEX_UNLIT) ? 1 : 0;
@@ -472,6 +475,7 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.rows = rows;
     F.tiles_x = (p->width + 15) / 16;
     F.tiles_y = (rows + 15) / 16;
+    F.tile_map = p->flags & 3;
     F.n_inst = ctx->scene.n_instances;
     F.n_nodes = ctx->n_nodes;
     F.n_point = std::min(ctx->scene.n_point_lights, VRT_MAX_POINT_LIGHTS);
@@ -492,8 +496,8 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, int row0, in
                  int ring) {
     DFrame F;
     build_frame(ctx, D, p, row0, rows, out, D.d_stats, F);
-    if ((long long)F.tiles_x * F.tiles_y > kMaxBlocks) return VRT_ERR_INVALID;
-    D.last_blocks = F.tiles_x * F.tiles_y;
+    if ((long long)F.tiles_x * F.tiles_y > kMaxBlocks / 2) return VRT_ERR_INVALID;
+    D.last_blocks = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     HIP_TRY(hipEventRecord(D.ev0[ring], stream));
     HIP_TRY(launch_march(F, resolve_path(p->path), ctx->scene.n_instances == 1, stream));
     HIP_TRY(hipEventRecord(D.ev1[ring], stream));

@@ -19,6 +19,18 @@ constexpr int kStatWords = 6;
 constexpr int kStatRecord = 8;                 /* words per workgroup record (32 B) */
 constexpr int kMaxBlocks = 1 << 20;            /* 16x16-pixel workgroups per launch (e.g. 16384 x 16384) */
 
+/* blockIdx → tile maps of the march kernel (vrt_params.flags bits 0-1; speed only). */
+constexpr int kMapSupertile = 0;
+constexpr int kMapBand = 1;
+constexpr int kMapLinear = 2;
+
+/* Workgroups launched for a tiles_x x tiles_y frame under a tile map. */
+inline int grid_blocks(int tiles_x, int tiles_y, int tile_map) {
+    if (tile_map != kMapSupertile) return tiles_x * tiles_y;
+    const int st = ((tiles_x + 3) / 4) * ((tiles_y + 3) / 4);
+    return ((st + 7) / 8) * 8 * 16; /* whole supertiles, a multiple of 8 of them */
+}
+
 /* Per-volume record (VGeometryConstantBuffer analogue). */
 struct DVolume {
     const float* dense;    /* N^3 fp32, index x*N*N + z*N + y */
@@ -84,7 +96,7 @@ struct DFrame {
     float light_dir[3];
     float light_strength;
     /* march contract */
-    float eps_hit, eps_in, step_min, k_relax;
+    float eps_hit, eps_in, step_min, k_relax, cone_eps;
     int32_t max_steps;
     int32_t shadow;
     int32_t unlit;
@@ -93,6 +105,8 @@ struct DFrame {
     int32_t width, height;
     int32_t row0, rows;        /* this launch renders rows [row0,row0+rows) */
     int32_t tiles_x, tiles_y;  /* 16x16-pixel blocks covering width x rows */
+    int32_t tile_map;          /* kMapSupertile / kMapBand / kMapLinear */
+    int32_t pad0_;
     /* scene arrays */
     int32_t n_inst, n_nodes;
     int32_t n_point, n_spot;

@@ -186,7 +186,7 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
         cz = (int)czf;
         float s = trilinear<PATH>(V, cx, cy, cz, fx, fy, fz) * ds;
         steps++;
-        if (s < F.eps_hit) {
+        if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
             hit = true;
             break;
         }
@@ -373,25 +373,44 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 }
 
 /*
- * Primary-ray kernel.  grid = tiles_x*tiles_y workgroups of 256 threads; the blockIdx → tile map
- * hands each XCD (blockIdx % 8) a contiguous band of tiles so that its L2 holds the part of
- * the volume that band looks at.
+ * Primary-ray kernel.  One workgroup = one 16x16-pixel tile.  blockIdx → tile map (F.tile_map):
+ *   SUPERTILE (default): tiles are grouped into 4x4-tile supertiles (64x64 pixels); supertile s
+ *     goes to XCD s % 8 (workgroups are dealt round-robin over the 8 XCDs, so the blocks
+ *     b ≡ k (mod 8) share XCD k's L2).  An XCD's 16 consecutive blocks cover one supertile, so its
+ *     L2 sees the bricks of a compact screen region, while heavy (object) and cheap (sky)
+ *     regions are spread over all 8 XCDs.
+ *   BAND: XCD k gets the k-th contiguous eighth of the tiles (best L2 locality, worst balance).
+ *   LINEAR: tile = blockIdx (consecutive tiles on different XCDs).
+ * Placement only affects speed, never results.
  */
 template <int PATH, bool SINGLE>
 __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
     const int nblk = (int)gridDim.x;
     const int b = (int)blockIdx.x;
-    const int xcd = b & 7, q = b >> 3;
-    const int per = nblk >> 3, rem = nblk & 7;
-    const int L = (xcd < rem) ? xcd * (per + 1) + q : rem * (per + 1) + (xcd - rem) * per + q;
-    const int tile_x = L % F.tiles_x;
-    const int tile_y = L / F.tiles_x;
+    int tile_x, tile_y;
+    if (F.tile_map == kMapSupertile) {
+        const int xcd = b & 7, q = b >> 3;
+        const int st = (q >> 4) * 8 + xcd;      /* supertile index, row-major over st_x columns */
+        const int within = q & 15;
+        const int st_x = (F.tiles_x + 3) >> 2;
+        tile_x = (st % st_x) * 4 + (within & 3);
+        tile_y = (st / st_x) * 4 + (within >> 2);
+    } else if (F.tile_map == kMapBand) {
+        const int xcd = b & 7, q = b >> 3;
+        const int per = nblk >> 3, rem = nblk & 7;
+        const int L = (xcd < rem) ? xcd * (per + 1) + q : rem * (per + 1) + (xcd - rem) * per + q;
+        tile_x = L % F.tiles_x;
+        tile_y = L / F.tiles_x;
+    } else {
+        tile_x = b % F.tiles_x;
+        tile_y = b / F.tiles_x;
+    }
     const int wave = (int)threadIdx.x >> 6;
     const int lane = (int)threadIdx.x & 63;
     const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
     const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int py = F.row0 + pyl;
-    const bool valid = px < F.width && pyl < F.rows;
+    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows;
 
     unsigned n_primary = 0, n_shadow = 0, n_bounce = 0, s_primary = 0, s_shadow = 0, n_hits = 0;
 
@@ -503,7 +522,7 @@ __global__ void split_voxels_kernel(const uint2* __restrict__ voxels, float* __r
 
 template <int PATH, bool SINGLE>
 static hipError_t launch_t(const DFrame& F, hipStream_t stream) {
-    const int grid = F.tiles_x * F.tiles_y;
+    const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
     hipLaunchKernelGGL((march_kernel<PATH, SINGLE>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
     return hipGetLastError();

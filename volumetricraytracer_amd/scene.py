@@ -432,8 +432,10 @@ def procedural_skybox(face_size: int = 256) -> np.ndarray:
 
 
 def default_params(width: int, height: int, cell: float, max_steps: int = 128, shadow: bool = False,
-                   mode: int = _abi.MODE_INTERP_NOTEX, path: int = _abi.PATH_AUTO) -> _abi.vrt_params:
-    """March contract defaults: hit threshold and minimum step are 0.4 % of a cell."""
+                   mode: int = _abi.MODE_INTERP_NOTEX, path: int = _abi.PATH_AUTO, fov_deg: float = 60.0,
+                   cone: bool = True) -> _abi.vrt_params:
+    """March contract defaults: hit threshold and minimum step are 0.4 % of a cell at
+    the ray origin and grow with the pixel footprint (angular pixel radius tan(fov/2)/height)."""
     p = _abi.vrt_params()
     p.width, p.height = int(width), int(height)
     p.max_steps = int(max_steps)
@@ -446,4 +448,5 @@ def default_params(width: int, height: int, cell: float, max_steps: int = 128, s
     p.eps_in = 0.01  # Raytracing.hlsl:178
     p.step_min = float(np.float32(0.004 * cell))
     p.k_relax = 1.0
+    p.cone_eps = float(np.float32(math.tan(math.radians(fov_deg) * 0.5) / height)) if cone else 0.0
     return p
