@@ -43,6 +43,7 @@ extern "C" {
 #define VRT_MAX_SPOT_LIGHTS  5  /* RaytracingHlsl.h:113 */
 #define VRT_MAX_INSTANCES    64
 #define VRT_MAX_DEVICES      8
+#define VRT_FLAG_DIAG_TIMELINE 4 /* run the diagnostic kernel build that stamps per-wave timeline records */
 
 enum vrt_status {
     VRT_OK = 0,
@@ -147,8 +148,8 @@ typedef struct vrt_params {
     int32_t mode;         /* vrt_render_mode */
     int32_t path;         /* vrt_data_path */
     int32_t max_bounces;  /* mirror-reflection depth, 0..2 (MAX_RAY_RECURSION_DEPTH 3 = primary + 2) */
-    int32_t flags;        /* bits 0-1: blockIdx→tile map, 0 supertile (default) / 1 XCD band / 2 linear;
-                             speed only, never results.  Other bits reserved, 0 */
+    int32_t flags;        /* bits 0-1: blockIdx→tile map, 0 supertile (default) / 1 XCD band / 2 linear
+                             (speed only, never results); bit 2: VRT_FLAG_DIAG_TIMELINE.  Others 0 */
     float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
     float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
     float step_min;       /* lower bound of one march step (ray-parameter units) */
@@ -210,6 +211,14 @@ int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out);
 /* Kernel durations (ms) of the last n vrt_render_rows/vrt_render launches, oldest first;
  * returns how many were written (<= n), or a negative status. */
 int vrt_timing_history(vrt_ctx* ctx, int n, float* kernel_ms_out);
+
+/* Diagnostics: per-wave records of the last launch on the first device, 8 words each, record
+ * index = blockIdx*4 + wave.  which = 0: counters {primary_rays, shadow_rays, bounce_rays,
+ * primary_steps, shadow_steps, hits, 0, 0}.  which = 1 (only after a VRT_FLAG_DIAG_TIMELINE launch):
+ * {start, end (100 MHz ticks), HW_ID, XCC_ID, longest per-lane sample chain, load+interpolate
+ * cycles, march-loop cycles, march-loop iterations}.  Returns the number of words available and
+ * copies min(max_words, that). */
+long long vrt_debug_wave_records(vrt_ctx* ctx, int which, uint32_t* out, long long max_words);
 
 const char* vrt_strerror(int status);
 /* "x.y.z gfx950" */

@@ -138,6 +138,7 @@ struct Packed {
     float light_strength;
     const vrt_scene* scene;
     vrt_params prm;
+    uint32_t* steps_img; /* optional: per-pixel samples taken (primary+shadow), rows*width */
 };
 
 Instance build_instance(const vrt_instance& in) {
@@ -192,6 +193,7 @@ bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env
     P.light_strength = scene->light_strength;
     P.scene = scene;
     P.prm = *prm;
+    P.steps_img = nullptr;
     return true;
 }
 
@@ -243,7 +245,7 @@ inline bool slab(V3 o, V3 d, float e, float t_cur, float& t_enter, float& t_exit
 }
 
 /* March one instance.  Returns true on hit with t (ray parameter, shared with world space). */
-bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, bool want_normal,
+bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_base, bool want_normal,
                     float& t_hit, V3& n_world, uint64_t& steps) {
     const Instance& I = P.inst[ii];
     const Volume& V = P.vol[I.slot];
@@ -262,6 +264,9 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, bool want_
 
     float t = (t_enter > 0.0f ? t_enter : 0.0f) + P.prm.eps_in;
     float t_end = minf(t_exit, t_cur);
+    /* smallest step: one pixel-footprint radius at the total path length t_base + t (t_base = length of
+       the path that led to this ray's origin: 0 for camera rays, the hit distance for shadow rays) */
+    const float base_min = fmaf(t_base, P.prm.cone_eps, P.prm.step_min);
     for (int i = 0; i < P.prm.max_steps; i++) {
         if (t > t_end) return false;
         float ux = fmaf(ud.x, t, uo.x), uy = fmaf(ud.y, t, uo.y), uz = fmaf(ud.z, t, uo.z);
@@ -305,20 +310,21 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, bool want_
         }
         float adv = s * P.prm.k_relax;
         adv = adv > smax ? smax : adv;
-        adv = adv < P.prm.step_min ? P.prm.step_min : adv;
+        float adv_min = fmaf(t, P.prm.cone_eps, base_min);
+        adv = adv < adv_min ? adv_min : adv;
         t = t + adv;
     }
     return false;
 }
 
 /* Closest hit over all instances (ascending index; strict '<' keeps the lower index on ties). */
-bool trace_closest(const Packed& P, V3 o, V3 d, float t_max, HitRec& h, uint64_t& steps) {
+bool trace_closest(const Packed& P, V3 o, V3 d, float t_max, float t_base, HitRec& h, uint64_t& steps) {
     bool any = false;
     float best = t_max;
     for (int i = 0; i < P.n_inst; i++) {
         float t;
         V3 n;
-        if (march_instance(P, i, o, d, best, true, t, n, steps)) {
+        if (march_instance(P, i, o, d, best, t_base, true, t, n, steps)) {
             if (!any || t < best) {
                 any = true;
                 best = t;
@@ -331,11 +337,11 @@ bool trace_closest(const Packed& P, V3 o, V3 d, float t_max, HitRec& h, uint64_t
     return any;
 }
 
-bool trace_any(const Packed& P, V3 o, V3 d, float t_max, uint64_t& steps) {
+bool trace_any(const Packed& P, V3 o, V3 d, float t_max, float t_base, uint64_t& steps) {
     for (int i = 0; i < P.n_inst; i++) {
         float t;
         V3 n;
-        if (march_instance(P, i, o, d, t_max, false, t, n, steps)) return true;
+        if (march_instance(P, i, o, d, t_max, t_base, false, t, n, steps)) return true;
     }
     return false;
 }
@@ -409,10 +415,10 @@ void radiance(V3 Li, V3 wi, V3 wo, V3 n, V3 albedo, float rough, float metal, fl
 const int MAX_DEPTH = 3; /* MAX_RAY_RECURSION_DEPTH, RaytracingHlsl.h:32 */
 
 /* TraceRadianceRay + VRClosestHit / VRMiss, level = 1 for the primary ray. */
-V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, Stats& st) {
+V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st) {
     HitRec h;
     uint64_t steps = 0;
-    bool hit = trace_closest(P, o, d, 10000.0f, h, steps);
+    bool hit = trace_closest(P, o, d, 10000.0f, t_base, h, steps);
     st.primary_steps += steps;
     if (!hit) {
         float rgb[3];
@@ -436,7 +442,7 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, Stats& st) {
         float dn = dot(d, n);
         V3 rd = normalize(v3(d.x - (2.0f * dn) * n.x, d.y - (2.0f * dn) * n.y, d.z - (2.0f * dn) * n.z));
         st.bounce_rays++;
-        V3 rc = radiance_ray(P, so, rd, level + 1, st);
+        V3 rc = radiance_ray(P, so, rd, level + 1, t_base + h.t, st);
         float fade = V.roughness * 2.2f;
         rc = v3(maxf(0.0f, rc.x + (0.0f - rc.x) * fade), maxf(0.0f, rc.y + (0.0f - rc.y) * fade),
                 maxf(0.0f, rc.z + (0.0f - rc.z) * fade));
@@ -449,7 +455,7 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, Stats& st) {
     if (P.prm.shadow && shadows) {
         st.shadow_rays++;
         uint64_t ss = 0;
-        shadowed = trace_any(P, so, P.light_dir, 5000.0f, ss);
+        shadowed = trace_any(P, so, P.light_dir, 5000.0f, t_base + h.t, ss);
         st.shadow_steps += ss;
     }
     if (!shadowed) {
@@ -473,7 +479,7 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, Stats& st) {
             if (P.prm.shadow && shadows) {
                 st.shadow_rays++;
                 uint64_t ss = 0;
-                sh = trace_any(P, so, ld, dist, ss);
+                sh = trace_any(P, so, ld, dist, t_base + h.t, ss);
                 st.shadow_steps += ss;
             }
             if (!sh) {
@@ -506,7 +512,7 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, Stats& st) {
             if (P.prm.shadow && shadows) {
                 st.shadow_rays++;
                 uint64_t ss = 0;
-                sh = trace_any(P, so, ld, dist, ss);
+                sh = trace_any(P, so, ld, dist, t_base + h.t, ss);
                 st.shadow_steps += ss;
             }
             if (!sh) {
@@ -533,7 +539,9 @@ void render_rows(const Packed& P, int y0, int y1, int row0, float* out, Stats& s
             V3 o, d;
             camera_ray(P.cam, W, H, x, y, o, d);
             st.primary_rays++;
-            V3 c = radiance_ray(P, o, d, 1, st);
+            const uint64_t before = st.primary_steps + st.shadow_steps;
+            V3 c = radiance_ray(P, o, d, 1, 0.0f, st);
+            if (P.steps_img) P.steps_img[(size_t)(y - row0) * W + x] = (uint32_t)(st.primary_steps + st.shadow_steps - before);
             float* px = out + ((size_t)(y - row0) * W + x) * 4;
             px[0] = tonemap(c.x);
             px[1] = tonemap(c.y);
@@ -548,6 +556,9 @@ bool mode_supported(int mode) { return mode >= VRT_MODE_INTERP && mode <= VRT_MO
 }  // namespace
 
 extern "C" {
+
+static uint32_t* g_steps_img = nullptr;
+void vrto_debug_set_steps_image(uint32_t* img) { g_steps_img = img; }
 
 int vrto_render(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env_rgba8, int env_face_size,
                 const vrt_params* params, int row0, int rows, float* out_rgba, vrto_stats* stats_or_null,
@@ -565,6 +576,7 @@ int vrto_render(const vrt_scene* scene, const vrto_volume* volumes, const uint8_
         delete P;
         return VRT_ERR_INVALID;
     }
+    P->steps_img = g_steps_img;
     if (threads < 1) threads = 1;
     if (threads > rows && rows > 0) threads = rows;
     std::vector<Stats> st((size_t)threads);
@@ -615,7 +627,7 @@ int vrto_trace(const vrt_scene* scene, const vrto_volume* volumes, const vrt_par
     V3 d = normalize(v3(dir[0], dir[1], dir[2]));
     HitRec h;
     uint64_t steps = 0;
-    bool hit = trace_closest(*P, o, d, t_max, h, steps);
+    bool hit = trace_closest(*P, o, d, t_max, 0.0f, h, steps);
     if (steps_out) *steps_out = (int)steps;
     if (hit) {
         if (t_out) *t_out = h.t;

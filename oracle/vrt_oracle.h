@@ -43,6 +43,10 @@ int vrto_render(const vrt_scene* scene, const vrto_volume* volumes,
                 const vrt_params* params, int row0, int rows,
                 float* out_rgba, vrto_stats* stats_or_null, int threads);
 
+/* Debug: when set (non-NULL), the next vrto_render calls also write the number of trilinear
+ * samples each pixel took (primary + shadow) into img (rows*width).  Not thread-safe. */
+void vrto_debug_set_steps_image(uint32_t* img);
+
 /* Single-ray probes used by the analytic pins (world-space ray, direction is normalised
  * internally; returns 1 on hit and writes t / world normal / instance index). */
 int vrto_trace(const vrt_scene* scene, const vrto_volume* volumes, const vrt_params* params,

@@ -34,6 +34,8 @@ MODE_CUBE_UNLIT = 5
 MODE_CUBE_NOTEX = 6
 MODE_CUBE_NOTEX_UNLIT = 7
 
+FLAG_DIAG_TIMELINE = 4
+
 PATH_AUTO = 0
 PATH_DENSE = 1
 PATH_BRICK = 2
@@ -148,6 +150,7 @@ SYMBOLS = {
     "vrt_render_rows": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vrt_last_timing": (C.c_int, [C.c_void_p, C.POINTER(vrt_timing)]),
     "vrt_timing_history": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "vrt_debug_wave_records": (C.c_longlong, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]),
     "vrt_strerror": (C.c_char_p, [C.c_int]),
     "vrt_version": (C.c_char_p, []),
 }

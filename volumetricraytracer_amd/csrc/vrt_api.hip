@@ -58,8 +58,10 @@ struct DeviceState {
     uint8_t* d_env = nullptr;
     float* fb = nullptr;
     size_t fb_bytes = 0;
-    unsigned* d_stats = nullptr; /* kMaxBlocks x kStatRecord: per-workgroup records of the last launch */
+    unsigned* d_stats = nullptr; /* kMaxBlocks x 4 x kStatRecord: per-wave records of the last launch */
+    unsigned* d_diag = nullptr;  /* allocated on first use of VRT_FLAG_DIAG_TIMELINE (never in a capture) */
     int last_blocks = 0;
+    bool last_diag = false;
     hipEvent_t ev0[kRing];
     hipEvent_t ev1[kRing];
     bool events_ok = false;
@@ -294,7 +296,7 @@ int init_device(DeviceState& D, int ordinal) {
     HIP_TRY(hipMalloc(&D.d_nodes, sizeof(DBvhNode) * kMaxBvhNodes));
     HIP_TRY(hipMalloc(&D.d_point, sizeof(DPointLight) * VRT_MAX_POINT_LIGHTS));
     HIP_TRY(hipMalloc(&D.d_spot, sizeof(DSpotLight) * VRT_MAX_SPOT_LIGHTS));
-    HIP_TRY(hipMalloc(&D.d_stats, sizeof(unsigned) * kStatRecord * (size_t)kMaxBlocks));
+    HIP_TRY(hipMalloc(&D.d_stats, sizeof(unsigned) * kStatRecord * 4 * (size_t)kMaxBlocks));
     for (int i = 0; i < kRing; i++) {
         HIP_TRY(hipEventCreate(&D.ev0[i]));
         HIP_TRY(hipEventCreate(&D.ev1[i]));
@@ -318,6 +320,7 @@ void destroy_device(DeviceState& D) {
     if (D.d_env) (void)hipFree(D.d_env);
     if (D.fb) (void)hipFree(D.fb);
     if (D.d_stats) (void)hipFree(D.d_stats);
+    if (D.d_diag) (void)hipFree(D.d_diag);
     if (D.events_ok)
         for (int i = 0; i < kRing; i++) {
             (void)hipEventDestroy(D.ev0[i]);
@@ -439,7 +442,7 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
     if (p->mode < VRT_MODE_INTERP || p->mode > VRT_MODE_CUBE_NOTEX_UNLIT) return VRT_ERR_INVALID;
     if (p->mode >= VRT_MODE_CUBE) return VRT_ERR_UNSUPPORTED; /* Cube* modes: SURVEY §8f */
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_BRICK_LDS) return VRT_ERR_INVALID;
-    if ((p->flags & ~3) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
+    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE)) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
     if (!ctx->have_scene) return VRT_ERR_NOT_READY;
     if (p->max_bounces > 0 || ctx->scene.n_point_lights > 0 || ctx->scene.n_spot_lights > 0)
         return VRT_ERR_UNSUPPORTED; /* full closest-hit: SURVEY §8f-2 (next) */
@@ -476,6 +479,7 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.tiles_x = (p->width + 15) / 16;
     F.tiles_y = (rows + 15) / 16;
     F.tile_map = p->flags & 3;
+    F.diag = (p->flags & VRT_FLAG_DIAG_TIMELINE) ? 1 : 0;
     F.n_inst = ctx->scene.n_instances;
     F.n_nodes = ctx->n_nodes;
     F.n_point = std::min(ctx->scene.n_point_lights, VRT_MAX_POINT_LIGHTS);
@@ -498,6 +502,11 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, int row0, in
     build_frame(ctx, D, p, row0, rows, out, D.d_stats, F);
     if ((long long)F.tiles_x * F.tiles_y > kMaxBlocks / 2) return VRT_ERR_INVALID;
     D.last_blocks = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
+    D.last_diag = F.diag != 0;
+    if (F.diag) {
+        if (!D.d_diag) HIP_TRY(hipMalloc(&D.d_diag, sizeof(unsigned) * kDiagRecord * 4 * (size_t)kMaxBlocks));
+        F.diag_buf = D.d_diag;
+    }
     HIP_TRY(hipEventRecord(D.ev0[ring], stream));
     HIP_TRY(launch_march(F, resolve_path(p->path), ctx->scene.n_instances == 1, stream));
     HIP_TRY(hipEventRecord(D.ev1[ring], stream));
@@ -751,11 +760,11 @@ int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, D.ev0[ring], D.ev1[ring]));
         kernel_ms = std::max(kernel_ms, ms);
-        std::vector<unsigned> rec((size_t)D.last_blocks * kStatRecord);
+        std::vector<unsigned> rec((size_t)D.last_blocks * 4 * kStatRecord);
         if (D.last_blocks > 0)
             HIP_TRY(hipMemcpy(rec.data(), D.d_stats, rec.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-        for (int blk = 0; blk < D.last_blocks; blk++)
-            for (int k = 0; k < kStatWords; k++) tot[k] += rec[(size_t)blk * kStatRecord + k];
+        for (size_t w = 0; w < (size_t)D.last_blocks * 4; w++)
+            for (int k = 0; k < kStatWords; k++) tot[k] += rec[w * kStatRecord + k];
     }
     out->kernel_ms = kernel_ms;
     out->gather_ms = ctx->last_gather_ms;
@@ -786,6 +795,21 @@ int vrt_timing_history(vrt_ctx* ctx, int n, float* kernel_ms_out) {
         kernel_ms_out[i] = ms;
     }
     return m;
+}
+
+long long vrt_debug_wave_records(vrt_ctx* ctx, int which, uint32_t* out, long long max_words) {
+    if (!ctx || max_words < 0 || (max_words > 0 && !out) || which < 0 || which > 1) return VRT_ERR_INVALID;
+    if (ctx->launches == 0) return VRT_ERR_NOT_READY;
+    DeviceState& D = ctx->dev[0];
+    if (which == 1 && (!D.last_diag || !D.d_diag)) return VRT_ERR_NOT_READY;
+    const long long words = (long long)D.last_blocks * 4 * (which == 0 ? kStatRecord : kDiagRecord);
+    if (out && max_words > 0) {
+        HIP_TRY(hipSetDevice(D.ordinal));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, which == 0 ? D.d_stats : D.d_diag, sizeof(uint32_t) * (size_t)std::min(words, max_words),
+                          hipMemcpyDeviceToHost));
+    }
+    return words;
 }
 
 const char* vrt_strerror(int status) {

@@ -16,7 +16,8 @@ constexpr int kTile = 8;                       /* one wave = 8x8 pixels */
 constexpr int kBlockThreads = 256;             /* 4 waves = 16x16 pixels */
 constexpr int kMaxBvhNodes = 2 * 64 - 1;
 constexpr int kStatWords = 6;
-constexpr int kStatRecord = 8;                 /* words per workgroup record (32 B) */
+constexpr int kStatRecord = 8;                 /* words per wave record (32 B) */
+constexpr int kDiagRecord = 8;                 /* words per wave in the diagnostic timeline buffer */
 constexpr int kMaxBlocks = 1 << 20;            /* 16x16-pixel workgroups per launch (e.g. 16384 x 16384) */
 
 /* blockIdx → tile maps of the march kernel (vrt_params.flags bits 0-1; speed only). */
@@ -106,7 +107,7 @@ struct DFrame {
     int32_t row0, rows;        /* this launch renders rows [row0,row0+rows) */
     int32_t tiles_x, tiles_y;  /* 16x16-pixel blocks covering width x rows */
     int32_t tile_map;          /* kMapSupertile / kMapBand / kMapLinear */
-    int32_t pad0_;
+    int32_t diag;              /* 1: diagnostic kernel build that stamps per-wave timeline records */
     /* scene arrays */
     int32_t n_inst, n_nodes;
     int32_t n_point, n_spot;
@@ -119,8 +120,10 @@ struct DFrame {
     int32_t env_size;
     int32_t pad_;
     float* out;                /* rows x width float4 */
-    unsigned* stats;           /* one 8-word record per workgroup: primary_rays, shadow_rays,
+    unsigned* stats;           /* one 8-word record per wave (4 per workgroup): primary_rays, shadow_rays,
                                   bounce_rays, primary_steps, shadow_steps, hits, 0, 0 */
+    unsigned* diag_buf;        /* diagnostic build only: 8 words per wave {start, end (100 MHz), hw_id, xcc,
+                                  longest sample chain, load+lerp cycles, loop cycles, loop iterations} */
 };
 
 }  // namespace vrt

@@ -44,6 +44,14 @@ __device__ __forceinline__ F3 mul33(const float* m, F3 v) {
 }
 __device__ __forceinline__ float lerp1(float a, float b, float w) { return __builtin_fmaf(w, b - a, a); }
 
+/* 1-ulp hardware approximations (v_rcp_f32 / v_rsq_f32 / v_log_f32 / v_exp_f32).  Used ONLY downstream
+ * of the hit decision — normal length, BRDF, tone-map — where a last-bit difference moves a colour
+ * channel by ~1e-7.  Everything that feeds a discrete decision (ray setup, slab tests, the march,
+ * texel selection) uses correctly rounded division / sqrt and matches the CPU oracle bit for bit. */
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_pow(float x, float e) { return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * e); }
+
 /* Volume as the march sees it (all in registers; wave-uniform for single-instance scenes). */
 /* Global-address-space view of a pointer that was itself loaded from memory (keeps the taps
  * on global_load instead of flat_load). */
@@ -70,43 +78,70 @@ __device__ __forceinline__ VolRef load_vol(const DVolume* __restrict__ v) {
     return r;
 }
 
-/* Trilinear interpolant of cell (cx,cy,cz) at fraction (fx,fy,fz): y-lerps, z-lerps, x-lerp. */
+/* The 8 corner taps of one cell, in the order the lerp tree consumes them. */
+struct Taps {
+    float y00a, y00b, y01a, y01b, y10a, y10b, y11a, y11b; /* (x,z) = 00,01,10,11; a = y, b = y+1 */
+};
+
+typedef const char __attribute__((address_space(1))) * gchar_p;
+
+/* a*b + c with 24-bit unsigned operands (full-rate v_mad_u32_u24; v_mul_lo_u32 is quarter rate). */
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+/* Fetch the taps of cell (cx,cy,cz).  Offsets are unsigned 32-bit byte offsets from the volume
+ * base (≤ 4 GiB pools), built with 24-bit multiplies (cells < 2^10, bricks < 2^24). */
 template <int PATH>
-__device__ __forceinline__ float trilinear(const VolRef& V, int cx, int cy, int cz, float fx, float fy, float fz) {
-    float y00a, y00b, y01a, y01b, y10a, y10b, y11a, y11b;
+__device__ __forceinline__ Taps fetch8(const VolRef& V, int cx, int cy, int cz) {
+    Taps t;
     if constexpr (PATH == VRT_PATH_DENSE) {
-        const int N = V.N;
-        const int NN = N * N;
-        const gfloat_p b = V.p + ((cx * N + cz) * N + cy);
-        y00a = b[0];
-        y00b = b[1];
-        y01a = b[N];
-        y01b = b[N + 1];
-        y10a = b[NN];
-        y10b = b[NN + 1];
-        y11a = b[NN + N];
-        y11b = b[NN + N + 1];
+        const unsigned N = (unsigned)V.N;
+        const unsigned off = mad24(mad24((unsigned)cx, N, (unsigned)cz), N, (unsigned)cy);
+        const gfloat_p b = (gfloat_p)((gchar_p)V.p + ((size_t)off << 2));
+        const unsigned NN = N * N;
+        t.y00a = b[0];
+        t.y00b = b[1];
+        t.y01a = b[N];
+        t.y01b = b[N + 1];
+        t.y10a = b[NN];
+        t.y10b = b[NN + 1];
+        t.y11a = b[NN + N];
+        t.y11b = b[NN + N + 1];
     } else {
-        const int nb = V.nb;
-        const int brick = ((cx >> 2) * nb + (cz >> 2)) * nb + (cy >> 2);
-        const int local = (cx & 3) * 25 + (cz & 3) * 5 + (cy & 3);
-        const gfloat_p b = V.p + (brick * kBrickFloats + local);
-        y00a = b[0];
-        y00b = b[1];
-        y01a = b[5];
-        y01b = b[6];
-        y10a = b[25];
-        y10b = b[26];
-        y11a = b[30];
-        y11b = b[31];
+        const unsigned nb = (unsigned)V.nb;
+        const unsigned brick = mad24(mad24((unsigned)cx >> 2, nb, (unsigned)cz >> 2), nb, (unsigned)cy >> 2);
+        const unsigned local = ((unsigned)cx & 3u) * 25u + ((unsigned)cz & 3u) * 5u + ((unsigned)cy & 3u);
+        const unsigned off = ((brick << 7) + local) << 2; /* bytes */
+        const gfloat_p b = (gfloat_p)((gchar_p)V.p + off);
+        t.y00a = b[0];
+        t.y00b = b[1];
+        t.y01a = b[5];
+        t.y01b = b[6];
+        t.y10a = b[25];
+        t.y10b = b[26];
+        t.y11a = b[30];
+        t.y11b = b[31];
     }
-    float a00 = lerp1(y00a, y00b, fy);
-    float a01 = lerp1(y01a, y01b, fy);
-    float a10 = lerp1(y10a, y10b, fy);
-    float a11 = lerp1(y11a, y11b, fy);
+    return t;
+}
+
+/* Trilinear interpolant from the taps: y-lerps, z-lerps, x-lerp (each lerp is one sub + one fma). */
+__device__ __forceinline__ float lerp8(const Taps& t, float fx, float fy, float fz) {
+    float a00 = lerp1(t.y00a, t.y00b, fy);
+    float a01 = lerp1(t.y01a, t.y01b, fy);
+    float a10 = lerp1(t.y10a, t.y10b, fy);
+    float a11 = lerp1(t.y11a, t.y11b, fy);
     float c0 = lerp1(a00, a01, fz);
     float c1 = lerp1(a10, a11, fz);
     return lerp1(c0, c1, fx);
+}
+
+template <int PATH>
+__device__ __forceinline__ float trilinear(const VolRef& V, int cx, int cy, int cz, float fx, float fy, float fz) {
+    return lerp8(fetch8<PATH>(V, cx, cy, cz), fx, fy, fz);
 }
 
 /* Ray / box [-e,e]^3 slab test with inf-safe reciprocals (Ray.hlsli:111-134). */
@@ -140,15 +175,27 @@ __device__ __forceinline__ bool slab_box(F3 o, F3 d, const DBvhNode& n, float t_
     return !(tx < te) && !(tx < 0.0f) && !(te > t_cur);
 }
 
+/* Diagnostic-build accumulators (wave-uniform, shader-clock cycles); unused otherwise. */
+struct DiagAcc {
+    unsigned long long mem = 0;   /* address ready → interpolated value available (loads + lerps) */
+    unsigned long long loop = 0;  /* whole march-loop iterations */
+    unsigned iters = 0;           /* iterations this wave executed (any lane active) */
+};
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 /*
  * Sphere-trace one instance.  o,d: world-space ray (d normalised).  Returns true on hit and
  * the ray parameter (shared by world and object space — the object-space direction is not
  * re-normalised, DXR semantics).  NORMAL: also produce the world-space normal.
  */
-template <int PATH, bool NORMAL>
+template <int PATH, bool NORMAL, bool DIAG = false>
 __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance* __restrict__ I,
-                                               const DVolume* __restrict__ Vd, F3 o, F3 d, float t_cur,
-                                               float& t_hit, F3& n_world, unsigned& steps) {
+                                               const DVolume* __restrict__ Vd, F3 o, F3 d, float t_cur, float t_base,
+                                               float& t_hit, F3& n_world, unsigned& steps, DiagAcc* dg = nullptr) {
     const VolRef V = load_vol<PATH>(Vd);
     F3 rel = f3(o.x - I->pos[0], o.y - I->pos[1], o.z - I->pos[2]);
     F3 oo = mul33(I->w2o, rel);
@@ -165,6 +212,8 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
 
     float t = (t_enter > 0.0f ? t_enter : 0.0f) + F.eps_in;
     const float t_end = minf_(t_exit, t_cur);
+    /* smallest step: one pixel-footprint radius at the total path length t_base + t */
+    const float base_min = __builtin_fmaf(t_base, F.cone_eps, F.step_min);
     const int max_steps = F.max_steps;
     bool hit = false;
     int i = 0;
@@ -172,28 +221,42 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     float fx = 0.0f, fy = 0.0f, fz = 0.0f;
     for (; i < max_steps; i++) {
         if (t > t_end) break;
-        float ux = __builtin_fmaf(ud.x, t, uo.x);
-        float uy = __builtin_fmaf(ud.y, t, uo.y);
-        float uz = __builtin_fmaf(ud.z, t, uo.z);
-        float cxf = minf_(maxf_(floorf(ux), 0.0f), cmax);
-        float cyf = minf_(maxf_(floorf(uy), 0.0f), cmax);
-        float czf = minf_(maxf_(floorf(uz), 0.0f), cmax);
+        unsigned long long st0 = 0, st1 = 0;
+        if constexpr (DIAG) st0 = stamp();
+        const float ux = __builtin_fmaf(ud.x, t, uo.x);
+        const float uy = __builtin_fmaf(ud.y, t, uo.y);
+        const float uz = __builtin_fmaf(ud.z, t, uo.z);
+        /* cell = clamp(floor(u), 0, N-2): v_med3_f32 (u is finite) */
+        const float cxf = __builtin_amdgcn_fmed3f(floorf(ux), 0.0f, cmax);
+        const float cyf = __builtin_amdgcn_fmed3f(floorf(uy), 0.0f, cmax);
+        const float czf = __builtin_amdgcn_fmed3f(floorf(uz), 0.0f, cmax);
         fx = ux - cxf;
         fy = uy - cyf;
         fz = uz - czf;
         cx = (int)cxf;
         cy = (int)cyf;
         cz = (int)czf;
-        float s = trilinear<PATH>(V, cx, cy, cz, fx, fy, fz) * ds;
+        if constexpr (DIAG) {
+            asm volatile("" ::"v"(cx), "v"(cy), "v"(cz), "v"(fx), "v"(fy), "v"(fz));
+            st1 = stamp();
+        }
+        const Taps taps = fetch8<PATH>(V, cx, cy, cz);
+        if constexpr (DIAG) {
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(taps.y00a), "v"(taps.y00b), "v"(taps.y01a), "v"(taps.y01b), "v"(taps.y10a),
+                         "v"(taps.y10b), "v"(taps.y11a), "v"(taps.y11b));
+            const unsigned long long st2 = stamp();
+            dg->mem += st2 - st1; /* address arithmetic + 4 loads until the data is back */
+            dg->iters++;
+            dg->loop += st2 - st0;
+        }
+        const float s = lerp8(taps, fx, fy, fz) * ds;
         steps++;
         if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
             hit = true;
             break;
         }
-        float adv = s * F.k_relax;
-        adv = adv > smax ? smax : adv;
-        adv = adv < F.step_min ? F.step_min : adv;
-        t = t + adv;
+        const float adv_min = __builtin_fmaf(t, F.cone_eps, base_min);
+        t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, smax), adv_min);
     }
     if (!hit) return false;
     t_hit = t;
@@ -223,7 +286,7 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
         if (!(l2 > 0.0f)) {
             n = f3(0.0f, 0.0f, 0.0f);
         } else {
-            n = n * (1.0f / sqrtf(l2));
+            n = n * fast_rsq(l2);
         }
         n_world = mul33(I->o2w, n);
     }
@@ -231,13 +294,13 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
 }
 
 /* Closest hit over the scene.  SINGLE: exactly one instance, no BVH, all scene data wave-uniform. */
-template <int PATH, bool SINGLE>
-__device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float t_max, float& t_best, int& inst_best,
-                                              F3& n_best, unsigned& steps) {
+template <int PATH, bool SINGLE, bool DIAG = false>
+__device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float t_max, float t_base, float& t_best,
+                                              int& inst_best, F3& n_best, unsigned& steps, DiagAcc* dg = nullptr) {
     if constexpr (SINGLE) {
         float t;
         F3 n;
-        if (march_instance<PATH, true>(F, F.inst, F.vols + F.inst->slot, o, d, t_max, t, n, steps)) {
+        if (march_instance<PATH, true, DIAG>(F, F.inst, F.vols + F.inst->slot, o, d, t_max, t_base, t, n, steps, dg)) {
             t_best = t;
             inst_best = 0;
             n_best = n;
@@ -258,7 +321,7 @@ __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float
                 const DInstance* I = F.inst + ii;
                 float t;
                 F3 n;
-                if (march_instance<PATH, true>(F, I, F.vols + I->slot, o, d, best, t, n, steps)) {
+                if (march_instance<PATH, true, DIAG>(F, I, F.vols + I->slot, o, d, best, t_base, t, n, steps, dg)) {
                     if (!any || t < best || (t == best && ii < inst_best)) {
                         any = true;
                         best = t;
@@ -276,12 +339,13 @@ __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float
     }
 }
 
-template <int PATH, bool SINGLE>
-__device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_max, unsigned& steps) {
+template <int PATH, bool SINGLE, bool DIAG = false>
+__device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_max, float t_base, unsigned& steps,
+                                          DiagAcc* dg = nullptr) {
     float t;
     F3 n;
     if constexpr (SINGLE) {
-        return march_instance<PATH, false>(F, F.inst, F.vols + F.inst->slot, o, d, t_max, t, n, steps);
+        return march_instance<PATH, false, DIAG>(F, F.inst, F.vols + F.inst->slot, o, d, t_max, t_base, t, n, steps, dg);
     } else {
         int stack[16];
         int sp = 0;
@@ -291,7 +355,7 @@ __device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_m
             if (!slab_box(o, d, nd, t_max)) continue;
             if (nd.left < 0) {
                 const DInstance* I = F.inst + (-nd.left - 1);
-                if (march_instance<PATH, false>(F, I, F.vols + I->slot, o, d, t_max, t, n, steps)) return true;
+                if (march_instance<PATH, false, DIAG>(F, I, F.vols + I->slot, o, d, t_max, t_base, t, n, steps, dg)) return true;
             } else {
                 stack[sp++] = nd.right;
                 stack[sp++] = nd.left;
@@ -335,13 +399,15 @@ __device__ __forceinline__ F3 env_lookup(const uint8_t* __restrict__ env, int S,
 /* Radiance(), Lighting.hlsli:50-101 (F enters twice, PI = 3.141592f as in Constants.hlsli). */
 __device__ __forceinline__ F3 radiance(F3 Li, F3 wi, F3 wo, F3 n, F3 albedo, float rough, float metal, float k) {
     const float PI_REF = 3.141592f;
-    F3 h = normalize3(wi + wo);
+    const float INV_PI_REF = 1.0f / 3.141592f;
+    F3 hv = wi + wo;
+    F3 h = hv * fast_rsq(dot3(hv, hv));
     F3 f0 = f3(0.04f + (albedo.x - 0.04f) * metal, 0.04f + (albedo.y - 0.04f) * metal,
                0.04f + (albedo.z - 0.04f) * metal);
     float a2 = rough * rough;
     float ndoth = maxf_(dot3(n, h), 0.0f);
     float c = (ndoth * ndoth) * (a2 - 1.0f) + 1.0f;
-    float D = a2 / maxf_((PI_REF * c) * c, 0.001f);
+    float D = a2 * fast_rcp(maxf_((PI_REF * c) * c, 0.001f));
     float wdoth = maxf_(dot3(wo, h), 0.0f);
     float m = maxf_(-wdoth + 1.0f, 0.0f);
     float m2 = m * m;
@@ -349,21 +415,21 @@ __device__ __forceinline__ F3 radiance(F3 Li, F3 wi, F3 wo, F3 n, F3 albedo, flo
     F3 Fr = f3(f0.x + (-f0.x + 1.0f) * m5, f0.y + (-f0.y + 1.0f) * m5, f0.z + (-f0.z + 1.0f) * m5);
     float dwo = maxf_(dot3(n, wo), 0.0f);
     float dwi = maxf_(dot3(n, wi), 0.0f);
-    float G = (dwo / (dwo * (1.0f - k) + k)) * (dwi / (dwi * (1.0f - k) + k));
-    float den = maxf_((4.0f * dwo) * dwi, 0.0001f);
-    F3 cook = f3(((D * Fr.x) * G) / den, ((D * Fr.y) * G) / den, ((D * Fr.z) * G) / den);
+    float G = (dwo * fast_rcp(dwo * (1.0f - k) + k)) * (dwi * fast_rcp(dwi * (1.0f - k) + k));
+    float dg = (D * G) * fast_rcp(maxf_((4.0f * dwo) * dwi, 0.0001f));
+    F3 cook = f3(dg * Fr.x, dg * Fr.y, dg * Fr.z);
     float km = 1.0f - metal;
     F3 kd = f3((1.0f - Fr.x) * km, (1.0f - Fr.y) * km, (1.0f - Fr.z) * km);
-    F3 brdf = f3((albedo.x / PI_REF) * kd.x + cook.x * Fr.x, (albedo.y / PI_REF) * kd.y + cook.y * Fr.y,
-                 (albedo.z / PI_REF) * kd.z + cook.z * Fr.z);
+    F3 brdf = f3((albedo.x * INV_PI_REF) * kd.x + cook.x * Fr.x, (albedo.y * INV_PI_REF) * kd.y + cook.y * Fr.y,
+                 (albedo.z * INV_PI_REF) * kd.z + cook.z * Fr.z);
     float ndwi = dot3(n, wi);
     return f3((brdf.x * Li.x) * ndwi, (brdf.y * Li.y) * ndwi, (brdf.z * Li.z) * ndwi);
 }
 
 __device__ __forceinline__ float tonemap(float c) {
-    c = c > 0.0f ? c : 0.0f;
-    c = c / (c + 1.0f);
-    return powf(c, 1.0f / 2.2f);
+    c = c > 0.0f ? c : 0.0f;          /* negative / NaN → 0, what the UNORM render target keeps */
+    c = c * fast_rcp(c + 1.0f);        /* Reinhard, Raytracing.hlsl:35 */
+    return fast_pow(c, 1.0f / 2.2f);   /* gamma, :36 (pow(0, e) = exp2(-inf) = 0) */
 }
 
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
@@ -383,8 +449,10 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
  *   LINEAR: tile = blockIdx (consecutive tiles on different XCDs).
  * Placement only affects speed, never results.
  */
-template <int PATH, bool SINGLE>
+template <int PATH, bool SINGLE, bool DIAG>
 __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
+    unsigned long long t_start = 0;
+    if constexpr (DIAG) t_start = __builtin_amdgcn_s_memrealtime(); /* 100 MHz; diagnostic build only */
     const int nblk = (int)gridDim.x;
     const int b = (int)blockIdx.x;
     int tile_x, tile_y;
@@ -413,6 +481,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
     const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows;
 
     unsigned n_primary = 0, n_shadow = 0, n_bounce = 0, s_primary = 0, s_shadow = 0, n_hits = 0;
+    DiagAcc dg;
 
     if (valid) {
         /* camera ray (Ray.hlsli:36-48, then normalised) */
@@ -429,7 +498,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
         int inst = 0;
         F3 n = f3(0.0f, 0.0f, 0.0f);
         F3 color;
-        if (trace_closest<PATH, SINGLE>(F, o, d, 10000.0f, t_hit, inst, n, s_primary)) {
+        if (trace_closest<PATH, SINGLE, DIAG>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, s_primary, &dg)) {
             n_hits = 1;
             const DVolume* V = F.vols + F.inst[inst].slot;
             F3 albedo = f3(V->tint[0], V->tint[1], V->tint[2]);
@@ -444,7 +513,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
                 bool shadowed = false;
                 if (F.shadow) {
                     n_shadow = 1;
-                    shadowed = trace_any<PATH, SINGLE>(F, so, ld, 5000.0f, s_shadow);
+                    shadowed = trace_any<PATH, SINGLE, DIAG>(F, so, ld, 5000.0f, t_hit, s_shadow, &dg);
                 }
                 color = f3(0.0f, 0.0f, 0.0f);
                 if (!shadowed) {
@@ -459,30 +528,61 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
         reinterpret_cast<float4*>(F.out)[(size_t)pyl * F.width + px] = outp;
     }
 
-    /* Statistics (algorithmic-byte accounting): wave shuffle-reduce → LDS → one
-       32-byte record per workgroup, plain stores.  No atomics: 6 same-address atomics per wave
-       serialise at ~12 ns each at the memory side and cost more than the march itself. */
+    /* Statistics (algorithmic-byte accounting): wave shuffle-reduce, then one 32-byte
+       record per WAVE with plain stores.  No atomics (6 same-address atomics per wave serialise at
+       ~12 ns each at the memory side and cost more than the march itself) and no workgroup
+       barrier (it would pin the three fast waves of a tile until its slowest wave retires). */
+    const unsigned s_primary_lane = s_primary, s_shadow_lane = s_shadow;
     n_primary = wave_sum(n_primary);
     n_shadow = wave_sum(n_shadow);
     n_bounce = wave_sum(n_bounce);
     s_primary = wave_sum(s_primary);
     s_shadow = wave_sum(s_shadow);
     n_hits = wave_sum(n_hits);
-    __shared__ unsigned red[4][kStatWords];
-    if (lane == 0) {
-        red[wave][0] = n_primary;
-        red[wave][1] = n_shadow;
-        red[wave][2] = n_bounce;
-        red[wave][3] = s_primary;
-        red[wave][4] = s_shadow;
-        red[wave][5] = n_hits;
+    unsigned max_iter = 0, d_mem = 0, d_loop = 0, d_iters = 0;
+    if constexpr (DIAG) {
+        /* the accumulators are per lane (each lane only counts iterations it was active in): report
+           the lane with the longest chain of dependent samples, i.e. the wave's critical path */
+        max_iter = s_primary_lane + s_shadow_lane;
+        unsigned long long key = ((unsigned long long)dg.iters << 8) | (unsigned)lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            unsigned other = __shfl_xor(max_iter, o);
+            max_iter = other > max_iter ? other : max_iter;
+            unsigned long long ok = __shfl_xor(key, o);
+            key = ok > key ? ok : key;
+        }
+        const int src = (int)(key & 0xff);
+        d_mem = __shfl((unsigned)dg.mem, src);
+        d_loop = __shfl((unsigned)dg.loop, src);
+        d_iters = __shfl(dg.iters, src);
     }
-    __syncthreads();
-    if (threadIdx.x < 8 && F.stats != nullptr) {
-        unsigned v = 0;
-        if (threadIdx.x < kStatWords)
-            v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        F.stats[(size_t)b * 8 + threadIdx.x] = v;
+    if (F.stats != nullptr && lane < 8) {
+        unsigned v = lane == 0 ? n_primary : lane == 1 ? n_shadow : lane == 2 ? n_bounce : lane == 3 ? s_primary
+                   : lane == 4 ? s_shadow : lane == 5 ? n_hits : 0u;
+        F.stats[((size_t)b * 4 + wave) * kStatRecord + lane] = v;
+    }
+    if constexpr (DIAG) {
+        /* diagnostic timeline record: where and when this wave ran and where its march cycles went
+           (never in the production kernel; stamp values leave only through this buffer) */
+        if (F.diag_buf != nullptr && lane < kDiagRecord) {
+            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+            const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4); /* HW_REG_HW_ID */
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   /* HW_REG_XCC_ID[3:0] */
+            unsigned v = 0;
+            switch (lane) {
+                case 0: v = (unsigned)t_start; break;
+                case 1: v = (unsigned)t_end; break;
+                case 2: v = hw_id; break;
+                case 3: v = xcc; break;
+                case 4: v = max_iter; break;
+                case 5: v = d_mem; break;
+                case 6: v = d_loop; break;
+                case 7: v = d_iters; break;
+                default: break;
+            }
+            F.diag_buf[((size_t)b * 4 + wave) * kDiagRecord + lane] = v;
+        }
     }
 }
 
@@ -524,7 +624,10 @@ template <int PATH, bool SINGLE>
 static hipError_t launch_t(const DFrame& F, hipStream_t stream) {
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL((march_kernel<PATH, SINGLE>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
+    if (F.diag)
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, true>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
+    else
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
     return hipGetLastError();
 }
 

@@ -152,6 +152,17 @@ class VHipRenderer:
             _abi.check(m, "vrt_timing_history")
         return [buf[i] for i in range(m)]
 
+    def wave_records(self, which: int = 0) -> np.ndarray:
+        """Per-wave records of the last launch, [waves, 8] uint32 (vrt_debug_wave_records):
+        which=0 counters, which=1 diagnostic timeline (after a FLAG_DIAG_TIMELINE launch)."""
+        self._require()
+        n = self._lib.vrt_debug_wave_records(self._ctx, which, None, 0)
+        if n < 0:
+            _abi.check(int(n), "vrt_debug_wave_records")
+        buf = np.zeros(int(n), dtype=np.uint32)
+        self._lib.vrt_debug_wave_records(self._ctx, which, buf.ctypes.data_as(C.c_void_p), int(n))
+        return buf.reshape(-1, 8)
+
     def _require(self) -> None:
         if not self._ctx:
             raise RuntimeError("renderer is not active (Start() not called or failed)")
