@@ -54,16 +54,17 @@ def test_config2_full_size(renderer, oracle_lib):
 
 
 @pytest.mark.parametrize("shadow", [False, True])
-@pytest.mark.parametrize("path", [_abi.PATH_DENSE, _abi.PATH_BRICK])
+@pytest.mark.parametrize("path", [_abi.PATH_DENSE, _abi.PATH_BRICK, _abi.PATH_BRICK_LDS])
 def test_config3_torus_parity(renderer, oracle_lib, shadow, path):
     sc = scenes.config3_torus(7, 64)
     p = v.default_params(480, 270, scenes.min_cell(sc), 255, shadow=shadow, path=path)
     assert_parity(renderer, sc, p)
 
 
-def test_config3_at_256_cubed(renderer, oracle_lib):
+@pytest.mark.parametrize("path", [_abi.PATH_BRICK, _abi.PATH_BRICK_LDS])
+def test_config3_at_256_cubed(renderer, oracle_lib, path):
     sc = scenes.config3_torus(8, 256)
-    p = v.default_params(640, 360, scenes.min_cell(sc), 255, shadow=True)
+    p = v.default_params(640, 360, scenes.min_cell(sc), 255, shadow=True, path=path)
     assert_parity(renderer, sc, p)
 
 
@@ -113,10 +114,12 @@ def test_edge_cases(renderer, oracle_lib):
     cell = scenes.min_cell(sc)
     for (w, h) in [(1, 1), (17, 9), (33, 47), (250, 3), (3, 250)]:
         assert_parity(renderer, sc, v.default_params(w, h, cell, 64))
+        assert_parity(renderer, sc, v.default_params(w, h, cell, 64, path=_abi.PATH_BRICK_LDS))
     # camera inside the volume (tEnter < 0), inside the solid, and looking away
     for pos in [(60.0, 0.0, 0.0), (10.0, 5.0, 0.0), (-300.0, 0.0, 0.0)]:
         sc.Camera = v.VCamera(Position=pos, Rotation=sc.Camera.Rotation)
         assert_parity(renderer, sc, v.default_params(96, 54, cell, 64, shadow=True))
+        assert_parity(renderer, sc, v.default_params(96, 54, cell, 64, shadow=True, path=_abi.PATH_BRICK_LDS))
     # max_steps = 0 and a 1-step budget: everything misses / only entry hits
     sc = scenes.config2_sphere(5, 8)
     assert_parity(renderer, sc, v.default_params(64, 36, cell, 0))
@@ -126,6 +129,7 @@ def test_edge_cases(renderer, oracle_lib):
         vol = v.VVoxelVolume(r, 50.0).fill(lambda X, Y, Z: np.sqrt(X * X + Y * Y + Z * Z) - 30.0)
         s2 = v.VScene(Camera=v.look_minus_x_camera(200.0), DirectionalLight=v.demo_light(), Objects=[v.VVoxelObject(Volume=vol)])
         assert_parity(renderer, s2, v.default_params(64, 36, vol.GetCellSize(), 64, shadow=True))
+        assert_parity(renderer, s2, v.default_params(64, 36, vol.GetCellSize(), 64, shadow=True, path=_abi.PATH_BRICK_LDS))
     # empty scene: every ray reads the environment (or black without one)
     s3 = v.VScene(Camera=v.look_minus_x_camera(200.0), EnvironmentMap=v.procedural_skybox(8))
     assert_parity(renderer, s3, v.default_params(64, 36, 1.0, 64))
@@ -150,6 +154,7 @@ def test_shell_volume_with_step_clamp(renderer, oracle_lib):
                   EnvironmentMap=v.procedural_skybox(8))
     img, t = assert_parity(renderer, sc, v.default_params(320, 180, vol.GetCellSize(), 255, shadow=True))
     assert t["primary_steps"] / t["primary_rays"] > 10  # the clamp makes this a long march
+    assert_parity(renderer, sc, v.default_params(320, 180, vol.GetCellSize(), 255, shadow=True, path=_abi.PATH_BRICK_LDS))
 
 
 def test_row_tiles_into_device_memory(renderer, oracle_lib):

@@ -27,6 +27,23 @@ __global__ void chase_global_div(const unsigned* __restrict__ buf, int n, int it
     if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
     sink[threadIdx.x] = idx;
 }
+// dependent 8-byte loads (global_load_dwordx2) at 8-byte aligned or 4-byte aligned addresses
+struct __attribute__((packed, aligned(4))) f2u { unsigned a, b; };
+__global__ void chase_x2(const unsigned* __restrict__ buf, int n, int iters, int odd, unsigned long long* out, unsigned* sink) {
+    unsigned idx = ((threadIdx.x * 977u) % (n / 2)) * 2 + odd;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned acc = 0;
+    for (int i = 0; i < iters; i++) {
+        const f2u v = *reinterpret_cast<const f2u*>(buf + idx);
+        acc += v.b;
+        idx = v.a;
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+    sink[threadIdx.x] = idx + acc;
+}
 __global__ void chase_lds(int iters, unsigned long long* out, unsigned* sink) {
     __shared__ unsigned l[4096];
     for (int i = threadIdx.x; i < 4096; i += 64) l[i] = (i * 61 + 17) & 4095;
@@ -76,6 +93,18 @@ int main() {
             for (int rep = 0; rep < 3; rep++) { hipLaunchKernelGGL(chase_global_div, 1, 64, 0, 0, d, (int)n, iters, d_out, d_sink); hipMemcpy(c, d_out, 16, hipMemcpyDeviceToHost); }
             printf("global chase, footprint %10zu B: %7.1f ticks/load = %6.1f ns (64 divergent lanes)\n", bytes, (double)c[0] / iters, (double)c[1] * 10.0 / iters);
         }
+        hipFree(d);
+    }
+    for (int odd = 0; odd < 2; odd++) {
+        // 4 KB buffer: a random cycle over the even (or odd) word slots; the second word is junk
+        const size_t n = 1024;
+        std::vector<unsigned> slots(n / 2); std::iota(slots.begin(), slots.end(), 0u); std::shuffle(slots.begin(), slots.end(), rng);
+        std::vector<unsigned> h(n + 2, 7u);
+        for (size_t i = 0; i < slots.size(); i++) h[slots[i] * 2 + odd] = slots[(i + 1) % slots.size()] * 2 + odd;
+        unsigned* d; hipMalloc(&d, (n + 2) * 4); hipMemcpy(d, h.data(), (n + 2) * 4, hipMemcpyHostToDevice);
+        unsigned long long c2[2] = {0, 0};
+        for (int rep = 0; rep < 3; rep++) { hipLaunchKernelGGL(chase_x2, 1, 64, 0, 0, d, (int)n, iters, odd, d_out, d_sink); hipMemcpy(c2, d_out, 16, hipMemcpyDeviceToHost); }
+        printf("global dwordx2 chase, 4 KB, %s: %7.1f ticks/load = %6.1f ns (64 divergent lanes)\n", odd ? "4-byte aligned (odd word)" : "8-byte aligned", (double)c2[0] / iters, (double)c2[1] * 10.0 / iters);
         hipFree(d);
     }
     unsigned long long c[2] = {0, 0};

@@ -19,8 +19,13 @@ from volumetricraytracer_amd import _abi  # noqa: E402
 
 workload = sys.argv[1] if len(sys.argv) > 1 else "c3"
 tile_map = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-sc, W, H, max_steps, shadow, label = bench.build_workload(workload)
-p = v.default_params(W, H, scenes.min_cell(sc), max_steps, shadow=shadow)
+if workload.startswith("torus"):  # torus6 / torus7 / torus8: the config-3 scene at another grid resolution
+    res = int(workload[5:])
+    sc, W, H, max_steps, shadow, label = scenes.config3_torus(res, 256, distance=190.0), 1920, 1080, 255, True, f"torus SDF at 2^{res} cells"
+else:
+    sc, W, H, max_steps, shadow, label = bench.build_workload(workload)
+path = {"auto": 0, "dense": 1, "brick": 2, "lds": 3}[os.environ.get("VRT_PATH", "auto")]
+p = v.default_params(W, H, scenes.min_cell(sc), max_steps, shadow=shadow, path=path)
 p.flags = tile_map | _abi.FLAG_DIAG_TIMELINE
 r = v.VHipRenderer()
 assert r.Start()
@@ -47,6 +52,7 @@ maxit = dg[:, 4].astype(np.int64)
 mem_cyc = dg[:, 5].astype(np.int64)
 loop_cyc = dg[:, 6].astype(np.int64)
 iters = dg[:, 7].astype(np.int64)
+fetches = dg[:, 2].astype(np.int64)
 span = e_us[live].max()
 print(f"{label}: kernel {t['kernel_ms']*1e3:.1f} us (event, diagnostic build), waves {len(rec)} (live {live.sum()}), span {span:.1f} us")
 print("wave duration us: mean %.2f  p50 %.2f  p90 %.2f  p99 %.2f  max %.2f" % (dur[live].mean(), *np.percentile(dur[live], [50, 90, 99]), dur[live].max()))
@@ -68,8 +74,9 @@ m = live & (iters > 60)
 if m.any():
     print("waves with >60 loop iterations: %d" % m.sum())
     print("  cycles per loop iteration (stamped region): mean %.0f  p10 %.0f  p90 %.0f" % ((loop_cyc[m] / iters[m]).mean(), *np.percentile(loop_cyc[m] / iters[m], [10, 90])))
-    print("  of which load+interpolate:                  mean %.0f  p10 %.0f  p90 %.0f" % ((mem_cyc[m] / iters[m]).mean(), *np.percentile(mem_cyc[m] / iters[m], [10, 90])))
+    print("  of which tap fetches:                       mean %.0f  p10 %.0f  p90 %.0f" % ((mem_cyc[m] / iters[m]).mean(), *np.percentile(mem_cyc[m] / iters[m], [10, 90])))
     print("  wave us per iteration (wall):               mean %.3f" % (dur[m] / iters[m]).mean())
+    print("  iterations that fetched a new cell: %.1f %%; cycles per fetch: mean %.0f" % (100.0 * fetches[m].sum() / iters[m].sum(), (mem_cyc[m] / np.maximum(fetches[m], 1)).mean()))
     tail = m & (e_us > 0.6 * span)
     if tail.any():
         print("  waves ending in the tail (%d): cycles/iter %.0f, load+interp %.0f, us/iter %.3f" % (

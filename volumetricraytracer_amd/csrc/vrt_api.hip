@@ -449,9 +449,11 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
     return VRT_OK;
 }
 
-int resolve_path(int path) {
+/* AUTO picks the fastest measured path; the LDS brick cache is wave-cooperative and currently
+ * covers single-instance scenes — multi-instance scenes fall back to bricks in global memory. */
+int resolve_path(int path, bool single) {
     if (path == VRT_PATH_AUTO) return VRT_PATH_BRICK;
-    if (path == VRT_PATH_BRICK_LDS) return VRT_PATH_BRICK; /* TODO(round 1): LDS brick cache */
+    if (path == VRT_PATH_BRICK_LDS && !single) return VRT_PATH_BRICK;
     return path;
 }
 
@@ -508,7 +510,8 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, int row0, in
         F.diag_buf = D.d_diag;
     }
     HIP_TRY(hipEventRecord(D.ev0[ring], stream));
-    HIP_TRY(launch_march(F, resolve_path(p->path), ctx->scene.n_instances == 1, stream));
+    const bool single = ctx->scene.n_instances == 1;
+    HIP_TRY(launch_march(F, resolve_path(p->path, single), single, stream));
     HIP_TRY(hipEventRecord(D.ev1[ring], stream));
     return VRT_OK;
 }

@@ -179,7 +179,8 @@ __device__ __forceinline__ bool slab_box(F3 o, F3 d, const DBvhNode& n, float t_
 struct DiagAcc {
     unsigned long long mem = 0;   /* address ready → interpolated value available (loads + lerps) */
     unsigned long long loop = 0;  /* whole march-loop iterations */
-    unsigned iters = 0;           /* iterations this wave executed (any lane active) */
+    unsigned iters = 0;           /* march-loop iterations of this lane */
+    unsigned fetches = 0;         /* iterations that had to load a new cell's taps */
 };
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
@@ -187,109 +188,149 @@ __device__ __forceinline__ unsigned long long stamp() {
     return t;
 }
 
+/* One ray against one instance, in the instance's object / voxel space. */
+struct RaySeg {
+    F3 oo, od;            /* object-space origin and (un-normalised) direction */
+    F3 uo, ud;            /* the same ray in voxel units: u(t) = uo + ud*t */
+    float t_enter, t0, t_end;
+    float ds;             /* density → ray-parameter distance: density_scale / |od| */
+    float smax;           /* step_max / |od| */
+    float cmax;           /* N - 2 */
+    float base_min;       /* step_min + cone_eps * t_base */
+};
+
+/* Transform the ray into the instance, slab-test its volume box and derive the march constants.
+ * Returns false when the box is missed (nothing else is then valid). */
+__device__ __forceinline__ bool setup_ray(const DFrame& F, const DInstance* __restrict__ I, const VolRef& V, F3 o, F3 d,
+                                          float t_cur, float t_base, RaySeg& R) {
+    F3 rel = f3(o.x - I->pos[0], o.y - I->pos[1], o.z - I->pos[2]);
+    R.oo = mul33(I->w2o, rel);
+    R.od = mul33(I->w2o, d);
+    float t_exit;
+    if (!slab(R.oo, R.od, V.extent, t_cur, R.t_enter, t_exit)) return false;
+    const float inv_len = 1.0f / sqrtf(dot3(R.od, R.od));
+    R.ds = V.dscale * inv_len;
+    R.smax = V.step_max * inv_len;
+    R.uo = f3((R.oo.x + V.extent) * V.inv_cell, (R.oo.y + V.extent) * V.inv_cell, (R.oo.z + V.extent) * V.inv_cell);
+    R.ud = R.od * V.inv_cell;
+    R.cmax = (float)(V.N - 2);
+    R.t0 = (R.t_enter > 0.0f ? R.t_enter : 0.0f) + F.eps_in;
+    R.t_end = minf_(t_exit, t_cur);
+    /* smallest step: one pixel-footprint radius at the total path length t_base + t */
+    R.base_min = __builtin_fmaf(t_base, F.cone_eps, F.step_min);
+    return true;
+}
+
+/* Cell + fraction of the sample at ray parameter t: cell = clamp(floor(u), 0, N-2) (v_med3_f32). */
+struct Cell {
+    int cx, cy, cz;
+    float fx, fy, fz;
+};
+__device__ __forceinline__ Cell cell_at(const RaySeg& R, float t) {
+    const float ux = __builtin_fmaf(R.ud.x, t, R.uo.x);
+    const float uy = __builtin_fmaf(R.ud.y, t, R.uo.y);
+    const float uz = __builtin_fmaf(R.ud.z, t, R.uo.z);
+    const float cxf = __builtin_amdgcn_fmed3f(floorf(ux), 0.0f, R.cmax);
+    const float cyf = __builtin_amdgcn_fmed3f(floorf(uy), 0.0f, R.cmax);
+    const float czf = __builtin_amdgcn_fmed3f(floorf(uz), 0.0f, R.cmax);
+    Cell c;
+    c.fx = ux - cxf;
+    c.fy = uy - cyf;
+    c.fz = uz - czf;
+    c.cx = (int)cxf;
+    c.cy = (int)cyf;
+    c.cz = (int)czf;
+    return c;
+}
+
+/* World-space normal at a hit found in cell c after `iter` march iterations.  Taps always come from
+ * global memory here (once per hit, 24 independent loads in flight). */
+template <int PATH>
+__device__ __forceinline__ F3 hit_normal(const DInstance* __restrict__ I, const VolRef& V, const RaySeg& R, const Cell& c,
+                                         int iter) {
+    F3 n;
+    if (iter == 0 && R.t_enter >= 0.0f) {
+        /* surface cut by the volume boundary: AABB-face normal (Raytracing.hlsl:198-226) */
+        float tb = R.t_enter - 0.1f;
+        float rx = __builtin_fmaf(R.od.x, tb, R.oo.x);
+        float ry = __builtin_fmaf(R.od.y, tb, R.oo.y);
+        float rz = __builtin_fmaf(R.od.z, tb, R.oo.z);
+        float e = V.extent;
+        n.x = rx > e ? 1.0f : (rx < -e ? -1.0f : 0.0f);
+        n.y = ry > e ? 1.0f : (ry < -e ? -1.0f : 0.0f);
+        n.z = rz > e ? 1.0f : (rz < -e ? -1.0f : 0.0f);
+    } else {
+        /* central differences of the interpolant one cell either side (Voxel.hlsli:783-804) */
+        const int N2 = V.N - 2;
+        int xp = c.cx + 1 > N2 ? N2 : c.cx + 1, xm = c.cx - 1 < 0 ? 0 : c.cx - 1;
+        int yp = c.cy + 1 > N2 ? N2 : c.cy + 1, ym = c.cy - 1 < 0 ? 0 : c.cy - 1;
+        int zp = c.cz + 1 > N2 ? N2 : c.cz + 1, zm = c.cz - 1 < 0 ? 0 : c.cz - 1;
+        n.x = trilinear<PATH>(V, xp, c.cy, c.cz, c.fx, c.fy, c.fz) - trilinear<PATH>(V, xm, c.cy, c.cz, c.fx, c.fy, c.fz);
+        n.y = trilinear<PATH>(V, c.cx, yp, c.cz, c.fx, c.fy, c.fz) - trilinear<PATH>(V, c.cx, ym, c.cz, c.fx, c.fy, c.fz);
+        n.z = trilinear<PATH>(V, c.cx, c.cy, zp, c.fx, c.fy, c.fz) - trilinear<PATH>(V, c.cx, c.cy, zm, c.fx, c.fy, c.fz);
+    }
+    float l2 = dot3(n, n);
+    if (!(l2 > 0.0f)) {
+        n = f3(0.0f, 0.0f, 0.0f);
+    } else {
+        n = n * fast_rsq(l2);
+    }
+    return mul33(I->o2w, n);
+}
+
 /*
- * Sphere-trace one instance.  o,d: world-space ray (d normalised).  Returns true on hit and
- * the ray parameter (shared by world and object space — the object-space direction is not
- * re-normalised, DXR semantics).  NORMAL: also produce the world-space normal.
+ * Sphere-trace one instance (per-lane control flow).  o,d: world-space ray (d normalised).  Returns
+ * true on hit and the ray parameter (shared by world and object space — the object-space direction
+ * is not re-normalised, DXR semantics).  NORMAL: also produce the world-space normal.
  */
 template <int PATH, bool NORMAL, bool DIAG = false>
 __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance* __restrict__ I,
                                                const DVolume* __restrict__ Vd, F3 o, F3 d, float t_cur, float t_base,
                                                float& t_hit, F3& n_world, unsigned& steps, DiagAcc* dg = nullptr) {
     const VolRef V = load_vol<PATH>(Vd);
-    F3 rel = f3(o.x - I->pos[0], o.y - I->pos[1], o.z - I->pos[2]);
-    F3 oo = mul33(I->w2o, rel);
-    F3 od = mul33(I->w2o, d);
-    float t_enter, t_exit;
-    if (!slab(oo, od, V.extent, t_cur, t_enter, t_exit)) return false;
-
-    const float inv_len = 1.0f / sqrtf(dot3(od, od));
-    const float ds = V.dscale * inv_len;
-    const float smax = V.step_max * inv_len;
-    const F3 uo = f3((oo.x + V.extent) * V.inv_cell, (oo.y + V.extent) * V.inv_cell, (oo.z + V.extent) * V.inv_cell);
-    const F3 ud = od * V.inv_cell;
-    const float cmax = (float)(V.N - 2);
-
-    float t = (t_enter > 0.0f ? t_enter : 0.0f) + F.eps_in;
-    const float t_end = minf_(t_exit, t_cur);
-    /* smallest step: one pixel-footprint radius at the total path length t_base + t */
-    const float base_min = __builtin_fmaf(t_base, F.cone_eps, F.step_min);
+    RaySeg R;
+    if (!setup_ray(F, I, V, o, d, t_cur, t_base, R)) return false;
+    float t = R.t0;
     const int max_steps = F.max_steps;
     bool hit = false;
     int i = 0;
-    int cx = 0, cy = 0, cz = 0;
-    float fx = 0.0f, fy = 0.0f, fz = 0.0f;
+    Cell c = {0, 0, 0, 0.0f, 0.0f, 0.0f};
+    /* (Keeping the current cell's 8 taps in registers and skipping the loads while a ray stays in
+       the cell was measured: even the slowest rays change cell every other sample, and the extra
+       compare + branch made the frame 7 % slower.  Not done.) */
     for (; i < max_steps; i++) {
-        if (t > t_end) break;
+        if (t > R.t_end) break;
         unsigned long long st0 = 0, st1 = 0;
         if constexpr (DIAG) st0 = stamp();
-        const float ux = __builtin_fmaf(ud.x, t, uo.x);
-        const float uy = __builtin_fmaf(ud.y, t, uo.y);
-        const float uz = __builtin_fmaf(ud.z, t, uo.z);
-        /* cell = clamp(floor(u), 0, N-2): v_med3_f32 (u is finite) */
-        const float cxf = __builtin_amdgcn_fmed3f(floorf(ux), 0.0f, cmax);
-        const float cyf = __builtin_amdgcn_fmed3f(floorf(uy), 0.0f, cmax);
-        const float czf = __builtin_amdgcn_fmed3f(floorf(uz), 0.0f, cmax);
-        fx = ux - cxf;
-        fy = uy - cyf;
-        fz = uz - czf;
-        cx = (int)cxf;
-        cy = (int)cyf;
-        cz = (int)czf;
+        c = cell_at(R, t);
         if constexpr (DIAG) {
-            asm volatile("" ::"v"(cx), "v"(cy), "v"(cz), "v"(fx), "v"(fy), "v"(fz));
+            asm volatile("" ::"v"(c.cx), "v"(c.cy), "v"(c.cz), "v"(c.fx), "v"(c.fy), "v"(c.fz));
             st1 = stamp();
         }
-        const Taps taps = fetch8<PATH>(V, cx, cy, cz);
+        const Taps taps = fetch8<PATH>(V, c.cx, c.cy, c.cz);
         if constexpr (DIAG) {
             asm volatile("s_waitcnt vmcnt(0)" ::"v"(taps.y00a), "v"(taps.y00b), "v"(taps.y01a), "v"(taps.y01b), "v"(taps.y10a),
                          "v"(taps.y10b), "v"(taps.y11a), "v"(taps.y11b));
-            const unsigned long long st2 = stamp();
-            dg->mem += st2 - st1; /* address arithmetic + 4 loads until the data is back */
-            dg->iters++;
-            dg->loop += st2 - st0;
+            dg->mem += stamp() - st1; /* address arithmetic + 4 loads until the data is back */
+            dg->fetches++;
         }
-        const float s = lerp8(taps, fx, fy, fz) * ds;
+        const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
+        if constexpr (DIAG) {
+            asm volatile("" ::"v"(s));
+            dg->iters++;
+            dg->loop += stamp() - st0;
+        }
         steps++;
         if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
             hit = true;
             break;
         }
-        const float adv_min = __builtin_fmaf(t, F.cone_eps, base_min);
-        t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, smax), adv_min);
+        const float adv_min = __builtin_fmaf(t, F.cone_eps, R.base_min);
+        t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
     }
     if (!hit) return false;
     t_hit = t;
-    if constexpr (NORMAL) {
-        F3 n;
-        if (i == 0 && t_enter >= 0.0f) {
-            /* surface cut by the volume boundary: AABB-face normal (Raytracing.hlsl:198-226) */
-            float tb = t_enter - 0.1f;
-            float rx = __builtin_fmaf(od.x, tb, oo.x);
-            float ry = __builtin_fmaf(od.y, tb, oo.y);
-            float rz = __builtin_fmaf(od.z, tb, oo.z);
-            float e = V.extent;
-            n.x = rx > e ? 1.0f : (rx < -e ? -1.0f : 0.0f);
-            n.y = ry > e ? 1.0f : (ry < -e ? -1.0f : 0.0f);
-            n.z = rz > e ? 1.0f : (rz < -e ? -1.0f : 0.0f);
-        } else {
-            /* central differences of the interpolant one cell either side (Voxel.hlsli:783-804) */
-            const int N2 = V.N - 2;
-            int xp = cx + 1 > N2 ? N2 : cx + 1, xm = cx - 1 < 0 ? 0 : cx - 1;
-            int yp = cy + 1 > N2 ? N2 : cy + 1, ym = cy - 1 < 0 ? 0 : cy - 1;
-            int zp = cz + 1 > N2 ? N2 : cz + 1, zm = cz - 1 < 0 ? 0 : cz - 1;
-            n.x = trilinear<PATH>(V, xp, cy, cz, fx, fy, fz) - trilinear<PATH>(V, xm, cy, cz, fx, fy, fz);
-            n.y = trilinear<PATH>(V, cx, yp, cz, fx, fy, fz) - trilinear<PATH>(V, cx, ym, cz, fx, fy, fz);
-            n.z = trilinear<PATH>(V, cx, cy, zp, fx, fy, fz) - trilinear<PATH>(V, cx, cy, zm, fx, fy, fz);
-        }
-        float l2 = dot3(n, n);
-        if (!(l2 > 0.0f)) {
-            n = f3(0.0f, 0.0f, 0.0f);
-        } else {
-            n = n * fast_rsq(l2);
-        }
-        n_world = mul33(I->o2w, n);
-    }
+    if constexpr (NORMAL) n_world = hit_normal<PATH>(I, V, R, c, i);
     return true;
 }
 
@@ -449,13 +490,8 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
  *   LINEAR: tile = blockIdx (consecutive tiles on different XCDs).
  * Placement only affects speed, never results.
  */
-template <int PATH, bool SINGLE, bool DIAG>
-__global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
-    unsigned long long t_start = 0;
-    if constexpr (DIAG) t_start = __builtin_amdgcn_s_memrealtime(); /* 100 MHz; diagnostic build only */
-    const int nblk = (int)gridDim.x;
-    const int b = (int)blockIdx.x;
-    int tile_x, tile_y;
+/* blockIdx → 16x16-pixel tile under F.tile_map (see the kernel comment). */
+__device__ __forceinline__ void tile_of_block(const DFrame& F, int b, int nblk, int& tile_x, int& tile_y) {
     if (F.tile_map == kMapSupertile) {
         const int xcd = b & 7, q = b >> 3;
         const int st = (q >> 4) * 8 + xcd;      /* supertile index, row-major over st_x columns */
@@ -473,77 +509,50 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
         tile_x = b % F.tiles_x;
         tile_y = b / F.tiles_x;
     }
-    const int wave = (int)threadIdx.x >> 6;
-    const int lane = (int)threadIdx.x & 63;
-    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const int py = F.row0 + pyl;
-    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows;
+}
 
+/* Camera ray of pixel (px,py) (Ray.hlsli:36-48, then normalised). */
+__device__ __forceinline__ void camera_ray(const DFrame& F, int px, int py, F3& o, F3& d) {
+    float sx = (((float)px + 0.5f) / (float)F.width) * 2.0f - 1.0f;
+    float sy = (((float)py + 0.5f) / (float)F.height) * 2.0f - 1.0f;
+    float tx = sx * F.cx;
+    float ty = (-sy) * F.cy;
+    d = normalize3(f3((tx * F.r0[0] + ty * F.r1[0]) - F.r2[0], (tx * F.r0[1] + ty * F.r1[1]) - F.r2[1],
+                      (tx * F.r0[2] + ty * F.r1[2]) - F.r2[2]));
+    o = f3(F.cam_o[0], F.cam_o[1], F.cam_o[2]);
+}
+
+struct Counters {
     unsigned n_primary = 0, n_shadow = 0, n_bounce = 0, s_primary = 0, s_shadow = 0, n_hits = 0;
-    DiagAcc dg;
+};
 
-    if (valid) {
-        /* camera ray (Ray.hlsli:36-48, then normalised) */
-        float sx = (((float)px + 0.5f) / (float)F.width) * 2.0f - 1.0f;
-        float sy = (((float)py + 0.5f) / (float)F.height) * 2.0f - 1.0f;
-        float tx = sx * F.cx;
-        float ty = (-sy) * F.cy;
-        F3 d = normalize3(f3((tx * F.r0[0] + ty * F.r1[0]) - F.r2[0], (tx * F.r0[1] + ty * F.r1[1]) - F.r2[1],
-                             (tx * F.r0[2] + ty * F.r1[2]) - F.r2[2]));
-        F3 o = f3(F.cam_o[0], F.cam_o[1], F.cam_o[2]);
-        n_primary = 1;
-
-        float t_hit = 0.0f;
-        int inst = 0;
-        F3 n = f3(0.0f, 0.0f, 0.0f);
-        F3 color;
-        if (trace_closest<PATH, SINGLE, DIAG>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, s_primary, &dg)) {
-            n_hits = 1;
-            const DVolume* V = F.vols + F.inst[inst].slot;
-            F3 albedo = f3(V->tint[0], V->tint[1], V->tint[2]);
-            if (F.unlit) {
-                color = albedo;
-            } else {
-                F3 hp = f3(__builtin_fmaf(d.x, t_hit, o.x), __builtin_fmaf(d.y, t_hit, o.y),
-                           __builtin_fmaf(d.z, t_hit, o.z));
-                F3 so = f3(hp.x - d.x * 0.1f, hp.y - d.y * 0.1f, hp.z - d.z * 0.1f);
-                F3 wo = f3(-d.x, -d.y, -d.z);
-                F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
-                bool shadowed = false;
-                if (F.shadow) {
-                    n_shadow = 1;
-                    shadowed = trace_any<PATH, SINGLE, DIAG>(F, so, ld, 5000.0f, t_hit, s_shadow, &dg);
-                }
-                color = f3(0.0f, 0.0f, 0.0f);
-                if (!shadowed) {
-                    F3 Li = f3(F.light_strength, F.light_strength, F.light_strength);
-                    color = color + radiance(Li, ld, wo, n, albedo, V->roughness, V->metallic, V->k);
-                }
-            }
-        } else {
-            color = env_lookup(F.env, F.env_size, d);
-        }
-        float4 outp = make_float4(tonemap(color.x), tonemap(color.y), tonemap(color.z), 1.0f);
-        reinterpret_cast<float4*>(F.out)[(size_t)pyl * F.width + px] = outp;
+/*
+ * Statistics (algorithmic-byte accounting): wave shuffle-reduce, then one 32-byte record
+ * per WAVE with plain stores.  No atomics (6 same-address atomics per wave serialise at ~12 ns each
+ * at the memory side and cost more than the march itself) and no workgroup barrier (it would pin
+ * the three fast waves of a tile until its slowest wave retires).
+ */
+template <bool DIAG>
+__device__ __forceinline__ void write_records(const DFrame& F, int b, int wave, int lane, Counters k, const DiagAcc& dg,
+                                              unsigned long long t_start) {
+    const unsigned s_primary_lane = k.s_primary, s_shadow_lane = k.s_shadow;
+    k.n_primary = wave_sum(k.n_primary);
+    k.n_shadow = wave_sum(k.n_shadow);
+    k.n_bounce = wave_sum(k.n_bounce);
+    k.s_primary = wave_sum(k.s_primary);
+    k.s_shadow = wave_sum(k.s_shadow);
+    k.n_hits = wave_sum(k.n_hits);
+    if (F.stats != nullptr && lane < 8) {
+        unsigned v = lane == 0 ? k.n_primary : lane == 1 ? k.n_shadow : lane == 2 ? k.n_bounce : lane == 3 ? k.s_primary
+                   : lane == 4 ? k.s_shadow : lane == 5 ? k.n_hits : 0u;
+        F.stats[((size_t)b * 4 + wave) * kStatRecord + lane] = v;
     }
-
-    /* Statistics (algorithmic-byte accounting): wave shuffle-reduce, then one 32-byte
-       record per WAVE with plain stores.  No atomics (6 same-address atomics per wave serialise at
-       ~12 ns each at the memory side and cost more than the march itself) and no workgroup
-       barrier (it would pin the three fast waves of a tile until its slowest wave retires). */
-    const unsigned s_primary_lane = s_primary, s_shadow_lane = s_shadow;
-    n_primary = wave_sum(n_primary);
-    n_shadow = wave_sum(n_shadow);
-    n_bounce = wave_sum(n_bounce);
-    s_primary = wave_sum(s_primary);
-    s_shadow = wave_sum(s_shadow);
-    n_hits = wave_sum(n_hits);
-    unsigned max_iter = 0, d_mem = 0, d_loop = 0, d_iters = 0;
     if constexpr (DIAG) {
-        /* the accumulators are per lane (each lane only counts iterations it was active in): report
-           the lane with the longest chain of dependent samples, i.e. the wave's critical path */
-        max_iter = s_primary_lane + s_shadow_lane;
+        /* diagnostic timeline record: where and when this wave ran and where its march cycles went
+           (never in the production kernel; stamp values leave only through this buffer).  The
+           accumulators are per lane: report the lane with the longest chain of dependent samples,
+           i.e. the wave's critical path */
+        unsigned max_iter = s_primary_lane + s_shadow_lane;
         unsigned long long key = ((unsigned long long)dg.iters << 8) | (unsigned)lane;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -553,18 +562,10 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
             key = ok > key ? ok : key;
         }
         const int src = (int)(key & 0xff);
-        d_mem = __shfl((unsigned)dg.mem, src);
-        d_loop = __shfl((unsigned)dg.loop, src);
-        d_iters = __shfl(dg.iters, src);
-    }
-    if (F.stats != nullptr && lane < 8) {
-        unsigned v = lane == 0 ? n_primary : lane == 1 ? n_shadow : lane == 2 ? n_bounce : lane == 3 ? s_primary
-                   : lane == 4 ? s_shadow : lane == 5 ? n_hits : 0u;
-        F.stats[((size_t)b * 4 + wave) * kStatRecord + lane] = v;
-    }
-    if constexpr (DIAG) {
-        /* diagnostic timeline record: where and when this wave ran and where its march cycles went
-           (never in the production kernel; stamp values leave only through this buffer) */
+        const unsigned d_mem = __shfl((unsigned)dg.mem, src);
+        const unsigned d_loop = __shfl((unsigned)dg.loop, src);
+        const unsigned d_iters = __shfl(dg.iters, src);
+        const unsigned d_fetches = __shfl(dg.fetches, src);
         if (F.diag_buf != nullptr && lane < kDiagRecord) {
             const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
             const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4); /* HW_REG_HW_ID */
@@ -573,8 +574,8 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
             switch (lane) {
                 case 0: v = (unsigned)t_start; break;
                 case 1: v = (unsigned)t_end; break;
-                case 2: v = hw_id; break;
-                case 3: v = xcc; break;
+                case 2: v = d_fetches; break;
+                case 3: v = xcc | (hw_id << 4); break;
                 case 4: v = max_iter; break;
                 case 5: v = d_mem; break;
                 case 6: v = d_loop; break;
@@ -584,6 +585,245 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
             F.diag_buf[((size_t)b * 4 + wave) * kDiagRecord + lane] = v;
         }
     }
+}
+
+/* Directional-light shading of a hit (NoTex closest hit, Raytracing_NoTex.hlsl:41-94). */
+__device__ __forceinline__ F3 shade_hit(const DFrame& F, const DVolume* __restrict__ V, F3 d, F3 n, bool shadowed) {
+    F3 albedo = f3(V->tint[0], V->tint[1], V->tint[2]);
+    if (F.unlit) return albedo;
+    F3 color = f3(0.0f, 0.0f, 0.0f); /* SHADOW_BRIGHTNESS */
+    if (!shadowed) {
+        F3 wo = f3(-d.x, -d.y, -d.z);
+        F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
+        F3 Li = f3(F.light_strength, F.light_strength, F.light_strength);
+        color = color + radiance(Li, ld, wo, n, albedo, V->roughness, V->metallic, V->k);
+    }
+    return color;
+}
+
+/* Shadow-ray origin: the hit point pulled 0.1 back along the ray (Raytracing.hlsl:51-52). */
+__device__ __forceinline__ F3 shadow_origin(F3 o, F3 d, float t_hit) {
+    F3 hp = f3(__builtin_fmaf(d.x, t_hit, o.x), __builtin_fmaf(d.y, t_hit, o.y), __builtin_fmaf(d.z, t_hit, o.z));
+    return f3(hp.x - d.x * 0.1f, hp.y - d.y * 0.1f, hp.z - d.z * 0.1f);
+}
+
+__device__ __forceinline__ void store_pixel(const DFrame& F, int px, int pyl, F3 color) {
+    float4 outp = make_float4(tonemap(color.x), tonemap(color.y), tonemap(color.z), 1.0f);
+    reinterpret_cast<float4*>(F.out)[(size_t)pyl * F.width + px] = outp;
+}
+
+template <int PATH, bool SINGLE, bool DIAG>
+__global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
+    unsigned long long t_start = 0;
+    if constexpr (DIAG) t_start = __builtin_amdgcn_s_memrealtime(); /* 100 MHz; diagnostic build only */
+    const int b = (int)blockIdx.x;
+    int tile_x, tile_y;
+    tile_of_block(F, b, (int)gridDim.x, tile_x, tile_y);
+    const int wave = (int)threadIdx.x >> 6;
+    const int lane = (int)threadIdx.x & 63;
+    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int py = F.row0 + pyl;
+    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows;
+
+    Counters k;
+    DiagAcc dg;
+
+    if (valid) {
+        F3 o, d;
+        camera_ray(F, px, py, o, d);
+        k.n_primary = 1;
+        float t_hit = 0.0f;
+        int inst = 0;
+        F3 n = f3(0.0f, 0.0f, 0.0f);
+        F3 color;
+        if (trace_closest<PATH, SINGLE, DIAG>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, k.s_primary, &dg)) {
+            k.n_hits = 1;
+            bool shadowed = false;
+            if (F.shadow && !F.unlit) {
+                k.n_shadow = 1;
+                F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
+                shadowed = trace_any<PATH, SINGLE, DIAG>(F, shadow_origin(o, d, t_hit), ld, 5000.0f, t_hit, k.s_shadow, &dg);
+            }
+            color = shade_hit(F, F.vols + F.inst[inst].slot, d, n, shadowed);
+        } else {
+            color = env_lookup(F.env, F.env_size, d);
+        }
+        store_pixel(F, px, pyl, color);
+    }
+    write_records<DIAG>(F, b, wave, lane, k, dg, t_start);
+}
+
+/* ---- wave-cooperative march through a per-wave LDS brick cache ------------------------------- */
+
+constexpr int kLdsSlots = 8;                 /* bricks cached per wave: any 2x2x2 brick neighbourhood fits */
+constexpr unsigned kTagInvalid = 0xffffffffu;
+
+/*
+ * Sphere-trace with the taps served from LDS.  ALL 64 lanes of the wave call this (wave-uniform
+ * control flow); `active` says which lanes carry a ray.  Each wave owns kLdsSlots brick slots
+ * (512 B each) and their tags.  Per step a lane looks up its brick's slot (direct-mapped on the
+ * low bit of each brick coordinate), reads tag + 8 taps speculatively, and commits them when the
+ * tag matches; lanes that miss vote (__ballot), the first one's brick is fetched by the whole
+ * wave with one coalesced 512-B read (64 lanes x 8 B) into its slot, and the loop re-checks.
+ * LDS operations of one wave execute in order, so no barrier is needed.  The march exits as soon
+ * as no lane is active (__ballot early-out).  Results are bit-identical to the global-memory
+ * paths: the same taps feed the same arithmetic.
+ */
+template <bool DIAG>
+__device__ __forceinline__ bool march_coop(const DFrame& F, const VolRef& V, const RaySeg& R, bool active,
+                                           float* __restrict__ slots, unsigned* __restrict__ tags, int lane, float& t_hit,
+                                           Cell& c_hit, int& iter_hit, unsigned& steps, DiagAcc* dg) {
+    float t = R.t0;
+    bool hit = false;
+    const int max_steps = F.max_steps;
+    const unsigned nb = (unsigned)V.nb;
+    for (int i = 0; i < max_steps; i++) {
+        active = active && !(t > R.t_end);
+        if (__ballot(active) == 0ull) break;
+        unsigned long long st0 = 0, st1 = 0;
+        if constexpr (DIAG) st0 = stamp();
+        const Cell c = cell_at(R, t);
+        const unsigned bx = (unsigned)c.cx >> 2, by = (unsigned)c.cy >> 2, bz = (unsigned)c.cz >> 2;
+        const unsigned tag = (bx & 0xffu) | ((by & 0xffu) << 8) | ((bz & 0xffu) << 16);
+        const unsigned slot = (bx & 1u) | ((by & 1u) << 1) | ((bz & 1u) << 2);
+        const unsigned local = ((unsigned)c.cx & 3u) * 25u + ((unsigned)c.cz & 3u) * 5u + ((unsigned)c.cy & 3u);
+        const float* sp = slots + (slot << 7) + local;
+        if constexpr (DIAG) {
+            asm volatile("" ::"v"(tag), "v"(slot), "v"(local));
+            st1 = stamp();
+        }
+        bool need = active;
+        Taps taps = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (;;) {
+            const unsigned tg = tags[slot];
+            Taps tmp;
+            tmp.y00a = sp[0];
+            tmp.y00b = sp[1];
+            tmp.y01a = sp[5];
+            tmp.y01b = sp[6];
+            tmp.y10a = sp[25];
+            tmp.y10b = sp[26];
+            tmp.y11a = sp[30];
+            tmp.y11b = sp[31];
+            const bool ok = need && tg == tag;
+            if (ok) taps = tmp;
+            need = need && !ok;
+            const unsigned long long m = __ballot(need);
+            if (m == 0ull) break;
+            /* miss: the whole wave fetches the first missing lane's brick */
+            const int leader = __builtin_ctzll(m);
+            const unsigned ltag = __builtin_amdgcn_readlane(tag, leader);
+            const unsigned lbx = ltag & 0xffu, lby = (ltag >> 8) & 0xffu, lbz = (ltag >> 16) & 0xffu;
+            const unsigned lslot = (lbx & 1u) | ((lby & 1u) << 1) | ((lbz & 1u) << 2);
+            const unsigned brick = (lbx * nb + lbz) * nb + lby;
+            const gfloat_p src = (gfloat_p)((gchar_p)V.p + (((size_t)brick << 9) + ((unsigned)lane << 3)));
+            const float v0 = src[0], v1 = src[1];
+            float* dst = slots + (lslot << 7) + ((unsigned)lane << 1);
+            dst[0] = v0;
+            dst[1] = v1;
+            if (lane == 0) tags[lslot] = ltag;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr (DIAG) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(taps.y00a), "v"(taps.y00b), "v"(taps.y01a), "v"(taps.y01b), "v"(taps.y10a),
+                         "v"(taps.y10b), "v"(taps.y11a), "v"(taps.y11b));
+            const unsigned long long st2 = stamp();
+            if (active) {
+                dg->mem += st2 - st1; /* slot lookup (+ fills) until the taps are in registers */
+                dg->iters++;
+                dg->loop += st2 - st0;
+            }
+        }
+        const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
+        if (active) steps++;
+        const bool hit_now = active && s < __builtin_fmaf(t, F.cone_eps, F.eps_hit);
+        if (hit_now) {
+            hit = true;
+            t_hit = t;
+            c_hit = c;
+            iter_hit = i;
+        }
+        active = active && !hit_now;
+        const float adv_min = __builtin_fmaf(t, F.cone_eps, R.base_min);
+        const float t_next = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
+        t = active ? t_next : t;
+    }
+    return hit;
+}
+
+/*
+ * Single-instance kernel on the LDS brick cache (VRT_PATH_BRICK_LDS).  Same tile mapping and
+ * per-pixel arithmetic as march_kernel; the two marches (primary, shadow) run with wave-uniform
+ * control flow so that every lane can take part in brick fills.
+ */
+template <bool DIAG>
+__global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame F) {
+    __shared__ float s_slots[4][kLdsSlots * kBrickFloats];
+    __shared__ unsigned s_tags[4][kLdsSlots];
+    unsigned long long t_start = 0;
+    if constexpr (DIAG) t_start = __builtin_amdgcn_s_memrealtime();
+    const int b = (int)blockIdx.x;
+    int tile_x, tile_y;
+    tile_of_block(F, b, (int)gridDim.x, tile_x, tile_y);
+    const int wave = (int)threadIdx.x >> 6;
+    const int lane = (int)threadIdx.x & 63;
+    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int py = F.row0 + pyl;
+    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows;
+
+    float* slots = s_slots[wave];
+    unsigned* tags = s_tags[wave];
+    if (lane < kLdsSlots) tags[lane] = kTagInvalid;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    Counters k;
+    DiagAcc dg;
+    const DInstance* I = F.inst;
+    const DVolume* Vd = F.vols + I->slot;
+    const VolRef V = load_vol<VRT_PATH_BRICK>(Vd);
+
+    F3 o = f3(0.0f, 0.0f, 0.0f), d = f3(1.0f, 0.0f, 0.0f);
+    RaySeg R = {};
+    bool act = false;
+    if (valid) {
+        camera_ray(F, px, py, o, d);
+        k.n_primary = 1;
+        act = setup_ray(F, I, V, o, d, 10000.0f, 0.0f, R);
+    }
+    float t_hit = 0.0f;
+    Cell c_hit = {0, 0, 0, 0.0f, 0.0f, 0.0f};
+    int iter_hit = 0;
+    const bool hit = march_coop<DIAG>(F, V, R, act, slots, tags, lane, t_hit, c_hit, iter_hit, k.s_primary, &dg);
+
+    F3 n = f3(0.0f, 0.0f, 0.0f);
+    if (hit) {
+        k.n_hits = 1;
+        n = hit_normal<VRT_PATH_BRICK>(I, V, R, c_hit, iter_hit);
+    }
+    bool shadowed = false;
+    const bool want_shadow = hit && F.shadow && !F.unlit;
+    if (__ballot(want_shadow) != 0ull) {
+        RaySeg Rs = {};
+        bool act_s = false;
+        if (want_shadow) {
+            k.n_shadow = 1;
+            F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
+            act_s = setup_ray(F, I, V, shadow_origin(o, d, t_hit), ld, 5000.0f, t_hit, Rs);
+        }
+        float ts = 0.0f;
+        Cell cs = {0, 0, 0, 0.0f, 0.0f, 0.0f};
+        int is = 0;
+        shadowed = march_coop<DIAG>(F, V, Rs, act_s, slots, tags, lane, ts, cs, is, k.s_shadow, &dg);
+    }
+    if (valid) {
+        F3 color = hit ? shade_hit(F, Vd, d, n, shadowed) : env_lookup(F.env, F.env_size, d);
+        store_pixel(F, px, pyl, color);
+    }
+    write_records<DIAG>(F, b, wave, lane, k, dg, t_start);
 }
 
 /* dense N^3 grid → 4^3-cell bricks with a one-sample apron (5^3 samples, padded to 128 floats). */
@@ -631,7 +871,18 @@ static hipError_t launch_t(const DFrame& F, hipStream_t stream) {
     return hipGetLastError();
 }
 
+static hipError_t launch_coop(const DFrame& F, hipStream_t stream) {
+    const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
+    if (grid <= 0) return hipSuccess;
+    if (F.diag)
+        hipLaunchKernelGGL((march_kernel_coop<true>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
+    else
+        hipLaunchKernelGGL((march_kernel_coop<false>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
+    return hipGetLastError();
+}
+
 hipError_t launch_march(const DFrame& F, int path, bool single, hipStream_t stream) {
+    if (path == VRT_PATH_BRICK_LDS && single) return launch_coop(F, stream);
     if (path == VRT_PATH_DENSE) return single ? launch_t<VRT_PATH_DENSE, true>(F, stream) : launch_t<VRT_PATH_DENSE, false>(F, stream);
     return single ? launch_t<VRT_PATH_BRICK, true>(F, stream) : launch_t<VRT_PATH_BRICK, false>(F, stream);
 }
