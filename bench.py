@@ -32,7 +32,7 @@ def build_workload(name: str):
 
     if name == "c3":
         sc = scenes.bench_config3()
-        return sc, 1920, 1080, 255, True, "config3: 256^3 volume, 1920x1080, shadow ray on"
+        return sc, 1920, 1080, 255, True, "config3: 256^3 voxelized glTF-style mesh (torus, 16384 triangles), 1920x1080, shadow ray on"
     if name == "c3sdf":
         sc = scenes.config3_torus(8, 256, distance=190.0)
         return sc, 1920, 1080, 255, True, "config3 (analytic SDF variant): 256^3 torus SDF, 1920x1080, shadow ray on"
@@ -41,7 +41,7 @@ def build_workload(name: str):
         return sc, 1280, 720, 128, False, "config2: 64^3 SDF sphere, 1280x720, 128 max steps"
     if name == "c4":
         sc = scenes.bench_config3()
-        return sc, 3840, 2160, 255, True, "config4: 256^3 volume, 3840x2160, row tiles + RCCL gather"
+        return sc, 3840, 2160, 255, True, "config4: 256^3 voxelized mesh, 3840x2160, row tiles + RCCL gather"
     if name == "c5":
         sc = scenes.config5_instances(7, 256)
         return sc, 1920, 1080, 255, True, "config5: 8 instanced 128^3 volumes + skybox, 1920x1080, AABB BVH"

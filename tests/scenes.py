@@ -53,6 +53,34 @@ def min_cell(scene: v.VScene) -> float:
     return min(vol.GetCellSize() for vol in scene.volumes())
 
 
+def voxelized_torus(resolution: int = 8, material=None) -> v.VVoxelVolume:
+    """A procedural UV-torus triangle mesh (128 x 64 quads, seedless) run through the build's C++
+    Voxelizer at `_<resolution>` — the stand-in for the reference's missing Monkey.vox.
+    The result is the Voxelizer's unsigned shell field (density_scale = thr, step_max = thr/2)."""
+    from volumetricraytracer_amd import voxelizer as vx
+
+    pos, nrm, idx = vx.torus_mesh(0.55, 0.22, 128, 64)
+    p, be = vx.importer_space(pos)
+    return vx.convert_mesh(p, idx, be, f"torus_{resolution}", material or v.VMaterial((0.8, 0.6, 0.2, 1.0), 0.8, 0.0))
+
+
+def config3_voxelized(resolution: int = 8, env: int = 256, distance: float = 195.0) -> v.VScene:
+    """BASELINE config 3: voxelized mesh at 2^resolution cells, demo light, shadow ray meaningful."""
+    vol = voxelized_torus(resolution)
+    cam = v.VCamera(Position=(distance * math.cos(math.radians(35.0)), 0.0, distance * math.sin(math.radians(35.0))),
+                    Rotation=tuple(v.quat_mul(v.quat_from_axis_angle(v.UP, math.pi),
+                                              v.quat_from_axis_angle(v.RIGHT, math.radians(35.0)))),
+                    FOVAngle=60.0)
+    return v.VScene(Camera=cam, DirectionalLight=v.demo_light(), Objects=[v.VVoxelObject(Volume=vol)],
+                    EnvironmentMap=v.procedural_skybox(env))
+
+
+_bench_c3 = None
+
+
 def bench_config3() -> v.VScene:
-    """bench.py workload for BASELINE config 3 (1080p, 256^3 volume, shadow ray on)."""
-    return config3_torus(8, 256, distance=190.0)
+    """bench.py workload for BASELINE config 3 (1080p, 256^3 voxelized mesh, shadow ray on)."""
+    global _bench_c3
+    if _bench_c3 is None:
+        _bench_c3 = config3_voxelized(8, 256)
+    return _bench_c3

@@ -1,0 +1,172 @@
+"""BASELINE config 1 (CPU plumbing): glTF unit cube -> 32^3 SDF voxel volume through the C++
+Voxelizer restatement, the `.vox` scene format, and the C++ <-> Python reader/writer cross-check.
+
+The reference ships no fixtures for this path: the expectations are analytic and follow from
+VolumeConverter.cpp:32-33,51-57,200-202 and GLTFImporter.cpp:56-63."""
+import math
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import volumetricraytracer_amd as v
+from volumetricraytracer_amd import vox_io
+from volumetricraytracer_amd import voxelizer as vx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VOXELIZER = os.path.join(ROOT, "volumetricraytracer_amd", "lib", "voxelizer")
+
+
+@pytest.fixture(scope="module")
+def cube_volume():
+    pos, nrm, idx = vx.cube_mesh(0.5)
+    p, be = vx.importer_space(pos)
+    assert np.allclose(be, 55.0)  # half size 50 + 5
+    return vx.convert_mesh(p, idx, be, "cube_5")
+
+
+def test_cube_volume_geometry(cube_volume):
+    vol = cube_volume
+    # resolution from the "_5" suffix, N = 33, extent = 55 * 1.25, cell = 2*extent/32, thr = cell*sqrt(3)
+    assert (vol.Resolution, vol.N) == (5, 33)
+    assert vol.VolumeExtends == pytest.approx(68.75)
+    assert vol.GetCellSize() == pytest.approx(4.296875)
+    assert vol.density_scale == pytest.approx(4.296875 * math.sqrt(3.0), rel=1e-6)
+    assert vol.step_max == pytest.approx(0.5 * vol.density_scale)
+
+
+def test_cube_densities_match_point_triangle_distance(cube_volume):
+    vol = cube_volume
+    thr = np.float32(vol.density_scale)
+    p = vol.axis_positions().astype(np.float64)
+    X, Z, Y = np.meshgrid(p, p, p, indexing="ij")  # density axes are (x, z, y)
+    # exact unsigned distance to the surface of the cube [-50,50]^3
+    q = np.stack([np.abs(X) - 50.0, np.abs(Y) - 50.0, np.abs(Z) - 50.0], -1)
+    outside = np.linalg.norm(np.maximum(q, 0.0), axis=-1)
+    inside = np.minimum(q.max(-1), 0.0)
+    dist = np.abs(outside + inside)
+    expect = dist / thr - 0.5
+    # a voxel closer than thr to the mesh holds exactly dist/thr - 0.5 (it lies inside the index box of
+    # its nearest triangle); the shell is unsigned: the same value either side of a face
+    near = dist < thr * 0.999
+    assert near.sum() > 3000
+    assert np.abs(vol.density[near] - expect[near]).max() < 2e-5
+    assert (vol.density[near] < 0.5).all()
+    # everything else is either another triangle's (larger) distance or the untouched background 2*extent
+    far = ~near
+    assert (vol.density[far] >= 0.5 - 1e-5).all()
+    corner = vol.density[0, 0, 0]
+    assert corner == pytest.approx(2 * 68.75) or corner >= 0.5
+    assert (vol.density == np.float32(137.5)).sum() > 0  # voxels outside every triangle's box
+    # material flag = density <= 0 (VolumeConverter.cpp:244)
+    touched = vol.density < 137.0
+    assert np.array_equal(vol.material_id[touched] == 1, vol.density[touched] <= 0)
+
+
+def test_resolution_suffix_rules():
+    pos, nrm, idx = vx.cube_mesh(0.5)
+    p, be = vx.importer_space(pos)
+    assert vx.convert_mesh(p, idx, be, "cube_3").N == 9
+    assert vx.convert_mesh(p, idx, be, "cube").N == 33            # no suffix -> 5
+    assert vx.convert_mesh(p, idx, be, "cube_x").N == 33          # not a number -> 5
+    assert vx.convert_mesh(p, idx, be, "cube_9").N == 33          # > 8 -> 5
+    assert vx.convert_mesh(p, idx, be, "a_b_4").N == 17           # last underscore wins
+
+
+def test_degenerate_and_ragged_input_is_tolerated():
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [2, 2, 2]], np.float32)
+    idx = np.array([0, 1, 2, 3, 3, 3, 0, 1], np.uint32)  # one good triangle, one zero-area, two dangling indices
+    p, be = vx.importer_space(pos)
+    vol = vx.convert_mesh(p, idx, be, "tri_4")
+    assert (vol.density < 0).sum() > 0 and np.isfinite(vol.density).all()
+    empty = vx.convert_mesh(p, np.zeros(0, np.uint32), be, "none_4")
+    assert (empty.density == empty.density[0, 0, 0]).all()
+
+
+def test_gltf_to_vox_cli_and_roundtrip(tmp_path):
+    pos, nrm, idx = vx.cube_mesh(0.5)
+    gltf = str(tmp_path / "scene.gltf")
+    yaw = v.quat_from_axis_angle(v.UP, math.radians(30.0))
+    nodes = [
+        {"name": "Cube", "mesh": 0, "translation": [1.0, 2.0, 3.0], "rotation": [float(x) for x in yaw], "scale": [1.0, 2.0, 0.5]},
+        {"name": "Light_Sun", "rotation": [0.0, 0.0, 0.0, 1.0], "extras": {"strength": 6.0, "color_r": 1.0, "color_g": 0.9, "color_b": 0.8}},
+        {"name": "Light_Point", "translation": [0.5, 0.0, 1.0], "extras": {"strength": 40.0, "attl": 0.25, "attexp": 0.01}},
+        {"name": "Light_Spot", "translation": [0.0, 1.0, 1.0], "extras": {"strength": 30.0, "fangle": 15.0, "angle": 50.0}},
+        {"name": "Empty"},
+    ]
+    mats = [{"name": "paint", "pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.4, 0.6, 1.0], "metallicFactor": 0.3, "roughnessFactor": 0.7}}]
+    vx.write_gltf(gltf, [("cube_5", pos, nrm, idx, 0)], nodes, mats)
+    assert os.path.exists(VOXELIZER), "run __graft_entry__.build()"
+    r = subprocess.run([VOXELIZER, gltf], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = str(tmp_path / "scene.vox")
+    assert os.path.exists(out) and "Exported voxelized scene" in r.stdout
+
+    sc = vox_io.load_scene(out)  # Python reader on the C++ writer's file
+    assert len(sc.volumes()) == 1 and len(sc.Objects) == 1
+    vol = sc.volumes()[0]
+    assert (vol.Resolution, vol.N) == (5, 33) and vol.VolumeExtends == pytest.approx(68.75)
+    assert np.allclose(vol.Material.AlbedoColor, [0.2, 0.4, 0.6, 1.0]) and vol.Material.Roughness == pytest.approx(0.7)
+    assert vol.Material.Metallic == pytest.approx(0.3)
+    o = sc.Objects[0]
+    assert np.allclose(o.Position, [100, 200, 300]) and np.allclose(o.Scale, [1, 2, 0.5]) and np.allclose(o.Rotation, yaw, atol=1e-6)
+    assert sc.DirectionalLight.IlluminationStrength == 6.0 and np.allclose(sc.DirectionalLight.Color, [1, 0.9, 0.8, 1])
+    assert len(sc.PointLights) == 1 and sc.PointLights[0].AttenuationLinear == 0.25 and np.allclose(sc.PointLights[0].Position, [50, 0, 100])
+    assert len(sc.SpotLights) == 1 and sc.SpotLights[0].FalloffAngle == 15.0 and sc.SpotLights[0].Angle == 50.0
+    # same volume as the in-memory conversion
+    p, be = vx.importer_space(pos)
+    ref = vx.convert_mesh(p, idx, be, "cube_5")
+    assert np.array_equal(ref.density, vol.density) and np.array_equal(ref.material_id, vol.material_id)
+
+    # C++ reader + writer reproduce the file bit for bit; so does the Python writer on the Python-read scene
+    again = str(tmp_path / "again.vox")
+    vx.vox_rewrite(out, again)
+    assert open(out, "rb").read() == open(again, "rb").read()
+    py = str(tmp_path / "py.vox")
+    vox_io.save_scene(sc, py)
+    back = str(tmp_path / "back.vox")
+    vx.vox_rewrite(py, back)  # C++ reader on the Python writer's file
+    sc2 = vox_io.load_scene(back)
+    assert np.array_equal(sc2.volumes()[0].density, vol.density)
+    assert np.allclose(sc2.Objects[0].Rotation, o.Rotation) and sc2.SpotLights[0].Angle == 50.0
+
+    # embedded (data: URI) buffers give the same result
+    gltf2 = str(tmp_path / "embedded.gltf")
+    vx.write_gltf(gltf2, [("cube_5", pos, nrm, idx, 0)], nodes, mats, embed=True)
+    out2 = vx.voxelize_file(gltf2)
+    assert np.array_equal(vox_io.load_scene(out2).volumes()[0].density, vol.density)
+
+
+def test_vox_reader_is_order_agnostic_and_rejects_garbage(tmp_path):
+    # property order on disk is hash-map order in the reference: write a volume archive in reverse order
+    vol = v.sphere_volume(2, 10.0, 4.0, v.VMaterial((0.1, 0.2, 0.3, 1.0), 0.5, 0.25))
+    sc = v.VScene(Objects=[v.VVoxelObject(Position=(1, 2, 3), Volume=vol)])
+    sorted_path = str(tmp_path / "sorted.vox")
+    vox_io.save_scene(sc, sorted_path)
+    root = vox_io.read_archive(sorted_path)
+    path = str(tmp_path / "rev.vox")
+    with open(path, "wb") as f:  # hand-rolled writer emitting properties in reverse-sorted order
+        def w(ar):
+            f.write(struct.pack("<Q", len(ar.buffer)) + ar.buffer + struct.pack("<Q", len(ar.props)))
+            for k in sorted(ar.props, reverse=True):
+                raw = k.encode() + b"\0"
+                f.write(struct.pack("<Q", len(raw)) + raw)
+                w(ar.props[k])
+        w(root)
+    assert open(path, "rb").read() != open(sorted_path, "rb").read()
+    out = str(tmp_path / "norm.vox")
+    vx.vox_rewrite(path, out)  # the C++ reader copes with any order, its writer sorts again
+    got = vox_io.load_scene(out)
+    assert np.array_equal(got.volumes()[0].density, vol.density) and got.volumes()[0].Material.Metallic == pytest.approx(0.25)
+    assert np.allclose(got.Objects[0].Position, [1, 2, 3])
+    assert np.array_equal(vox_io.load_scene(path).volumes()[0].density, vol.density)  # and so does the Python reader
+    bad = str(tmp_path / "bad.vox")
+    open(bad, "wb").write(b"\xff" * 64)
+    with pytest.raises(RuntimeError):
+        vx.vox_rewrite(bad, out)
+    with pytest.raises(Exception):
+        vox_io.load_scene(bad)
+    with pytest.raises(RuntimeError):
+        vx.voxelize_file(str(tmp_path / "missing.gltf"))

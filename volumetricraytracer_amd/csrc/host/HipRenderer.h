@@ -1,0 +1,57 @@
+/*
+ * HipRenderer.h — `VRenderer` for MI355X: the sibling of the reference's Renderer/DX backend
+ * (VDXRenderer, Renderer/DX/Public/DXRenderer.h:120-257).  It owns a vrt_ctx (include/vrt.h) and
+ * does on the host what VRDXScene did: mirror the VScene into the C-ABI's flat structs every
+ * frame (volumes only when dirty), then render.  There is no swap chain on a headless node: the
+ * frame lands in a host float RGBA buffer the caller can read (GetFrame) — the backend-specific
+ * part, like VDXRenderer::SetWindowHandle was.
+ *
+ * Error convention of the reference: Start() returns bool, everything else logs and returns.
+ */
+#pragma once
+#include <vector>
+#include "../../../include/vrt.h"
+#include "HostRenderer.h"
+
+namespace VolumeRaytracer {
+namespace Renderer {
+namespace Hip {
+
+class VHipRenderer : public VRenderer {
+public:
+    VHipRenderer();
+    ~VHipRenderer() override;
+
+    void Render() override;
+    bool Start() override;
+    void Stop() override;
+    bool IsActive() const override { return Ctx != nullptr; }
+    void InitializeTexture(VObjectPtr<VTextureCube> texture) override;
+    void UploadToGPU(VObjectPtr<VTextureCube> texture) override;
+    void ResizeRenderOutput(unsigned int width, unsigned int height) override;
+
+    /* backend-specific */
+    void SetDevices(const std::vector<int>& hipOrdinals) { Devices = hipOrdinals; } /* before Start(); default {0} */
+    const std::vector<float>& GetFrame() const { return Frame; }                     /* Width*Height RGBA */
+    unsigned GetWidth() const { return Width; }
+    unsigned GetHeight() const { return Height; }
+    bool GetLastTiming(vrt_timing& out) const;
+    /* march contract knobs; defaults follow the smallest cell of the scene */
+    int MaxSteps = 255;       /* Raytracing.hlsl:229 */
+    bool Shadows = true;      /* the reference always casts the directional shadow ray */
+    int DataPath = VRT_PATH_AUTO;
+
+private:
+    bool SyncWithScene(Scene::VScene& scene);
+    vrt_ctx* Ctx = nullptr;
+    std::vector<int> Devices{0};
+    unsigned Width = 1024, Height = 576; /* Win32Window.cpp:218-219 */
+    std::vector<float> Frame;
+    std::vector<const Voxel::VVoxelVolume*> Uploaded; /* per slot */
+    const VTextureCube* UploadedEnv = nullptr;
+    float MinCell = 1.f;
+};
+
+}  // namespace Hip
+}  // namespace Renderer
+}  // namespace VolumeRaytracer

@@ -1,0 +1,146 @@
+/*
+ * HostScene.h — scene graph types the renderer consumes, restated without VObject / boost /
+ * tick-manager machinery (out of scope: interactive editing).  What is kept:
+ * the object/volume/light model, spawn semantics, the active camera / directional light, the
+ * environment cube map, and change detection (volume dirty flags + a scene revision counter in
+ * place of the per-frame add/remove sets, Scene.cpp:265-300).
+ *
+ * Reference (relative to /root/reference/VolumetricRaytracer/VolumetricRaytracer/Scene/):
+ *   Public/LevelObject.h:28-52, Public/VoxelObject.h, Public/Camera.h:23-33, Public/Light.h:22-40,
+ *   Public/PointLight.h:22-32, Public/SpotLight.h:22-35, Public/Scene.h:52-161,
+ *   serialisation Private/Scene.cpp:314-544, Private/VoxelObject.cpp:37-71, Private/Light.cpp:17-57.
+ */
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+#include "HostCore.h"
+#include "HostVoxel.h"
+
+namespace VolumeRaytracer {
+
+template <typename T> using VObjectPtr = std::shared_ptr<T>;
+
+/* VTextureCube reduced to what the miss shader reads: 6 faces (+X,-X,+Y,-Y,+Z,-Z) of RGBA8. */
+class VTextureCube {
+public:
+    VTextureCube(size_t faceSize, std::vector<uint8_t> rgba8) : Width(faceSize), Height(faceSize), Pixels(std::move(rgba8)) {}
+    size_t GetWidth() const { return Width; }
+    size_t GetHeight() const { return Height; }
+    size_t GetArraySize() const { return 6; }
+    const std::vector<uint8_t>& GetPixels() const { return Pixels; }
+
+private:
+    size_t Width, Height;
+    std::vector<uint8_t> Pixels;
+};
+
+namespace Scene {
+
+class VScene;
+
+class VLevelObject {
+public:
+    virtual ~VLevelObject() = default;
+    VVector Position = VVector::ZERO;
+    VQuat Rotation = VQuat::IDENTITY;
+    VVector Scale = VVector::ZERO; /* LevelObject.h:50 — SpawnObject always overwrites it */
+};
+
+class VVoxelObject : public VLevelObject {
+public:
+    void SetVoxelVolume(VObjectPtr<Voxel::VVoxelVolume> volume) { VoxelVolume = std::move(volume); }
+    VObjectPtr<Voxel::VVoxelVolume> GetVoxelVolume() const { return VoxelVolume; }
+
+private:
+    VObjectPtr<Voxel::VVoxelVolume> VoxelVolume;
+};
+
+class VCamera : public VLevelObject {
+public:
+    float FOVAngle = 60.f;
+    float NearClipPlane = 0.01f;
+    float FarClipPlane = 125.f;
+    float AspectRatio = 1.7777f;
+};
+
+class VLight : public VLevelObject {
+public:
+    float IlluminationStrength = 1.f;
+    VColor Color = VColor::WHITE;
+};
+
+class VPointLight : public VLight {
+public:
+    float AttenuationLinear = 0.5f;
+    float AttenuationExp = 0.005f;
+};
+
+class VSpotLight : public VLight {
+public:
+    float AttenuationLinear = 0.5f;
+    float AttenuationExp = 0.005f;
+    float FalloffAngle = 20.f;
+    float Angle = 45.f;
+};
+
+class VScene : public std::enable_shared_from_this<VScene> {
+public:
+    template <typename T, class... Args>
+    VObjectPtr<T> SpawnObject(const VVector& location, const VQuat& rotation, const VVector& scale, Args&&... args) {
+        static_assert(std::is_base_of<VLevelObject, T>::value, "T must inherit from VLevelObject");
+        VObjectPtr<T> obj = std::make_shared<T>(std::forward<Args>(args)...);
+        obj->Position = location;
+        obj->Rotation = rotation;
+        obj->Scale = scale;
+        PlacedObjects.push_back(obj);
+        Revision++;
+        return obj;
+    }
+    void DestroyObject(const VObjectPtr<VLevelObject>& obj) {
+        for (size_t i = 0; i < PlacedObjects.size(); i++)
+            if (PlacedObjects[i] == obj) {
+                PlacedObjects.erase(PlacedObjects.begin() + (long)i);
+                Revision++;
+                return;
+            }
+    }
+    void SetEnvironmentTexture(VObjectPtr<VTextureCube> texture) {
+        EnvironmentTexture = std::move(texture);
+        Revision++;
+    }
+    VObjectPtr<VTextureCube> GetEnvironmentTexture() const { return EnvironmentTexture; }
+    void SetActiveSceneCamera(std::weak_ptr<VCamera> camera) { ActiveCamera = std::move(camera); }
+    void SetActiveDirectionalLight(std::weak_ptr<VLight> light) { ActiveDirectionalLight = std::move(light); }
+    VObjectPtr<VCamera> GetActiveCamera() const { return ActiveCamera.lock(); }
+    VObjectPtr<VLight> GetActiveDirectionalLight() const { return ActiveDirectionalLight.lock(); }
+    const std::vector<VObjectPtr<VLevelObject>>& GetAllPlacedObjects() const { return PlacedObjects; }
+    /* distinct volumes in first-use order (the index is the renderer's volume slot) */
+    std::vector<VObjectPtr<Voxel::VVoxelVolume>> GetAllRegisteredVolumes() const {
+        std::vector<VObjectPtr<Voxel::VVoxelVolume>> out;
+        for (const auto& o : PlacedObjects) {
+            auto vo = std::dynamic_pointer_cast<VVoxelObject>(o);
+            if (!vo || !vo->GetVoxelVolume()) continue;
+            bool seen = false;
+            for (const auto& v : out) seen = seen || v == vo->GetVoxelVolume();
+            if (!seen) out.push_back(vo->GetVoxelVolume());
+        }
+        return out;
+    }
+    void PostRender() { /* Scene.cpp:568-576 clears the frame diffs; volumes clear their dirty flags */
+        for (const auto& v : GetAllRegisteredVolumes()) v->PostRender();
+    }
+    uint64_t GetRevision() const { return Revision; }
+    void Touch() { Revision++; } /* call after moving objects / lights between frames */
+
+private:
+    std::vector<VObjectPtr<VLevelObject>> PlacedObjects;
+    std::weak_ptr<VCamera> ActiveCamera;
+    std::weak_ptr<VLight> ActiveDirectionalLight;
+    VObjectPtr<VTextureCube> EnvironmentTexture;
+    uint64_t Revision = 0;
+};
+
+}  // namespace Scene
+}  // namespace VolumeRaytracer

@@ -1,0 +1,105 @@
+/* host_c_api.cpp — C entry points of libvrt_host.so for the Python tests / bench (ctypes): the
+ * Voxelizer on in-memory meshes and on .gltf files, and a .vox rewrite through the C++ reader and
+ * writer.  Not part of the renderer boundary (that is include/vrt.h). */
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "../../../include/vrt.h"
+#include "HostSerialization.h"
+#include "SceneConverter.h"
+#include "VolumeConverter.h"
+
+using namespace VolumeRaytracer;
+
+namespace {
+thread_local std::string g_error;
+struct VolumeHandle {
+    std::shared_ptr<Voxel::VVoxelVolume> volume;
+};
+}  // namespace
+
+extern "C" {
+
+const char* vrh_last_error(void) { return g_error.c_str(); }
+
+/* ConvertMeshInfoToVoxelVolume on caller arrays.  positions: n_vertices*3 floats, already in the
+ * importer's output space (x100, re-centred); bounds_extends: VMeshInfo::Bounds extents. */
+void* vrh_convert_mesh(const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_indices,
+                       const float bounds_extends[3], const char* mesh_name) {
+    try {
+        Voxelizer::VMeshInfo info;
+        info.MeshName = mesh_name ? mesh_name : "";
+        info.Vertices.resize(n_vertices);
+        for (size_t i = 0; i < n_vertices; i++) info.Vertices[i].Position = VVector(positions[i * 3], positions[i * 3 + 1], positions[i * 3 + 2]);
+        info.Indices.assign(indices, indices + n_indices);
+        info.Bounds = VAABB(VVector::ZERO, VVector(bounds_extends[0], bounds_extends[1], bounds_extends[2]));
+        auto* h = new VolumeHandle;
+        h->volume = Voxelizer::VVolumeConverter::ConvertMeshInfoToVoxelVolume(info, Voxelizer::VTextureLibrary());
+        return h;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return nullptr;
+    }
+}
+
+int vrh_volume_info(void* handle, int* resolution, int* size, float* extent, float* cell, float* density_scale, float* step_max) {
+    if (!handle) return -1;
+    const auto& v = *static_cast<VolumeHandle*>(handle)->volume;
+    if (resolution) *resolution = v.GetResolution();
+    if (size) *size = (int)v.GetSize();
+    if (extent) *extent = v.GetVolumeExtends();
+    if (cell) *cell = v.GetCellSize();
+    if (density_scale) *density_scale = v.DensityScale;
+    if (step_max) *step_max = v.StepMax;
+    return 0;
+}
+
+int vrh_volume_copy_voxels(void* handle, vrt_voxel* out) {
+    if (!handle || !out) return -1;
+    const auto& vox = static_cast<VolumeHandle*>(handle)->volume->GetVoxels();
+    for (size_t i = 0; i < vox.size(); i++) {
+        memset(&out[i], 0, sizeof(vrt_voxel));
+        out[i].material = vox[i].Material;
+        out[i].density = vox[i].Density;
+    }
+    return 0;
+}
+
+void vrh_volume_free(void* handle) { delete static_cast<VolumeHandle*>(handle); }
+
+/* The Voxelizer executable as a function; out_path receives the written file name. */
+int vrh_voxelize_file(const char* gltf_path, const char* texlib_or_null, const char* out_or_null, char* out_path, size_t out_path_len) {
+    try {
+        const std::string out = Voxelizer::VoxelizeFile(gltf_path, texlib_or_null ? texlib_or_null : "", out_or_null ? out_or_null : "");
+        if (out_path && out_path_len) {
+            strncpy(out_path, out.c_str(), out_path_len - 1);
+            out_path[out_path_len - 1] = '\0';
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
+    }
+}
+
+/* Load a .vox scene with the C++ reader and write it back with the C++ writer. */
+int vrh_vox_rewrite(const char* in_path, const char* out_path) {
+    try {
+        auto scene = VSerializationManager::LoadSceneFromFile(in_path);
+        if (!scene) {
+            g_error = std::string("cannot open ") + in_path;
+            return -1;
+        }
+        if (!VSerializationManager::SaveToFile(*scene, out_path)) {
+            g_error = std::string("cannot write ") + out_path;
+            return -1;
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
+    }
+}
+
+}  // extern "C"

@@ -322,13 +322,15 @@ class VLight(VLevelObject):
 
 @dataclass
 class VPointLight(VLight):
-    AttenuationLinear: float = 0.0
-    AttenuationExp: float = 0.0
+    AttenuationLinear: float = 0.5    # PointLight.h:26-27
+    AttenuationExp: float = 0.005
 
 
 @dataclass
-class VSpotLight(VPointLight):
-    FalloffAngle: float = 30.0
+class VSpotLight(VLight):
+    AttenuationLinear: float = 0.5    # SpotLight.h:26-29
+    AttenuationExp: float = 0.005
+    FalloffAngle: float = 20.0
     Angle: float = 45.0
 
 
