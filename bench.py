@@ -91,13 +91,10 @@ def main() -> None:
     r.ResizeRenderOutput(W, H)
     r.SyncWithScene()
 
-    rows_per = (H + world - 1) // world
-    row0 = min(rank * rows_per, H)
-    rows = max(0, min(rows_per, H - row0))
-    tiles = [torch.zeros((rows_per, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
-    frames = None
-    if world > 1 and rank == 0:
-        frames = [torch.empty((world * rows_per, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+    from volumetricraytracer_amd.tiles import FrameGather
+
+    fg = FrameGather(H, W, world, rank, dev, buffers=2)  # row tile of this rank + (rank 0) the gathered frames
+    row0, rows = fg.row0, fg.rows
     pending = [None, None]
     stream = torch.cuda.current_stream()
 
@@ -106,10 +103,9 @@ def main() -> None:
         if pending[b] is not None:
             pending[b].wait()  # tile buffer b is free again (its gather finished)
             pending[b] = None
-        r.render_rows(p, row0, rows, tiles[b].data_ptr(), stream.cuda_stream)
+        r.render_rows(p, row0, rows, fg.tiles[b].data_ptr(), stream.cuda_stream)
         if world > 1:
-            glist = [frames[b][k * rows_per:(k + 1) * rows_per] for k in range(world)] if rank == 0 else None
-            pending[b] = dist.gather(tiles[b], glist, dst=0, async_op=True)
+            pending[b] = fg.gather(b, async_op=True)  # RCCL gather over xGMI, overlaps the next frame's march
 
     def drain() -> None:
         for b in range(2):
