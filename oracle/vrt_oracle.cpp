@@ -30,6 +30,7 @@
 #include <limits>
 #include <thread>
 #include <vector>
+#include <cstdint>
 
 namespace {
 
@@ -118,6 +119,11 @@ struct Volume {
     int N;
     float extent, cell, inv_cell, density_scale, step_max;
     float tint[3], roughness, metallic, k;
+    /* empty-space table of volumes with a bounded step (step_max finite): per 4^3-cell brick the
+       Chebyshev distance, in bricks, to the nearest brick that holds a sample closer than step_max
+       to the surface (capped at 255).  Empty: no leaping. */
+    int nb = 0;
+    std::vector<uint8_t> skip;
 };
 
 struct Instance {
@@ -156,6 +162,65 @@ Instance build_instance(const vrt_instance& in) {
     return r;
 }
 
+/*
+ * Empty-space table (restates, for the sphere-trace, what the reference's collapsed octree did for
+ * its DDA: Voxel/Private/Octree.cpp:70-107,181-262 merges cells without surface).  A brick is
+ * "near" when any of its 5^3 samples satisfies density*density_scale < step_max, i.e. holds a
+ * trustworthy distance below the clamp.  D[b] = Chebyshev distance in bricks from b to the nearest
+ * near brick.  From any point of a brick with D >= 2 the ray may advance (D-1) brick edges: that
+ * cannot reach a near brick, and the interpolant is below the clamp only inside near bricks.
+ */
+void build_skip_table(Volume& v) {
+    const int nb = v.nb, N = v.N;
+    std::vector<uint8_t> cur((size_t)nb * nb * nb, 255);
+    for (int bx = 0; bx < nb; bx++)
+        for (int bz = 0; bz < nb; bz++)
+            for (int by = 0; by < nb; by++) {
+                bool near = false;
+                for (int lx = 0; lx < 5 && !near; lx++)
+                    for (int lz = 0; lz < 5 && !near; lz++)
+                        for (int ly = 0; ly < 5 && !near; ly++) {
+                            int x = bx * 4 + lx, y = by * 4 + ly, z = bz * 4 + lz;
+                            x = x > N - 1 ? N - 1 : x;
+                            y = y > N - 1 ? N - 1 : y;
+                            z = z > N - 1 ? N - 1 : z;
+                            near = v.den[((size_t)x * N + z) * N + y] * v.density_scale < v.step_max;
+                        }
+                if (near) cur[((size_t)bx * nb + bz) * nb + by] = 0;
+            }
+    /* exact Chebyshev distance transform: three separable passes of a 1-D "distance to the nearest
+       zero, but as a max-combination" do not apply to Chebyshev balls, so dilate instead: D = k for
+       the bricks first covered by the k-th 3x3x3 dilation of the near set. */
+    std::vector<uint8_t> nxt(cur.size());
+    for (int k = 1; k < 255; k++) {
+        bool changed = false;
+        for (int bx = 0; bx < nb; bx++)
+            for (int bz = 0; bz < nb; bz++)
+                for (int by = 0; by < nb; by++) {
+                    const size_t i = ((size_t)bx * nb + bz) * nb + by;
+                    uint8_t d = cur[i];
+                    if (d == 255) {
+                        bool hit = false;
+                        for (int dx = -1; dx <= 1 && !hit; dx++)
+                            for (int dz = -1; dz <= 1 && !hit; dz++)
+                                for (int dy = -1; dy <= 1 && !hit; dy++) {
+                                    int x = bx + dx, y = by + dy, z = bz + dz;
+                                    if (x < 0 || y < 0 || z < 0 || x >= nb || y >= nb || z >= nb) continue;
+                                    hit = cur[((size_t)x * nb + z) * nb + y] == (uint8_t)(k - 1);
+                                }
+                        if (hit) {
+                            d = (uint8_t)k;
+                            changed = true;
+                        }
+                    }
+                    nxt[i] = d;
+                }
+        cur.swap(nxt);
+        if (!changed) break;
+    }
+    v.skip.swap(cur);
+}
+
 bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env, int env_size,
           const vrt_params* prm, Packed& P) {
     if (!scene || !volumes || !prm) return false;
@@ -180,6 +245,9 @@ bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env
         v.metallic = minf(maxf(s.material.metallic, 0.0f), 1.0f);
         float r1 = s.material.roughness + 1.0f;
         v.k = (r1 * r1) / 8.0f; /* RDXVoxelVolume.cpp:383, from the unclamped roughness */
+        v.nb = (v.N - 1 + 3) / 4;
+        v.skip.clear();
+        if (s.step_max > 0.0f) build_skip_table(v);
     }
     P.n_inst = scene->n_instances;
     for (int i = 0; i < P.n_inst; i++) {
@@ -267,6 +335,7 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
     /* smallest step: one pixel-footprint radius at the total path length t_base + t (t_base = length of
        the path that led to this ray's origin: 0 for camera rays, the hit distance for shadow rays) */
     const float base_min = fmaf(t_base, P.prm.cone_eps, P.prm.step_min);
+    const float leap_unit = (4.0f * V.cell) * inv_len; /* one brick edge in ray-parameter units */
     for (int i = 0; i < P.prm.max_steps; i++) {
         if (t > t_end) return false;
         float ux = fmaf(ud.x, t, uo.x), uy = fmaf(ud.y, t, uo.y), uz = fmaf(ud.z, t, uo.z);
@@ -308,11 +377,14 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
             }
             return true;
         }
-        float adv = s * P.prm.k_relax;
-        adv = adv > smax ? smax : adv;
         float adv_min = fmaf(t, P.prm.cone_eps, base_min);
-        adv = adv < adv_min ? adv_min : adv;
-        t = t + adv;
+        if (!V.skip.empty()) {
+            /* empty-space leap: (D-1) brick edges from a brick whose nearest near brick is D away */
+            const int d = V.skip[((size_t)(cx >> 2) * V.nb + (size_t)(cz >> 2)) * V.nb + (size_t)(cy >> 2)];
+            const float leap = (float)(d > 1 ? d - 1 : 0) * leap_unit;
+            adv_min = fmaxf(adv_min, leap);
+        }
+        t = t + fmaxf(fminf(s * P.prm.k_relax, smax), adv_min);
     }
     return false;
 }

@@ -44,6 +44,8 @@ struct DeviceVolume {
     float* dense = nullptr;
     float* bricks = nullptr;
     uint8_t* material = nullptr;
+    uint8_t* skip = nullptr;      /* 2 x nb^3 bytes: the empty-space table and its build scratch */
+    bool skip_valid = false;      /* table built for the current metric (only when step_max > 0) */
 };
 
 struct DeviceState {
@@ -264,6 +266,24 @@ void fill_dvolume(const HostVolume& h, const DeviceVolume& d, DVolume& out) {
     out.metallic = std::min(std::max(h.mat.metallic, 0.0f), 1.0f);
     float r1 = h.mat.roughness + 1.0f;
     out.k = (r1 * r1) / 8.0f; /* RDXVoxelVolume.cpp:383 */
+    out.skip = (h.step_max > 0.0f && d.skip_valid) ? d.skip : nullptr;
+}
+
+/* (Re)builds the empty-space tables of a slot on every device for its current metric. */
+int rebuild_skip(vrt_ctx* ctx, int slot) {
+    const HostVolume& h = ctx->vol[slot];
+    for (auto& D : ctx->dev) {
+        DeviceVolume& v = D.vol[slot];
+        v.skip_valid = false;
+        if (!h.used || !(h.step_max > 0.0f) || !v.bricks) continue;
+        HIP_TRY(hipSetDevice(D.ordinal));
+        const size_t n = (size_t)h.nb * h.nb * h.nb;
+        if (!v.skip) HIP_TRY(hipMalloc(&v.skip, 2 * n));
+        HIP_TRY(launch_skip_table(v.bricks, v.skip, v.skip + n, h.nb, h.density_scale, h.step_max, D.stream));
+        HIP_TRY(hipStreamSynchronize(D.stream));
+        v.skip_valid = true;
+    }
+    return VRT_OK;
 }
 
 int sync_volume_table(vrt_ctx* ctx) {
@@ -282,6 +302,7 @@ int free_device_volume(DeviceState& D, int slot) {
     if (v.dense) HIP_TRY(hipFree(v.dense));
     if (v.bricks) HIP_TRY(hipFree(v.bricks));
     if (v.material) HIP_TRY(hipFree(v.material));
+    if (v.skip) HIP_TRY(hipFree(v.skip));
     v = DeviceVolume();
     return VRT_OK;
 }
@@ -311,6 +332,7 @@ void destroy_device(DeviceState& D) {
         if (D.vol[i].dense) (void)hipFree(D.vol[i].dense);
         if (D.vol[i].bricks) (void)hipFree(D.vol[i].bricks);
         if (D.vol[i].material) (void)hipFree(D.vol[i].material);
+        if (D.vol[i].skip) (void)hipFree(D.vol[i].skip);
     }
     if (D.d_vols) (void)hipFree(D.d_vols);
     if (D.d_inst) (void)hipFree(D.d_inst);
@@ -379,6 +401,8 @@ int upload_volume(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, cons
         h.step_max = 0.0f;
         h.mat = vrt_material{{0.8f, 0.8f, 0.8f, 1.0f}, 0.8f, 0.0f};
     }
+    int rc = rebuild_skip(ctx, slot);
+    if (rc != VRT_OK) return rc;
     return sync_volume_table(ctx);
 }
 
@@ -586,8 +610,15 @@ int vrt_volume_set_material(vrt_ctx* ctx, int slot, const vrt_material* material
 int vrt_volume_set_metric(vrt_ctx* ctx, int slot, float density_scale, float step_max) {
     if (!ctx || !(density_scale > 0.0f)) return VRT_ERR_INVALID;
     if (!valid_slot(slot) || !ctx->vol[slot].used) return VRT_ERR_SLOT;
+    if (ctx->vol[slot].density_scale == density_scale && ctx->vol[slot].step_max == step_max) return VRT_OK;
+    for (auto& D : ctx->dev) { /* frames in flight still read the old table */
+        HIP_TRY(hipSetDevice(D.ordinal));
+        HIP_TRY(hipDeviceSynchronize());
+    }
     ctx->vol[slot].density_scale = density_scale;
     ctx->vol[slot].step_max = step_max;
+    int rc = rebuild_skip(ctx, slot);
+    if (rc != VRT_OK) return rc;
     return sync_volume_table(ctx);
 }
 

@@ -48,6 +48,8 @@ struct DVolume {
     float metallic;        /* clamped to [0,1] */
     float k;               /* (roughness+1)^2 / 8 from the unclamped roughness */
     float pad_[2];
+    const uint8_t* skip;   /* nb^3 bytes or null: Chebyshev distance (bricks) to the nearest brick holding a
+                              sample closer than step_max to the surface; drives the empty-space leap */
 };
 
 struct DInstance {

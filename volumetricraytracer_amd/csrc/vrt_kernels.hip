@@ -58,8 +58,11 @@ __device__ __forceinline__ float fast_pow(float x, float e) { return __builtin_a
 typedef const float __attribute__((address_space(1))) * gfloat_p;
 typedef const unsigned __attribute__((address_space(1))) * guint_p;
 
+typedef const uint8_t __attribute__((address_space(1))) * gbyte_p;
+
 struct VolRef {
     gfloat_p p; /* dense grid or brick pool, by PATH */
+    gbyte_p skip; /* empty-space table or null */
     int N;
     int nb;
     float extent, inv_cell, dscale, step_max;
@@ -69,6 +72,7 @@ template <int PATH>
 __device__ __forceinline__ VolRef load_vol(const DVolume* __restrict__ v) {
     VolRef r;
     r.p = (gfloat_p)((PATH == VRT_PATH_DENSE) ? v->dense : v->bricks);
+    r.skip = (gbyte_p)v->skip;
     r.N = v->N;
     r.nb = v->nb;
     r.extent = v->extent;
@@ -197,6 +201,7 @@ struct RaySeg {
     float smax;           /* step_max / |od| */
     float cmax;           /* N - 2 */
     float base_min;       /* step_min + cone_eps * t_base */
+    float leap_unit;      /* one brick edge (4 cells) in ray-parameter units */
 };
 
 /* Transform the ray into the instance, slab-test its volume box and derive the march constants.
@@ -218,6 +223,7 @@ __device__ __forceinline__ bool setup_ray(const DFrame& F, const DInstance* __re
     R.t_end = minf_(t_exit, t_cur);
     /* smallest step: one pixel-footprint radius at the total path length t_base + t */
     R.base_min = __builtin_fmaf(t_base, F.cone_eps, F.step_min);
+    R.leap_unit = (4.0f * (1.0f / V.inv_cell)) * inv_len;
     return true;
 }
 
@@ -241,6 +247,16 @@ __device__ __forceinline__ Cell cell_at(const RaySeg& R, float t) {
     c.cy = (int)cyf;
     c.cz = (int)czf;
     return c;
+}
+
+/* Empty-space leap (ray-parameter units) from cell c: (D-1) brick edges when the nearest brick that
+ * can hold surface is D bricks away (Chebyshev), else 0.  The byte comes from a small L2-resident
+ * table and is requested together with the taps. */
+__device__ __forceinline__ float leap_at(const VolRef& V, const RaySeg& R, const Cell& c) {
+    const unsigned nb = (unsigned)V.nb;
+    const unsigned brick = mad24(mad24((unsigned)c.cx >> 2, nb, (unsigned)c.cz >> 2), nb, (unsigned)c.cy >> 2);
+    const int d = (int)V.skip[brick];
+    return (float)(d > 1 ? d - 1 : 0) * R.leap_unit;
 }
 
 /* World-space normal at a hit found in cell c after `iter` march iterations.  Taps always come from
@@ -308,6 +324,8 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
             st1 = stamp();
         }
         const Taps taps = fetch8<PATH>(V, c.cx, c.cy, c.cz);
+        float leap = 0.0f;
+        if (V.skip != nullptr) leap = leap_at(V, R, c);
         if constexpr (DIAG) {
             asm volatile("s_waitcnt vmcnt(0)" ::"v"(taps.y00a), "v"(taps.y00b), "v"(taps.y01a), "v"(taps.y01b), "v"(taps.y10a),
                          "v"(taps.y10b), "v"(taps.y11a), "v"(taps.y11b));
@@ -325,7 +343,7 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
             hit = true;
             break;
         }
-        const float adv_min = __builtin_fmaf(t, F.cone_eps, R.base_min);
+        const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
         t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
     }
     if (!hit) return false;
@@ -746,7 +764,9 @@ __device__ __forceinline__ bool march_coop(const DFrame& F, const VolRef& V, con
             iter_hit = i;
         }
         active = active && !hit_now;
-        const float adv_min = __builtin_fmaf(t, F.cone_eps, R.base_min);
+        float leap = 0.0f;
+        if (V.skip != nullptr && active) leap = leap_at(V, R, c);
+        const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
         const float t_next = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
         t = active ? t_next : t;
     }
@@ -846,6 +866,42 @@ __global__ __launch_bounds__(128) void retile_bricks_kernel(const float* __restr
     bricks[(size_t)brick * kBrickFloats + l] = v;
 }
 
+/* Empty-space table, step 1: a brick is "near" (0) when any of its 5^3 samples holds a trustworthy
+ * distance below the clamp, density*density_scale < step_max; everything else starts at 255. */
+__global__ __launch_bounds__(128) void skip_seed_kernel(const float* __restrict__ bricks, uint8_t* __restrict__ table,
+                                                        float density_scale, float step_max) {
+    const int brick = (int)blockIdx.x;
+    const int l = (int)threadIdx.x;
+    bool near = false;
+    if (l < 125) near = bricks[(size_t)brick * kBrickFloats + l] * density_scale < step_max;
+    const unsigned long long any0 = __ballot(near);
+    __shared__ int flag[2];
+    if ((l & 63) == 0) flag[l >> 6] = any0 != 0ull;
+    __syncthreads();
+    if (l == 0) table[brick] = (flag[0] || flag[1]) ? 0 : 255;
+}
+
+/* Step k of the exact Chebyshev distance transform: bricks still at 255 that touch (3x3x3) a brick at
+ * distance k-1 get distance k.  Launched for k = 1..nb on ping-pong buffers. */
+__global__ void skip_dilate_kernel(const uint8_t* __restrict__ cur, uint8_t* __restrict__ nxt, int nb, int k) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= nb * nb * nb) return;
+    const int by = i % nb, bz = (i / nb) % nb, bx = i / (nb * nb);
+    uint8_t d = cur[i];
+    if (d == 255) {
+        bool hit = false;
+        for (int dx = -1; dx <= 1; dx++)
+            for (int dz = -1; dz <= 1; dz++)
+                for (int dy = -1; dy <= 1; dy++) {
+                    const int x = bx + dx, y = by + dy, z = bz + dz;
+                    if (x < 0 || y < 0 || z < 0 || x >= nb || y >= nb || z >= nb) continue;
+                    hit = hit || cur[(x * nb + z) * nb + y] == (uint8_t)(k - 1);
+                }
+        if (hit) d = (uint8_t)k;
+    }
+    nxt[i] = d;
+}
+
 /* VVoxel records (8 B: u8 material, pad, f32 density) → dense fp32 densities + u8 materials. */
 __global__ void split_voxels_kernel(const uint2* __restrict__ voxels, float* __restrict__ density,
                                     uint8_t* __restrict__ material, size_t count) {
@@ -889,6 +945,26 @@ hipError_t launch_march(const DFrame& F, int path, bool single, hipStream_t stre
 
 hipError_t launch_retile(const float* dense, float* bricks, int N, int nb, hipStream_t stream) {
     hipLaunchKernelGGL(retile_bricks_kernel, dim3((unsigned)(nb * nb * nb)), dim3(128), 0, stream, dense, bricks, N, nb);
+    return hipGetLastError();
+}
+
+hipError_t launch_skip_table(const float* bricks, uint8_t* table, uint8_t* scratch, int nb, float density_scale, float step_max,
+                             hipStream_t stream) {
+    const int n = nb * nb * nb;
+    hipLaunchKernelGGL(skip_seed_kernel, dim3((unsigned)n), dim3(128), 0, stream, bricks, table, density_scale, step_max);
+    uint8_t* cur = table;
+    uint8_t* nxt = scratch;
+    const int rounds = nb < 254 ? nb : 254;
+    for (int k = 1; k <= rounds; k++) {
+        hipLaunchKernelGGL(skip_dilate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cur, nxt, nb, k);
+        uint8_t* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    if (cur != table) {
+        hipError_t e = hipMemcpyAsync(table, cur, (size_t)n, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+    }
     return hipGetLastError();
 }
 
