@@ -267,6 +267,8 @@ bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env
 
 inline float lerp1(float a, float b, float w) { return fmaf(w, b - a, a); }
 
+const int kRefine = 3; /* secant samples spent on a hit that overshot into the surface */
+
 /* Trilinear interpolant of cell (cx,cy,cz) at fractional position (fx,fy,fz). */
 inline float trilinear(const Volume& v, int cx, int cy, int cz, float fx, float fy, float fz) {
     const size_t N = (size_t)v.N;
@@ -336,6 +338,7 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
        the path that led to this ray's origin: 0 for camera rays, the hit distance for shadow rays) */
     const float base_min = fmaf(t_base, P.prm.cone_eps, P.prm.step_min);
     const float leap_unit = (4.0f * V.cell) * inv_len; /* one brick edge in ray-parameter units */
+    float t_prev = t, s_prev = 0.0f;
     for (int i = 0; i < P.prm.max_steps; i++) {
         if (t > t_end) return false;
         float ux = fmaf(ud.x, t, uo.x), uy = fmaf(ud.y, t, uo.y), uz = fmaf(ud.z, t, uo.z);
@@ -347,6 +350,30 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
         float s = trilinear(V, cx, cy, cz, fx, fy, fz) * ds;
         steps++;
         if (s < fmaf(t, P.prm.cone_eps, P.prm.eps_hit)) {
+            if (s < 0.0f && i > 0) {
+                /* the step overshot into the surface (band-edge cells of shell volumes interpolate towards the
+                   background value; trilinear SDFs are not exactly 1-Lipschitz): walk back to the crossing with
+                   kRefine secant (regula falsi) samples between the last outside and the first inside sample */
+                float ta = t_prev, sa = s_prev, tb = t, sb = s, tm = t;
+                for (int r = 0; r < kRefine; r++) {
+                    tm = fmaf(tb - ta, sa / (sa - sb), ta);
+                    float mx = fmaf(ud.x, tm, uo.x), my = fmaf(ud.y, tm, uo.y), mz = fmaf(ud.z, tm, uo.z);
+                    float mcx = minf(maxf(floorf(mx), 0.0f), cmax);
+                    float mcy = minf(maxf(floorf(my), 0.0f), cmax);
+                    float mcz = minf(maxf(floorf(mz), 0.0f), cmax);
+                    float sm = trilinear(V, (int)mcx, (int)mcy, (int)mcz, mx - mcx, my - mcy, mz - mcz) * ds;
+                    steps++;
+                    if (sm < 0.0f) { tb = tm; sb = sm; } else { ta = tm; sa = sm; }
+                }
+                /* report the last secant point: within the residual of the crossing, on either side */
+                t = tm;
+                ux = fmaf(ud.x, t, uo.x); uy = fmaf(ud.y, t, uo.y); uz = fmaf(ud.z, t, uo.z);
+                cxf = minf(maxf(floorf(ux), 0.0f), cmax);
+                cyf = minf(maxf(floorf(uy), 0.0f), cmax);
+                czf = minf(maxf(floorf(uz), 0.0f), cmax);
+                fx = ux - cxf; fy = uy - cyf; fz = uz - czf;
+                cx = (int)cxf; cy = (int)cyf; cz = (int)czf;
+            }
             t_hit = t;
             if (want_normal) {
                 V3 n;
@@ -377,6 +404,8 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
             }
             return true;
         }
+        t_prev = t;
+        s_prev = s;
         float adv_min = fmaf(t, P.prm.cone_eps, base_min);
         if (!V.skip.empty()) {
             /* empty-space leap: (D-1) brick edges from a brick whose nearest near brick is D away */

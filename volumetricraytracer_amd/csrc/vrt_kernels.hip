@@ -259,6 +259,36 @@ __device__ __forceinline__ float leap_at(const VolRef& V, const RaySeg& R, const
     return (float)(d > 1 ? d - 1 : 0) * R.leap_unit;
 }
 
+constexpr int kRefine = 3; /* secant samples spent on a hit that overshot into the surface */
+
+/*
+ * A step that lands inside the surface (s < 0) overshot: band-edge cells of shell volumes interpolate
+ * towards the background value, and a trilinear SDF is not exactly 1-Lipschitz.  Walk back to the
+ * crossing with kRefine regula-falsi samples between the last outside sample (ta, sa > 0) and the first
+ * inside one (tb, sb < 0); returns the last secant point and its cell.  Taps come from global memory
+ * (a few samples per overshooting hit).
+ */
+template <int PATH>
+__device__ __forceinline__ float refine_hit(const VolRef& V, const RaySeg& R, float ta, float sa, float tb, float sb, Cell& c,
+                                            unsigned& steps) {
+    float tm = tb;
+#pragma unroll 1
+    for (int r = 0; r < kRefine; r++) {
+        tm = __builtin_fmaf(tb - ta, sa / (sa - sb), ta);
+        c = cell_at(R, tm);
+        const float sm = trilinear<PATH>(V, c.cx, c.cy, c.cz, c.fx, c.fy, c.fz) * R.ds;
+        steps++;
+        if (sm < 0.0f) {
+            tb = tm;
+            sb = sm;
+        } else {
+            ta = tm;
+            sa = sm;
+        }
+    }
+    return tm;
+}
+
 /* World-space normal at a hit found in cell c after `iter` march iterations.  Taps always come from
  * global memory here (once per hit, 24 independent loads in flight). */
 template <int PATH>
@@ -311,6 +341,7 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     bool hit = false;
     int i = 0;
     Cell c = {0, 0, 0, 0.0f, 0.0f, 0.0f};
+    float t_prev = t, s_prev = 0.0f, s_hit = 0.0f;
     /* (Keeping the current cell's 8 taps in registers and skipping the loads while a ray stays in
        the cell was measured: even the slowest rays change cell every other sample, and the extra
        compare + branch made the frame 7 % slower.  Not done.) */
@@ -341,12 +372,16 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
         steps++;
         if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
             hit = true;
+            s_hit = s;
             break;
         }
+        t_prev = t;
+        s_prev = s;
         const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
         t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
     }
     if (!hit) return false;
+    if (s_hit < 0.0f && i > 0) t = refine_hit<PATH>(V, R, t_prev, s_prev, t, s_hit, c, steps);
     t_hit = t;
     if constexpr (NORMAL) n_world = hit_normal<PATH>(I, V, R, c, i);
     return true;
@@ -694,6 +729,7 @@ __device__ __forceinline__ bool march_coop(const DFrame& F, const VolRef& V, con
                                            Cell& c_hit, int& iter_hit, unsigned& steps, DiagAcc* dg) {
     float t = R.t0;
     bool hit = false;
+    float t_prev = t, s_prev = 0.0f, s_hit = 0.0f;
     const int max_steps = F.max_steps;
     const unsigned nb = (unsigned)V.nb;
     for (int i = 0; i < max_steps; i++) {
@@ -760,16 +796,23 @@ __device__ __forceinline__ bool march_coop(const DFrame& F, const VolRef& V, con
         if (hit_now) {
             hit = true;
             t_hit = t;
+            s_hit = s;
             c_hit = c;
             iter_hit = i;
         }
         active = active && !hit_now;
+        if (active) {
+            t_prev = t;
+            s_prev = s;
+        }
         float leap = 0.0f;
         if (V.skip != nullptr && active) leap = leap_at(V, R, c);
         const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
         const float t_next = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
         t = active ? t_next : t;
     }
+    /* overshooting hits walk back to the crossing (per lane, taps from global memory) */
+    if (hit && s_hit < 0.0f && iter_hit > 0) t_hit = refine_hit<VRT_PATH_BRICK>(V, R, t_prev, s_prev, t_hit, s_hit, c_hit, steps);
     return hit;
 }
 
