@@ -539,19 +539,6 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
     bool shadows = level < MAX_DEPTH; /* TraceShadowRay's recursion guard, Ray.hlsli:83-86 */
     V3 diffuse = v3(0.0f, 0.0f, 0.0f); /* SHADOW_BRIGHTNESS */
 
-    if (V.roughness < 0.3f && level <= P.prm.max_bounces && level < MAX_DEPTH) {
-        float dn = dot(d, n);
-        V3 rd = normalize(v3(d.x - (2.0f * dn) * n.x, d.y - (2.0f * dn) * n.y, d.z - (2.0f * dn) * n.z));
-        st.bounce_rays++;
-        V3 rc = radiance_ray(P, so, rd, level + 1, t_base + h.t, st);
-        float fade = V.roughness * 2.2f;
-        rc = v3(maxf(0.0f, rc.x + (0.0f - rc.x) * fade), maxf(0.0f, rc.y + (0.0f - rc.y) * fade),
-                maxf(0.0f, rc.z + (0.0f - rc.z) * fade));
-        V3 r;
-        radiance(rc, rd, wo, n, albedo, V.roughness, V.metallic, V.k, r);
-        diffuse = diffuse + r;
-    }
-
     bool shadowed = false;
     if (P.prm.shadow && shadows) {
         st.shadow_rays++;
@@ -623,6 +610,21 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
                 diffuse = diffuse + r;
             }
         }
+    }
+    /* Mirror bounce (Raytracing.hlsl:79-90).  The reference adds it before the direct light; here it is
+       added last so that the kernel can evaluate the recursion as a loop with the same rounding
+       (colour = direct + reflection at every level). */
+    if (V.roughness < 0.3f && level <= P.prm.max_bounces && level < MAX_DEPTH) {
+        float dn = dot(d, n);
+        V3 rd = normalize(v3(d.x - (2.0f * dn) * n.x, d.y - (2.0f * dn) * n.y, d.z - (2.0f * dn) * n.z));
+        st.bounce_rays++;
+        V3 rc = radiance_ray(P, so, rd, level + 1, t_base + h.t, st);
+        float fade = V.roughness * 2.2f;
+        rc = v3(maxf(0.0f, rc.x + (0.0f - rc.x) * fade), maxf(0.0f, rc.y + (0.0f - rc.y) * fade),
+                maxf(0.0f, rc.z + (0.0f - rc.z) * fade));
+        V3 r;
+        radiance(rc, rd, wo, n, albedo, V.roughness, V.metallic, V.k, r);
+        diffuse = diffuse + r;
     }
     return diffuse;
 }

@@ -84,3 +84,23 @@ def bench_config3() -> v.VScene:
     if _bench_c3 is None:
         _bench_c3 = config3_voxelized(8, 256)
     return _bench_c3
+
+
+def full_closest_hit_scene(resolution: int = 6, env: int = 32) -> v.VScene:
+    """Exercises the whole closest-hit shader: smooth metallic spheres that mirror each
+    other (roughness 0.1 < 0.3 → bounce, as in the reference's demo materials,
+    RendererEngineInstance.cpp:251-263), a rough one, one point and one spot light next to the
+    directional light."""
+    smooth_red = v.sphere_volume(resolution, 100.0, 60.0, v.VMaterial((1.0, 0.1, 0.1, 1.0), 0.1, 0.6))
+    smooth_blue = v.sphere_volume(resolution, 100.0, 45.0, v.VMaterial((0.1, 0.1, 1.0, 1.0), 0.2, 0.3))
+    rough = v.csg_volume(resolution, 100.0, v.VMaterial((0.8, 0.8, 0.3, 1.0), 0.7, 0.0))
+    objs = [v.VVoxelObject(Position=(0.0, -110.0, 0.0), Volume=smooth_red),
+            v.VVoxelObject(Position=(0.0, 80.0, 30.0), Volume=smooth_blue),
+            v.VVoxelObject(Position=(-60.0, 0.0, -150.0), Rotation=tuple(v.quat_from_axis_angle(v.UP, 0.6)), Scale=(1.6, 1.6, 0.5), Volume=rough)]
+    point = v.VPointLight(Position=(150.0, 0.0, 120.0), IlluminationStrength=400.0, Color=(1.0, 0.9, 0.7, 1.0),
+                          AttenuationLinear=0.05, AttenuationExp=0.002)
+    spot_dir = v.quat_mul(v.quat_from_axis_angle(v.UP, math.radians(150.0)), v.quat_from_axis_angle(v.RIGHT, math.radians(40.0)))
+    spot = v.VSpotLight(Position=(200.0, -150.0, 200.0), Rotation=tuple(spot_dir), IlluminationStrength=900.0,
+                        Color=(0.6, 1.0, 0.6, 1.0), AttenuationLinear=0.02, AttenuationExp=0.001, FalloffAngle=25.0, Angle=60.0)
+    return v.VScene(Camera=v.look_minus_x_camera(420.0, 40.0), DirectionalLight=v.demo_light(), Objects=objs,
+                    PointLights=[point], SpotLights=[spot], EnvironmentMap=v.procedural_skybox(env))

@@ -297,3 +297,28 @@ def test_cpp_host_adaptor_renders_the_demo_scene(renderer, tmp_path):
     # identical pipeline up to the light quaternion's last bit (float sin/cos vs double) and 8-bit rounding
     assert (diff > 1).mean() < 2e-3, f"{(diff > 1).sum()} pixels differ by more than one 8-bit step"
     assert (ppm[..., 0].astype(int) - ppm[..., 2] > 60).sum() > 2000  # the red sphere is in the frame
+
+
+@pytest.mark.parametrize("bounces", [0, 1, 2])
+@pytest.mark.parametrize("path", [_abi.PATH_BRICK, _abi.PATH_DENSE])
+def test_full_closest_hit_parity(renderer, oracle_lib, bounces, path):
+    """point + spot lights with their own shadow rays and the mirror bounce down to
+    MAX_RAY_RECURSION_DEPTH, against the (recursive) oracle."""
+    sc = scenes.full_closest_hit_scene(6, 32)
+    p = v.default_params(480, 270, scenes.min_cell(sc), 255, shadow=True, path=path)
+    p.max_bounces = bounces
+    img, t = assert_parity(renderer, sc, p, check_stats=False)
+    ref, st = OracleScene(sc).render(p, threads=8)
+    for key in ("hits", "shadow_rays", "bounce_rays", "primary_rays"):
+        assert t[key] == st[key], key
+    assert (st["bounce_rays"] > 1000) == (bounces > 0)
+
+
+def test_full_closest_hit_single_instance_counters(renderer, oracle_lib):
+    vol = v.sphere_volume(6, 100.0, 60.0, v.VMaterial((0.9, 0.6, 0.3, 1.0), 0.1, 0.6))
+    sc = scenes.full_closest_hit_scene(5, 16)
+    sc.Objects = [v.VVoxelObject(Volume=vol)]
+    sc.Camera = v.look_minus_x_camera(260.0)
+    p = v.default_params(320, 180, vol.GetCellSize(), 255, shadow=True)
+    p.max_bounces = 2
+    assert_parity(renderer, sc, p, check_stats=True)

@@ -468,8 +468,6 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_BRICK_LDS) return VRT_ERR_INVALID;
     if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE)) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
     if (!ctx->have_scene) return VRT_ERR_NOT_READY;
-    if (p->max_bounces > 0 || ctx->scene.n_point_lights > 0 || ctx->scene.n_spot_lights > 0)
-        return VRT_ERR_UNSUPPORTED; /* full closest-hit: SURVEY §8f-2 (next) */
     return VRT_OK;
 }
 

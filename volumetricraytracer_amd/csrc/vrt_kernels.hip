@@ -291,7 +291,7 @@ __device__ __forceinline__ float refine_hit(const VolRef& V, const RaySeg& R, fl
 
 /* World-space normal at a hit found in cell c after `iter` march iterations.  Taps always come from
  * global memory here (once per hit, 24 independent loads in flight). */
-template <int PATH>
+template <int PATH, bool EXACT = false>
 __device__ __forceinline__ F3 hit_normal(const DInstance* __restrict__ I, const VolRef& V, const RaySeg& R, const Cell& c,
                                          int iter) {
     F3 n;
@@ -318,6 +318,8 @@ __device__ __forceinline__ F3 hit_normal(const DInstance* __restrict__ I, const 
     float l2 = dot3(n, n);
     if (!(l2 > 0.0f)) {
         n = f3(0.0f, 0.0f, 0.0f);
+    } else if constexpr (EXACT) {
+        n = n * (1.0f / sqrtf(l2)); /* the normal steers a mirror bounce: keep it bit-identical to the oracle */
     } else {
         n = n * fast_rsq(l2);
     }
@@ -329,7 +331,7 @@ __device__ __forceinline__ F3 hit_normal(const DInstance* __restrict__ I, const 
  * true on hit and the ray parameter (shared by world and object space — the object-space direction
  * is not re-normalised, DXR semantics).  NORMAL: also produce the world-space normal.
  */
-template <int PATH, bool NORMAL, bool DIAG = false>
+template <int PATH, int NORMAL /* 0 none, 1 fast length, 2 exact length */, bool DIAG = false>
 __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance* __restrict__ I,
                                                const DVolume* __restrict__ Vd, F3 o, F3 d, float t_cur, float t_base,
                                                float& t_hit, F3& n_world, unsigned& steps, DiagAcc* dg = nullptr) {
@@ -383,18 +385,19 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     if (!hit) return false;
     if (s_hit < 0.0f && i > 0) t = refine_hit<PATH>(V, R, t_prev, s_prev, t, s_hit, c, steps);
     t_hit = t;
-    if constexpr (NORMAL) n_world = hit_normal<PATH>(I, V, R, c, i);
+    if constexpr (NORMAL == 1) n_world = hit_normal<PATH, false>(I, V, R, c, i);
+    if constexpr (NORMAL == 2) n_world = hit_normal<PATH, true>(I, V, R, c, i);
     return true;
 }
 
 /* Closest hit over the scene.  SINGLE: exactly one instance, no BVH, all scene data wave-uniform. */
-template <int PATH, bool SINGLE, bool DIAG = false>
+template <int PATH, bool SINGLE, bool DIAG = false, int NORMAL = 1>
 __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float t_max, float t_base, float& t_best,
                                               int& inst_best, F3& n_best, unsigned& steps, DiagAcc* dg = nullptr) {
     if constexpr (SINGLE) {
         float t;
         F3 n;
-        if (march_instance<PATH, true, DIAG>(F, F.inst, F.vols + F.inst->slot, o, d, t_max, t_base, t, n, steps, dg)) {
+        if (march_instance<PATH, NORMAL, DIAG>(F, F.inst, F.vols + F.inst->slot, o, d, t_max, t_base, t, n, steps, dg)) {
             t_best = t;
             inst_best = 0;
             n_best = n;
@@ -415,7 +418,7 @@ __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float
                 const DInstance* I = F.inst + ii;
                 float t;
                 F3 n;
-                if (march_instance<PATH, true, DIAG>(F, I, F.vols + I->slot, o, d, best, t_base, t, n, steps, dg)) {
+                if (march_instance<PATH, NORMAL, DIAG>(F, I, F.vols + I->slot, o, d, best, t_base, t, n, steps, dg)) {
                     if (!any || t < best || (t == best && ii < inst_best)) {
                         any = true;
                         best = t;
@@ -439,7 +442,7 @@ __device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_m
     float t;
     F3 n;
     if constexpr (SINGLE) {
-        return march_instance<PATH, false, DIAG>(F, F.inst, F.vols + F.inst->slot, o, d, t_max, t_base, t, n, steps, dg);
+        return march_instance<PATH, 0, DIAG>(F, F.inst, F.vols + F.inst->slot, o, d, t_max, t_base, t, n, steps, dg);
     } else {
         int stack[16];
         int sp = 0;
@@ -449,7 +452,7 @@ __device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_m
             if (!slab_box(o, d, nd, t_max)) continue;
             if (nd.left < 0) {
                 const DInstance* I = F.inst + (-nd.left - 1);
-                if (march_instance<PATH, false, DIAG>(F, I, F.vols + I->slot, o, d, t_max, t_base, t, n, steps, dg)) return true;
+                if (march_instance<PATH, 0, DIAG>(F, I, F.vols + I->slot, o, d, t_max, t_base, t, n, steps, dg)) return true;
             } else {
                 stack[sp++] = nd.right;
                 stack[sp++] = nd.left;
@@ -491,7 +494,8 @@ __device__ __forceinline__ F3 env_lookup(const uint8_t* __restrict__ env, int S,
 }
 
 /* Radiance(), Lighting.hlsli:50-101 (F enters twice, PI = 3.141592f as in Constants.hlsli). */
-__device__ __forceinline__ F3 radiance(F3 Li, F3 wi, F3 wo, F3 n, F3 albedo, float rough, float metal, float k) {
+/* BRDF(wi, wo) of Lighting.hlsli:77-96; Radiance = (BRDF * Li) * dot(n, wi)  (:98-101). */
+__device__ __forceinline__ F3 brdf_eval(F3 wi, F3 wo, F3 n, F3 albedo, float rough, float metal, float k) {
     const float PI_REF = 3.141592f;
     const float INV_PI_REF = 1.0f / 3.141592f;
     F3 hv = wi + wo;
@@ -514,9 +518,13 @@ __device__ __forceinline__ F3 radiance(F3 Li, F3 wi, F3 wo, F3 n, F3 albedo, flo
     F3 cook = f3(dg * Fr.x, dg * Fr.y, dg * Fr.z);
     float km = 1.0f - metal;
     F3 kd = f3((1.0f - Fr.x) * km, (1.0f - Fr.y) * km, (1.0f - Fr.z) * km);
-    F3 brdf = f3((albedo.x * INV_PI_REF) * kd.x + cook.x * Fr.x, (albedo.y * INV_PI_REF) * kd.y + cook.y * Fr.y,
-                 (albedo.z * INV_PI_REF) * kd.z + cook.z * Fr.z);
-    float ndwi = dot3(n, wi);
+    return f3((albedo.x * INV_PI_REF) * kd.x + cook.x * Fr.x, (albedo.y * INV_PI_REF) * kd.y + cook.y * Fr.y,
+              (albedo.z * INV_PI_REF) * kd.z + cook.z * Fr.z);
+}
+
+__device__ __forceinline__ F3 radiance(F3 Li, F3 wi, F3 wo, F3 n, F3 albedo, float rough, float metal, float k) {
+    const F3 brdf = brdf_eval(wi, wo, n, albedo, rough, metal, k);
+    const float ndwi = dot3(n, wi);
     return f3((brdf.x * Li.x) * ndwi, (brdf.y * Li.y) * ndwi, (brdf.z * Li.z) * ndwi);
 }
 
@@ -705,6 +713,138 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
         store_pixel(F, px, pyl, color);
     }
     write_records<DIAG>(F, b, wave, lane, k, dg, t_start);
+}
+
+/*
+ * Full closest hit (SH/Raytracing_NoTex.hlsl:41-139): directional + ≤5 point + ≤5 spot lights, each
+ * with its own shadow ray, and the mirror bounce of smooth materials (roughness < 0.3) down to
+ * MAX_RAY_RECURSION_DEPTH = 3 levels.  The reference recurses (TraceRay inside the closest-hit
+ * shader); here the ≤3 levels are a loop that records, per level, the direct light and the BRDF
+ * factor of the bounce, and folds them back to front:  colour_L = direct_L + (BRDF_L · fade(colour_L+1)) · n·wi.
+ * At level 3 the shadow rays are skipped and count as unoccluded (TraceShadowRay's recursion guard,
+ * SH/Include/Ray.hlsli:83-86).
+ */
+constexpr int kMaxDepth = 3;
+
+template <int PATH, bool SINGLE>
+__global__ __launch_bounds__(kBlockThreads) void march_kernel_full(const DFrame F) {
+    const int b = (int)blockIdx.x;
+    int tile_x, tile_y;
+    tile_of_block(F, b, (int)gridDim.x, tile_x, tile_y);
+    const int wave = (int)threadIdx.x >> 6;
+    const int lane = (int)threadIdx.x & 63;
+    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int py = F.row0 + pyl;
+    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows;
+
+    Counters k;
+    DiagAcc dg;
+    if (valid) {
+        F3 o, d;
+        camera_ray(F, px, py, o, d);
+        k.n_primary = 1;
+        F3 direct[kMaxDepth - 1], brdf[kMaxDepth - 1];
+        float ndwi[kMaxDepth - 1], fade[kMaxDepth - 1];
+        int pending = 0;
+        float t_base = 0.0f;
+        F3 color = f3(0.0f, 0.0f, 0.0f);
+#pragma unroll 1
+        for (int level = 1; level <= kMaxDepth; level++) {
+            float t_hit = 0.0f;
+            int inst = 0;
+            F3 n = f3(0.0f, 0.0f, 0.0f);
+            if (!trace_closest<PATH, SINGLE, false, 2>(F, o, d, 10000.0f, t_base, t_hit, inst, n, k.s_primary)) {
+                color = env_lookup(F.env, F.env_size, d);
+                break;
+            }
+            k.n_hits++;
+            const DVolume* V = F.vols + F.inst[inst].slot;
+            const F3 albedo = f3(V->tint[0], V->tint[1], V->tint[2]);
+            if (F.unlit) {
+                color = albedo;
+                break;
+            }
+            const float rough = V->roughness, metal = V->metallic, kk = V->k;
+            const F3 so = shadow_origin(o, d, t_hit);
+            const F3 wo = f3(-d.x, -d.y, -d.z);
+            const float tb = t_base + t_hit;
+            const bool shadows = F.shadow && level < kMaxDepth;
+            F3 sum = f3(0.0f, 0.0f, 0.0f);
+            {   /* directional light */
+                const F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
+                bool sh = false;
+                if (shadows) {
+                    k.n_shadow++;
+                    sh = trace_any<PATH, SINGLE>(F, so, ld, 5000.0f, tb, k.s_shadow);
+                }
+                if (!sh) sum = sum + radiance(f3(F.light_strength, F.light_strength, F.light_strength), ld, wo, n, albedo, rough, metal, kk);
+            }
+            for (int i = 0; i < F.n_point; i++) { /* ComputePointLightIntensity, Lighting.hlsli:17-20 */
+                const DPointLight L = F.point[i];
+                const F3 dl = f3(L.pos[0] - so.x, L.pos[1] - so.y, L.pos[2] - so.z);
+                const float dist = sqrtf(dot3(dl, dl));
+                const float inten = L.intensity / ((1.0f + L.att_linear * dist) + (L.att_exp * dist) * dist);
+                if (inten > 0.005f) {
+                    const F3 ld = dl * (1.0f / dist);
+                    bool sh = false;
+                    if (shadows) {
+                        k.n_shadow++;
+                        sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow);
+                    }
+                    if (!sh) sum = sum + radiance(f3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo, rough, metal, kk);
+                }
+            }
+            for (int i = 0; i < F.n_spot; i++) { /* ComputeSpotLightIntensity, Lighting.hlsli:30-48 */
+                const DSpotLight L = F.spot[i];
+                const F3 dl = f3(L.pos[0] - so.x, L.pos[1] - so.y, L.pos[2] - so.z);
+                const float dist = sqrtf(dot3(dl, dl));
+                const F3 sd = f3(-dl.x, -dl.y, -dl.z) * (1.0f / dist);
+                const float cs = dot3(f3(L.fwd[0], L.fwd[1], L.fwd[2]), sd);
+                float inten = 0.0f;
+                if (cs >= 0.0f && cs > L.cos_angle) {
+                    const float delta = (cs - L.cos_angle) / (L.cos_falloff - L.cos_angle);
+                    const float base = L.intensity * minf_(delta, 1.0f);
+                    inten = base / ((1.0f + L.att_linear * dist) + (L.att_exp * dist) * dist);
+                }
+                if (inten > 0.01f) {
+                    const F3 ld = dl * (1.0f / dist);
+                    bool sh = false;
+                    if (shadows) {
+                        k.n_shadow++;
+                        sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow);
+                    }
+                    if (!sh) sum = sum + radiance(f3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo, rough, metal, kk);
+                }
+            }
+            if (rough < 0.3f && level <= F.max_bounces && level < kMaxDepth) {
+                /* mirror bounce: continue along the reflected ray, fold this level in afterwards */
+                const float dn = dot3(d, n);
+                const F3 rd = normalize3(f3(d.x - (2.0f * dn) * n.x, d.y - (2.0f * dn) * n.y, d.z - (2.0f * dn) * n.z));
+                direct[pending] = sum;
+                brdf[pending] = brdf_eval(rd, wo, n, albedo, rough, metal, kk);
+                ndwi[pending] = dot3(n, rd);
+                fade[pending] = rough * 2.2f;
+                pending++;
+                k.n_bounce++;
+                o = so;
+                d = rd;
+                t_base = tb;
+                color = f3(0.0f, 0.0f, 0.0f); /* level kMaxDepth+1 would return black (Ray.hlsli:62-65) */
+                continue;
+            }
+            color = sum;
+            break;
+        }
+        for (int j = pending - 1; j >= 0; j--) {
+            const F3 rc = f3(maxf_(0.0f, color.x + (0.0f - color.x) * fade[j]), maxf_(0.0f, color.y + (0.0f - color.y) * fade[j]),
+                             maxf_(0.0f, color.z + (0.0f - color.z) * fade[j]));
+            const F3 r = f3((brdf[j].x * rc.x) * ndwi[j], (brdf[j].y * rc.y) * ndwi[j], (brdf[j].z * rc.z) * ndwi[j]);
+            color = direct[j] + r;
+        }
+        store_pixel(F, px, pyl, color);
+    }
+    write_records<false>(F, b, wave, lane, k, dg, 0ull);
 }
 
 /* ---- wave-cooperative march through a per-wave LDS brick cache ------------------------------- */
@@ -980,7 +1120,20 @@ static hipError_t launch_coop(const DFrame& F, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int PATH, bool SINGLE>
+static hipError_t launch_full_t(const DFrame& F, hipStream_t stream) {
+    const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
+    if (grid <= 0) return hipSuccess;
+    hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
+    return hipGetLastError();
+}
+
 hipError_t launch_march(const DFrame& F, int path, bool single, hipStream_t stream) {
+    if (F.max_bounces > 0 || F.n_point > 0 || F.n_spot > 0) {
+        /* full closest hit: per-lane kernels on the dense grid or the bricks */
+        if (path == VRT_PATH_DENSE) return single ? launch_full_t<VRT_PATH_DENSE, true>(F, stream) : launch_full_t<VRT_PATH_DENSE, false>(F, stream);
+        return single ? launch_full_t<VRT_PATH_BRICK, true>(F, stream) : launch_full_t<VRT_PATH_BRICK, false>(F, stream);
+    }
     if (path == VRT_PATH_BRICK_LDS && single) return launch_coop(F, stream);
     if (path == VRT_PATH_DENSE) return single ? launch_t<VRT_PATH_DENSE, true>(F, stream) : launch_t<VRT_PATH_DENSE, false>(F, stream);
     return single ? launch_t<VRT_PATH_BRICK, true>(F, stream) : launch_t<VRT_PATH_BRICK, false>(F, stream);
