@@ -176,6 +176,7 @@ void VHipRenderer::Render() {
     p.shadow = Shadows ? 1 : 0;
     p.mode = (int)RenderMode;
     p.path = DataPath;
+    p.max_bounces = MaxBounces;
     p.eps_hit = 0.004f * MinCell;
     p.eps_in = 0.01f; /* Raytracing.hlsl:178 */
     p.step_min = 0.004f * MinCell;

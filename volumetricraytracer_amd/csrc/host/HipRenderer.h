@@ -39,6 +39,7 @@ public:
     /* march contract knobs; defaults follow the smallest cell of the scene */
     int MaxSteps = 255;       /* Raytracing.hlsl:229 */
     bool Shadows = true;      /* the reference always casts the directional shadow ray */
+    int MaxBounces = 2;       /* MAX_RAY_RECURSION_DEPTH 3 = primary + 2 mirror bounces (RaytracingHlsl.h:32) */
     int DataPath = VRT_PATH_AUTO;
 
 private:

@@ -504,6 +504,14 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.tiles_y = (rows + 15) / 16;
     F.tile_map = p->flags & 3;
     F.diag = (p->flags & VRT_FLAG_DIAG_TIMELINE) ? 1 : 0;
+    /* the lean kernel covers directional light + shadow; the full closest hit is only launched when the
+       frame can need it: extra lights, or bounces allowed and some instanced material mirrors (roughness < 0.3) */
+    bool smooth = false;
+    for (int i = 0; i < ctx->scene.n_instances; i++) {
+        const HostVolume& hv = ctx->vol[ctx->scene.instances[i].volume_slot];
+        smooth = smooth || std::min(std::max(hv.mat.roughness, 0.0f), 1.0f) < 0.3f;
+    }
+    F.full = (ctx->scene.n_point_lights > 0 || ctx->scene.n_spot_lights > 0 || (p->max_bounces > 0 && smooth)) ? 1 : 0;
     F.n_inst = ctx->scene.n_instances;
     F.n_nodes = ctx->n_nodes;
     F.n_point = std::min(ctx->scene.n_point_lights, VRT_MAX_POINT_LIGHTS);

@@ -110,6 +110,8 @@ struct DFrame {
     int32_t tiles_x, tiles_y;  /* 16x16-pixel blocks covering width x rows */
     int32_t tile_map;          /* kMapSupertile / kMapBand / kMapLinear */
     int32_t diag;              /* 1: diagnostic kernel build that stamps per-wave timeline records */
+    int32_t full;              /* 1: full closest hit needed (point/spot lights, or bounces allowed and a smooth material in the scene) */
+    int32_t pad1_;
     /* scene arrays */
     int32_t n_inst, n_nodes;
     int32_t n_point, n_spot;

@@ -1129,7 +1129,7 @@ static hipError_t launch_full_t(const DFrame& F, hipStream_t stream) {
 }
 
 hipError_t launch_march(const DFrame& F, int path, bool single, hipStream_t stream) {
-    if (F.max_bounces > 0 || F.n_point > 0 || F.n_spot > 0) {
+    if (F.full) {
         /* full closest hit: per-lane kernels on the dense grid or the bricks */
         if (path == VRT_PATH_DENSE) return single ? launch_full_t<VRT_PATH_DENSE, true>(F, stream) : launch_full_t<VRT_PATH_DENSE, false>(F, stream);
         return single ? launch_full_t<VRT_PATH_BRICK, true>(F, stream) : launch_full_t<VRT_PATH_BRICK, false>(F, stream);

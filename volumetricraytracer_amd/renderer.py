@@ -30,6 +30,7 @@ class VHipRenderer:
         self.DataPath = _abi.PATH_AUTO
         self.Shadows = True
         self.MaxSteps = 255  # Raytracing.hlsl:229
+        self.MaxBounces = 2  # MAX_RAY_RECURSION_DEPTH 3 = primary + 2 mirror bounces (RaytracingHlsl.h:32)
         self._env_id = None
 
     # -- VRenderer surface -------------------------------------------------------------------
@@ -126,6 +127,7 @@ class VHipRenderer:
         else:
             cell = min((v.GetCellSize() for v in self._scene.volumes()), default=1.0) if self._scene else 1.0
             p = default_params(self.Width, self.Height, cell, max_steps=self.MaxSteps, shadow=self.Shadows)
+            p.max_bounces = self.MaxBounces
         p.width, p.height = self.Width, self.Height
         p.mode = self.RenderMode
         if self.params_override is None:
