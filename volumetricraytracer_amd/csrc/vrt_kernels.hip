@@ -232,6 +232,13 @@ struct Cell {
     int cx, cy, cz;
     float fx, fy, fz;
 };
+/* Per-lane march state handed from the per-lane head to the LDS tail of the hybrid march. */
+struct MarchState {
+    float t, t_prev, s_prev, s_hit;
+    int i;
+    bool hit, done;
+    Cell c;
+};
 __device__ __forceinline__ Cell cell_at(const RaySeg& R, float t) {
     const float ux = __builtin_fmaf(R.ud.x, t, R.uo.x);
     const float uy = __builtin_fmaf(R.ud.y, t, R.uo.y);
@@ -258,6 +265,15 @@ __device__ __forceinline__ float leap_at(const VolRef& V, const RaySeg& R, const
     const int d = (int)V.skip[brick];
     return (float)(d > 1 ? d - 1 : 0) * R.leap_unit;
 }
+
+/* Empty-space table byte of cell c's brick and its conversion to a leap (used by the hybrid march; the
+ * per-lane kernels use leap_at). */
+__device__ __forceinline__ unsigned leap_byte(const VolRef& V, const Cell& c) {
+    const unsigned nb = (unsigned)V.nb;
+    const unsigned brick = mad24(mad24((unsigned)c.cx >> 2, nb, (unsigned)c.cz >> 2), nb, (unsigned)c.cy >> 2);
+    return (unsigned)V.skip[brick];
+}
+__device__ __forceinline__ float leap_from(const RaySeg& R, unsigned d) { return (float)(d > 1u ? d - 1u : 0u) * R.leap_unit; }
 
 constexpr int kRefine = 3; /* secant samples spent on a hit that overshot into the surface */
 
@@ -847,69 +863,71 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_full(const DFrame 
     write_records<false>(F, b, wave, lane, k, dg, 0ull);
 }
 
-/* ---- wave-cooperative march through a per-wave LDS brick cache ------------------------------- */
+/* ---- hybrid march: per-lane head, wave-cooperative LDS tail ----------------------------------- */
 
 constexpr int kLdsSlots = 8;                 /* bricks cached per wave: any 2x2x2 brick neighbourhood fits */
 constexpr unsigned kTagInvalid = 0xffffffffu;
+constexpr int kHeadSteps = 12;               /* samples every ray takes from global memory before the LDS phase */
 
 /*
- * Sphere-trace with the taps served from LDS.  ALL 64 lanes of the wave call this (wave-uniform
- * control flow); `active` says which lanes carry a ray.  Each wave owns kLdsSlots brick slots
- * (512 B each) and their tags.  Per step a lane looks up its brick's slot (direct-mapped on the
- * low bit of each brick coordinate), reads tag + 8 taps speculatively, and commits them when the
- * tag matches; lanes that miss vote (__ballot), the first one's brick is fetched by the whole
- * wave with one coalesced 512-B read (64 lanes x 8 B) into its slot, and the loop re-checks.
- * LDS operations of one wave execute in order, so no barrier is needed.  The march exits as soon
- * as no lane is active (__ballot early-out).  Results are bit-identical to the global-memory
- * paths: the same taps feed the same arithmetic.
+ * Phase 2 of the hybrid march: the rays of a wave that are still marching after kHeadSteps samples
+ * (rays that graze a surface: 100+ dependent samples, each a full L2/HBM round trip for a lone wave —
+ * they set the kernel's tail) continue with their taps served from a per-wave LDS brick cache.
+ * ALL 64 lanes run this loop (wave-uniform control flow); `active` marks the lanes that carry a ray.
+ * Per sample a lane looks up its brick's slot (direct-mapped on the low bit of each brick
+ * coordinate), reads the tag and the 8 taps together, and keeps them when the tag matches; lanes that
+ * miss vote (__ballot), the first one's brick is fetched by the whole wave with one coalesced 512-B
+ * read (64 lanes x 8 B) into its slot, and the lookup repeats.  If the slot is in use by lanes that hit
+ * in this very sample, the missing lanes take their taps from global memory instead (no eviction
+ * ping-pong).  LDS operations of one wave execute in order: no barrier.  The loop ends as soon as no
+ * lane is active (__ballot early-out).  Same taps, same arithmetic: bit-identical results.
  */
-template <bool DIAG>
-__device__ __forceinline__ bool march_coop(const DFrame& F, const VolRef& V, const RaySeg& R, bool active,
-                                           float* __restrict__ slots, unsigned* __restrict__ tags, int lane, float& t_hit,
-                                           Cell& c_hit, int& iter_hit, unsigned& steps, DiagAcc* dg) {
-    float t = R.t0;
-    bool hit = false;
-    float t_prev = t, s_prev = 0.0f, s_hit = 0.0f;
+__device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V, const RaySeg& R, bool active, MarchState& st,
+                                               int i_start, float* __restrict__ slots, unsigned* __restrict__ tags, int lane,
+                                               unsigned& steps) {
+    float t = st.t, t_prev = st.t_prev, s_prev = st.s_prev;
     const int max_steps = F.max_steps;
     const unsigned nb = (unsigned)V.nb;
-    for (int i = 0; i < max_steps; i++) {
-        active = active && !(t > R.t_end);
+    for (int i = i_start; i < max_steps; i++) { /* every continuing lane has taken exactly i_start samples */
+        if (active && t > R.t_end) {
+            active = false;
+            st.done = true;
+        }
         if (__ballot(active) == 0ull) break;
-        unsigned long long st0 = 0, st1 = 0;
-        if constexpr (DIAG) st0 = stamp();
         const Cell c = cell_at(R, t);
         const unsigned bx = (unsigned)c.cx >> 2, by = (unsigned)c.cy >> 2, bz = (unsigned)c.cz >> 2;
         const unsigned tag = (bx & 0xffu) | ((by & 0xffu) << 8) | ((bz & 0xffu) << 16);
         const unsigned slot = (bx & 1u) | ((by & 1u) << 1) | ((bz & 1u) << 2);
         const unsigned local = ((unsigned)c.cx & 3u) * 25u + ((unsigned)c.cz & 3u) * 5u + ((unsigned)c.cy & 3u);
         const float* sp = slots + (slot << 7) + local;
-        if constexpr (DIAG) {
-            asm volatile("" ::"v"(tag), "v"(slot), "v"(local));
-            st1 = stamp();
-        }
-        bool need = active;
-        Taps taps = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        bool need = active, use_global = false;
+        Taps taps;
         for (;;) {
+            /* speculative: tag and taps travel together, the taps are only meaningful on a tag match */
             const unsigned tg = tags[slot];
-            Taps tmp;
-            tmp.y00a = sp[0];
-            tmp.y00b = sp[1];
-            tmp.y01a = sp[5];
-            tmp.y01b = sp[6];
-            tmp.y10a = sp[25];
-            tmp.y10b = sp[26];
-            tmp.y11a = sp[30];
-            tmp.y11b = sp[31];
-            const bool ok = need && tg == tag;
-            if (ok) taps = tmp;
-            need = need && !ok;
-            const unsigned long long m = __ballot(need);
-            if (m == 0ull) break;
-            /* miss: the whole wave fetches the first missing lane's brick */
-            const int leader = __builtin_ctzll(m);
+            taps.y00a = sp[0];
+            taps.y00b = sp[1];
+            taps.y01a = sp[5];
+            taps.y01b = sp[6];
+            taps.y10a = sp[25];
+            taps.y10b = sp[26];
+            taps.y11a = sp[30];
+            taps.y11b = sp[31];
+            const bool ok = tg == tag;
+            const unsigned long long miss = __ballot(need && !ok);
+            if (miss == 0ull) break; /* every lane that needs taps has them */
+            const int leader = __builtin_ctzll(miss);
             const unsigned ltag = __builtin_amdgcn_readlane(tag, leader);
             const unsigned lbx = ltag & 0xffu, lby = (ltag >> 8) & 0xffu, lbz = (ltag >> 16) & 0xffu;
             const unsigned lslot = (lbx & 1u) | ((lby & 1u) << 1) | ((lbz & 1u) << 2);
+            if (__ballot(need && ok && slot == lslot) != 0ull) {
+                /* the slot serves other lanes right now: the leader's brick is read from global memory */
+                if (need && tag == ltag) {
+                    use_global = true;
+                    need = false;
+                }
+                continue;
+            }
             const unsigned brick = (lbx * nb + lbz) * nb + lby;
             const gfloat_p src = (gfloat_p)((gchar_p)V.p + (((size_t)brick << 9) + ((unsigned)lane << 3)));
             const float v0 = src[0], v1 = src[1];
@@ -920,46 +938,98 @@ __device__ __forceinline__ bool march_coop(const DFrame& F, const VolRef& V, con
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (DIAG) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(taps.y00a), "v"(taps.y00b), "v"(taps.y01a), "v"(taps.y01b), "v"(taps.y10a),
-                         "v"(taps.y10b), "v"(taps.y11a), "v"(taps.y11b));
-            const unsigned long long st2 = stamp();
-            if (active) {
-                dg->mem += st2 - st1; /* slot lookup (+ fills) until the taps are in registers */
-                dg->iters++;
-                dg->loop += st2 - st0;
+        if (__ballot(use_global) != 0ull) {
+            if (use_global) taps = fetch8<VRT_PATH_BRICK>(V, c.cx, c.cy, c.cz);
+        }
+        unsigned dbyte = 0u;
+        if (V.skip != nullptr && active) dbyte = leap_byte(V, c);
+        const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
+        if (active) {
+            steps++;
+            st.c = c;
+            st.i = i;
+            if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
+                st.hit = true;
+                st.done = true;
+                st.s_hit = s;
+                active = false;
+            } else {
+                t_prev = t;
+                s_prev = s;
+                const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap_from(R, dbyte));
+                t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
             }
         }
-        const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
-        if (active) steps++;
-        const bool hit_now = active && s < __builtin_fmaf(t, F.cone_eps, F.eps_hit);
-        if (hit_now) {
-            hit = true;
-            t_hit = t;
-            s_hit = s;
-            c_hit = c;
-            iter_hit = i;
-        }
-        active = active && !hit_now;
-        if (active) {
-            t_prev = t;
-            s_prev = s;
-        }
-        float leap = 0.0f;
-        if (V.skip != nullptr && active) leap = leap_at(V, R, c);
-        const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
-        const float t_next = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
-        t = active ? t_next : t;
     }
-    /* overshooting hits walk back to the crossing (per lane, taps from global memory) */
-    if (hit && s_hit < 0.0f && iter_hit > 0) t_hit = refine_hit<VRT_PATH_BRICK>(V, R, t_prev, s_prev, t_hit, s_hit, c_hit, steps);
-    return hit;
+    st.t = t;
+    st.t_prev = t_prev;
+    st.s_prev = s_prev;
 }
 
 /*
- * Single-instance kernel on the LDS brick cache (VRT_PATH_BRICK_LDS).  Same tile mapping and
- * per-pixel arithmetic as march_kernel; the two marches (primary, shadow) run with wave-uniform
- * control flow so that every lane can take part in brick fills.
+ * One ray of every lane against the single instance of the scene.  Phase 1: kHeadSteps samples per
+ * lane with taps from the bricks in global memory (most rays finish here).  Phase 2 (only if some
+ * lane is still marching): the LDS tail above.  Returns true on hit with t / cell / iteration.
+ */
+__device__ __forceinline__ bool march_hybrid(const DFrame& F, const VolRef& V, const RaySeg& R, bool act, float* slots,
+                                             unsigned* tags, int lane, float& t_hit, Cell& c_hit, int& iter_hit, unsigned& steps) {
+    MarchState st;
+    st.t = st.t_prev = R.t0;
+    st.s_prev = st.s_hit = 0.0f;
+    st.i = 0;
+    st.hit = false;
+    st.done = !act;
+    st.c = Cell{0, 0, 0, 0.0f, 0.0f, 0.0f};
+    const int max_steps = F.max_steps;
+    const int head = max_steps < kHeadSteps ? max_steps : kHeadSteps;
+    if (act) {
+        float t = st.t, t_prev = st.t_prev, s_prev = 0.0f;
+        int i = 0;
+        Cell c = st.c;
+        for (; i < head; i++) {
+            if (t > R.t_end) {
+                st.done = true;
+                break;
+            }
+            c = cell_at(R, t);
+            const Taps taps = fetch8<VRT_PATH_BRICK>(V, c.cx, c.cy, c.cz);
+            unsigned dbyte = 0u;
+            if (V.skip != nullptr) dbyte = leap_byte(V, c);
+            const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
+            steps++;
+            if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
+                st.hit = true;
+                st.done = true;
+                st.s_hit = s;
+                break;
+            }
+            t_prev = t;
+            s_prev = s;
+            const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap_from(R, dbyte));
+            t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
+        }
+        st.t = t;
+        st.t_prev = t_prev;
+        st.s_prev = s_prev;
+        st.i = i;
+        st.c = c;
+    }
+    const bool cont = act && !st.done && st.i < max_steps;
+    if (__ballot(cont) != 0ull) march_tail_lds(F, V, R, cont, st, head, slots, tags, lane, steps);
+    if (!st.hit) return false;
+    float t = st.t;
+    Cell c = st.c;
+    if (st.s_hit < 0.0f && st.i > 0) t = refine_hit<VRT_PATH_BRICK>(V, R, st.t_prev, st.s_prev, t, st.s_hit, c, steps);
+    t_hit = t;
+    c_hit = c;
+    iter_hit = st.i;
+    return true;
+}
+
+/*
+ * Single-instance kernel with the hybrid march (VRT_PATH_BRICK_LDS).  Same tile mapping and per-pixel
+ * arithmetic as march_kernel; the skeleton is wave-uniform so that every lane can take part in the
+ * brick fills of the LDS phase.
  */
 template <bool DIAG>
 __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame F) {
@@ -1000,7 +1070,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame 
     float t_hit = 0.0f;
     Cell c_hit = {0, 0, 0, 0.0f, 0.0f, 0.0f};
     int iter_hit = 0;
-    const bool hit = march_coop<DIAG>(F, V, R, act, slots, tags, lane, t_hit, c_hit, iter_hit, k.s_primary, &dg);
+    const bool hit = march_hybrid(F, V, R, act, slots, tags, lane, t_hit, c_hit, iter_hit, k.s_primary);
 
     F3 n = f3(0.0f, 0.0f, 0.0f);
     if (hit) {
@@ -1020,7 +1090,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame 
         float ts = 0.0f;
         Cell cs = {0, 0, 0, 0.0f, 0.0f, 0.0f};
         int is = 0;
-        shadowed = march_coop<DIAG>(F, V, Rs, act_s, slots, tags, lane, ts, cs, is, k.s_shadow, &dg);
+        shadowed = march_hybrid(F, V, Rs, act_s, slots, tags, lane, ts, cs, is, k.s_shadow);
     }
     if (valid) {
         F3 color = hit ? shade_hit(F, Vd, d, n, shadowed) : env_lookup(F.env, F.env_size, d);
