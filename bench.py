@@ -3,10 +3,19 @@
 256^3 SDF volume, 1/2/4/8 MI355X).
 
 A "step" is one full frame.  With N ranks (one process per GPU, launched by torch.distributed.run)
-the frame is split into N contiguous row tiles; every rank marches its tile into device memory
-and the tiles are gathered onto rank 0 with one RCCL gather (torch.distributed backend "nccl")
-that overlaps with the next frame's march (two tile buffers).  Strong scaling: the frame is
-fixed, N only changes the tile height.
+the frame is cut into 32-row strips dealt round-robin to the ranks (interleaved row tiles: contiguous
+tiles would put every object row on the middle GPUs); every rank marches its strips into a compact
+device tile with ONE launch and the tiles are gathered onto rank 0 with one RCCL gather
+(torch.distributed backend "nccl") that overlaps with the next frame's march (two tile buffers);
+rank 0 un-shuffles the gathered strips into frame order.  The exchange format is R8G8B8A8_UNORM, the
+reference's own back-buffer precision (DXConstants.cpp:21): at 16 B/pixel rank 0's seven inbound
+xGMI links, not the march, would set the frame time.
+
+Scaling is WEAK by default: the per-GPU ray count is fixed at the 1080p frame of the metric and the
+frame grows with N at constant 16:9 aspect (N=1 1920x1080, N=2 2715x1527, N=4 3840x2160 = config 4's
+frame, N=8 5431x3055), same camera, same scene.  A 1080p frame is ~0.19 ms of GPU work, most of it
+the latency-bound tail of a few hundred grazing rays, so splitting THAT frame 8 ways
+cannot scale; `--scaling strong --workload c4` gives the fixed-4K-frame split of config 4.
 
 Prints ONE JSON line on rank 0 (see the driver contract), extended with "roofline" and
 "cpu_baseline".
@@ -55,6 +64,11 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3sdf", "c4", "c5"])
     ap.add_argument("--path", default="auto", choices=["auto", "dense", "brick", "lds"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = frame grows with N (fixed rays per GPU); strong = the workload's own frame split N ways")
+    ap.add_argument("--output", default="auto", choices=["auto", "f32", "rgba8"],
+                    help="tile pixel format; auto = float4 on one GPU, RGBA8 (the exchange format) on several")
+    ap.add_argument("--strip-rows", type=int, default=32, help="N>1: rows per interleaved strip; 0 = contiguous row tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
@@ -74,15 +88,30 @@ def main() -> None:
             print(f"[bench] WORLD_SIZE={world} but --gpus={args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # VRT_BENCH_BACKEND=gloo: rehearsal of the N>1 code path on a ONE-GPU box (every rank marches on cuda:0,
+    # tiles are staged through host memory and gathered over gloo).  Never a measurement.
+    rehearsal = os.environ.get("VRT_BENCH_BACKEND", "nccl") == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     sc, W, H, max_steps, shadow, label = build_workload(args.workload)
+    if world > 1 and args.scaling == "weak":
+        W, H = int(round(W * world ** 0.5)), int(round(H * world ** 0.5))
+        label += f" -- weak-scaled to {W}x{H} for {world} GPUs"
+    rgba8 = args.output == "rgba8" or (args.output == "auto" and world > 1)
+    strip_rows = args.strip_rows if world > 1 else 0
     path = {"auto": _abi.PATH_AUTO, "dense": _abi.PATH_DENSE, "brick": _abi.PATH_BRICK, "lds": _abi.PATH_BRICK_LDS}[args.path]
     p = v.default_params(W, H, scenes.min_cell(sc), max_steps, shadow=shadow, path=path)
+    if rgba8:
+        p.flags |= _abi.FLAG_OUTPUT_RGBA8
 
     r = v.VHipRenderer(devices=(local_rank,))
     if not r.Start():
@@ -93,8 +122,11 @@ def main() -> None:
 
     from volumetricraytracer_amd.tiles import FrameGather
 
-    fg = FrameGather(H, W, world, rank, dev, buffers=2)  # row tile of this rank + (rank 0) the gathered frames
+    # tile of this rank + (rank 0) the gathered frames
+    pix = torch.uint8 if rgba8 else torch.float32
+    fg = FrameGather(H, W, world, rank, torch.device("cpu") if rehearsal else dev, dtype=pix, buffers=2, strip_rows=strip_rows)
     row0, rows = fg.row0, fg.rows
+    march_tiles = [torch.zeros_like(x, device=dev) for x in fg.tiles] if rehearsal else fg.tiles
     pending = [None, None]
     stream = torch.cuda.current_stream()
 
@@ -103,7 +135,13 @@ def main() -> None:
         if pending[b] is not None:
             pending[b].wait()  # tile buffer b is free again (its gather finished)
             pending[b] = None
-        r.render_rows(p, row0, rows, fg.tiles[b].data_ptr(), stream.cuda_stream)
+            fg.unshuffle(b)  # rank 0, strips: gathered order -> frame order (one strided device copy)
+        if strip_rows > 0:
+            r.render_strips(p, strip_rows, rank, world, fg.strips_per, march_tiles[b].data_ptr(), stream.cuda_stream)
+        else:
+            r.render_rows(p, row0, rows, march_tiles[b].data_ptr(), stream.cuda_stream)
+        if rehearsal:
+            fg.tiles[b].copy_(march_tiles[b])
         if world > 1:
             pending[b] = fg.gather(b, async_op=True)  # RCCL gather over xGMI, overlaps the next frame's march
 
@@ -112,9 +150,11 @@ def main() -> None:
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
+                fg.unshuffle(b)
         torch.cuda.synchronize()
 
     def barrier() -> None:
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -130,14 +170,26 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if rehearsal else dev
+        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
     t = r.last_timing()  # this rank's tile, last frame (every frame is identical)
     kms = r.timing_history(min(args.steps, 200))
+    verified = None
+    if os.environ.get("VRT_BENCH_VERIFY") and rank == 0 and args.steps > 0:
+        # the gathered (and un-shuffled) frame must be the frame one GPU renders alone, bit for bit
+        whole = torch.empty((H, W, 4), dtype=pix, device=dev)
+        r.render_rows(p, 0, H, whole.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        got = fg.frame((args.steps - 1) & 1)
+        verified = bool(torch.equal(got.cpu(), whole.cpu()))
+        if not verified:
+            raise SystemExit("[bench] gathered frame differs from the single-GPU frame")
+        t = dict(t)  # keep the tile's counters (the verification launch overwrote last_timing)
     counts = torch.tensor([t["primary_rays"], t["shadow_rays"], t["primary_steps"], t["shadow_steps"], t["hits"]],
-                          dtype=torch.float64, device=dev)
+                          dtype=torch.float64, device=torch.device("cpu") if rehearsal else dev)
     if world > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     primary, shadow_rays, psteps, ssteps, hits = [float(x) for x in counts.tolist()]
@@ -148,7 +200,7 @@ def main() -> None:
     if rank == 0:
         # roofline of the march kernel on THIS rank's tile: algorithmic bytes / mean
         # kernel time from the hipEvent pairs recorded on the launch stream around every launch
-        alg_bytes = v.algorithmic_bytes(t)
+        alg_bytes = v.algorithmic_bytes(t, 4 if rgba8 else 16)
         k_ms = float(np.mean(kms)) if kms else float("nan")
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if kms else 0.0
         traffic = None
@@ -172,14 +224,19 @@ def main() -> None:
         out = {
             "metric": "Mrays/sec at 1080p, 256^3 SDF volume" if args.workload in ("c3", "c3sdf") else "Mrays/sec",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": W, "height": H, "volume": f"{sc.volumes()[0].N - 1}^3 cells",
                        "max_steps": max_steps, "shadow": bool(shadow), "data_path": args.path,
-                       "parallelism": f"row-tiles x{world}" + (" + RCCL gather" if world > 1 else ""),
+                       "output": "rgba8 (R8G8B8A8_UNORM tiles; march and shading in f32)" if rgba8 else "f32 (float4)",
+                       "parallelism": ("1 GPU" if world == 1 else
+                                       (f"{strip_rows}-row interleaved strips" if strip_rows else "contiguous row tiles") +
+                                       f" x{world} + " + ("gloo gather, REHEARSAL on one GPU" if rehearsal else "RCCL gather to rank 0")),
                        "rays_per_frame": int(rays_per_frame), "samples_per_ray": round((psteps + ssteps) / max(rays_per_frame, 1), 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if verified is not None:
+            out["gathered_frame_equals_single_gpu_frame"] = verified
         print(json.dumps(out), flush=True)
 
     r.Stop()

@@ -44,6 +44,9 @@ extern "C" {
 #define VRT_MAX_INSTANCES    64
 #define VRT_MAX_DEVICES      8
 #define VRT_FLAG_DIAG_TIMELINE 4 /* run the diagnostic kernel build that stamps per-wave timeline records */
+#define VRT_FLAG_OUTPUT_RGBA8 8  /* store R8G8B8A8_UNORM pixels (4 B, R in the low byte, A = 255) instead of float4:
+                                   the reference's back-buffer precision (B8G8R8A8_UNORM, DXConstants.cpp:21);
+                                   value = (uint)(min(c,1)*255 + 0.5) of the float channel the float4 path stores */
 
 enum vrt_status {
     VRT_OK = 0,
@@ -149,7 +152,8 @@ typedef struct vrt_params {
     int32_t path;         /* vrt_data_path */
     int32_t max_bounces;  /* mirror-reflection depth, 0..2 (MAX_RAY_RECURSION_DEPTH 3 = primary + 2) */
     int32_t flags;        /* bits 0-1: blockIdx→tile map, 0 supertile (default) / 1 XCD band / 2 linear
-                             (speed only, never results); bit 2: VRT_FLAG_DIAG_TIMELINE.  Others 0 */
+                             (speed only, never results); bit 2: VRT_FLAG_DIAG_TIMELINE; bit 3:
+                             VRT_FLAG_OUTPUT_RGBA8.  Others 0 */
     float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
     float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
     float step_min;       /* lower bound of one march step (ray-parameter units) */
@@ -199,13 +203,25 @@ int vrt_env_upload(vrt_ctx* ctx, int face_size, const uint8_t* rgba8_faces);
 
 int vrt_scene_set(vrt_ctx* ctx, const vrt_scene* scene);
 
-/* Render the whole frame.  host_rgba_or_null: width*height float4 (RGBA, alpha 1), row-major. */
+/* Render the whole frame.  host_rgba_or_null: width*height float4 (RGBA, alpha 1), row-major
+ * (width*height uint32 R8G8B8A8 when params->flags has VRT_FLAG_OUTPUT_RGBA8). */
 int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null);
 /* Render rows [row0, row0+rows) of the frame on the context's first device into a caller-owned
- * *device* buffer of rows*width float4, asynchronously on `hip_stream` (a hipStream_t, may be
+ * *device* buffer of rows*width float4 (uint32 R8G8B8A8 with VRT_FLAG_OUTPUT_RGBA8), asynchronously on `hip_stream` (a hipStream_t, may be
  * NULL).  No host synchronisation, no allocation: safe to capture into a hipGraph. */
 int vrt_render_rows(vrt_ctx* ctx, const vrt_params* params, int row0, int rows,
                     void* device_rgba, void* hip_stream);
+
+/* Interleaved-strip variant of vrt_render_rows for multi-GPU load balance (static
+ * contiguous row tiles put all the object rows on the middle GPUs).  The frame is cut into strips
+ * of strip_rows rows; this launch renders strips first_strip, first_strip + strip_stride, ...
+ * (n_strips of them; rank g of n passes first_strip = g, strip_stride = n) into a COMPACT device
+ * buffer of n_strips*strip_rows rows x width pixels, strip after strip.  Rows at or beyond
+ * params->height are skipped (their pixels are left untouched).  Same pixels as vrt_render_rows for
+ * the same frame rows; asynchronous on hip_stream like it.  (DispatchRays(W,H,1),
+ * DXRenderer.cpp:827-867 — the reference is single-adapter, NodeMask 0.) */
+int vrt_render_strips(vrt_ctx* ctx, const vrt_params* params, int strip_rows, int first_strip,
+                      int strip_stride, int n_strips, void* device_rgba, void* hip_stream);
 
 int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out);
 /* Kernel durations (ms) of the last n vrt_render_rows/vrt_render launches, oldest first;

@@ -182,6 +182,97 @@ def test_row_tiles_into_device_memory(renderer, oracle_lib):
     assert len(hist) == 3 and all(h > 0 for h in hist)
 
 
+def test_interleaved_strips_into_device_memory(renderer, oracle_lib):
+    """vrt_render_strips: rank g of 3 renders strips g, g+3, … into a compact tile; the union is the
+    oracle frame (ragged last strip; strip slots beyond the frame stay untouched); counters add up."""
+    import torch
+
+    from volumetricraytracer_amd.tiles import strip_frame_rows, strip_layout
+
+    W, H, world, sr = 200, 100, 3, 8
+    sc = scenes.config3_torus(6, 16)
+    p = v.default_params(W, H, scenes.min_cell(sc), 255, shadow=True)
+    renderer.SetSceneToRender(sc)
+    renderer.SyncWithScene()
+    ref, st = OracleScene(sc).render(p, threads=8)
+    total, per = strip_layout(H, world, sr)
+    assert (total, per) == (13, 5)
+    frame = np.full((H, W, 4), np.nan, np.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    rays = steps = 0
+    for g in range(world):
+        tile = torch.full((per * sr, W, 4), -7.0, dtype=torch.float32, device="cuda:0")
+        renderer.render_strips(p, sr, g, world, per, tile.data_ptr(), stream)
+        torch.cuda.synchronize()
+        t = renderer.last_timing()
+        rays += t["primary_rays"]
+        steps += t["primary_steps"] + t["shadow_steps"]
+        host = tile.cpu().numpy()
+        touched = np.zeros(per * sr, bool)
+        for local0, frame0, rows in strip_frame_rows(H, world, g, sr):
+            frame[frame0:frame0 + rows] = host[local0:local0 + rows]
+            touched[local0:local0 + rows] = True
+        assert (host[~touched] == -7.0).all()  # rows beyond the frame are skipped
+    assert rays == W * H and steps == st["primary_steps"] + st["shadow_steps"]
+    assert np.abs(frame - ref).max() <= TOL
+    with pytest.raises(_abi.VrtError):
+        renderer.render_strips(p, sr, 3, 3, per, tile.data_ptr(), stream)  # first_strip must be < strip_stride
+    with pytest.raises(_abi.VrtError):
+        renderer.render_strips(p, 0, 0, 3, per, tile.data_ptr(), stream)
+
+
+def test_rgba8_output_is_the_quantised_float_frame(renderer, oracle_lib):
+    """VRT_FLAG_OUTPUT_RGBA8 (the reference's 8-bit UNORM back-buffer precision, DXConstants.cpp:21): the
+    same pixels as the float4 path, stored as (uint)(min(c,1)*255+0.5).  Bit-exact against the float
+    frame of the same kernel; within 1 LSB of the quantised oracle frame (a 1e-4 float difference can
+    straddle a rounding boundary) with almost every byte equal."""
+    from test_tiles_gloo import quantize_rgba8
+
+    sc = scenes.config5_instances(5, 16)
+    p = v.default_params(320, 180, scenes.min_cell(sc), 255, shadow=True)
+    img, _ = gpu_render(renderer, sc, p)
+    q = _abi.vrt_params.from_buffer_copy(p)
+    q.flags |= _abi.FLAG_OUTPUT_RGBA8
+    img8, t8 = gpu_render(renderer, sc, q)
+    assert img8.dtype == np.uint8 and img8.shape == (180, 320, 4)
+    assert np.array_equal(img8, quantize_rgba8(img))
+    assert (img8[..., 3] == 255).all()
+    ref, st = OracleScene(sc).render(p, threads=8)
+    d = np.abs(img8.astype(np.int16) - quantize_rgba8(ref).astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    assert {k: t8[k] for k in STAT_KEYS} == {k: st[k] for k in STAT_KEYS}
+
+
+def test_bench_two_rank_rehearsal(oracle_lib):
+    """bench.py's N>1 code path end to end with 2 ranks sharing this box's one GPU (strips, RGBA8 tiles,
+    gather, un-shuffle, max-over-ranks timing, counters summed over ranks).  The tiles travel over gloo via
+    host memory here (RCCL needs one GPU per rank); rank 0 checks the gathered frame bit for bit against the
+    frame one GPU renders alone.  A rehearsal of the code path, not a measurement."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VRT_BENCH_BACKEND="gloo", VRT_BENCH_VERIFY="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "c2", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    W, H = int(round(1280 * 2 ** 0.5)), int(round(720 * 2 ** 0.5))
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
+    assert out["config"]["width"] == W and out["config"]["height"] == H
+    assert out["config"]["rays_per_frame"] == W * H  # config 2 has no shadow rays; every pixel rendered exactly once
+    assert out["gathered_frame_equals_single_gpu_frame"] is True
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
 def test_multi_tile_context_on_one_gpu(oracle_lib):
     """A context with two logical devices (the same ordinal twice) exercises the row-tile split
     and the gather into device 0's frame that an 8-GPU context uses."""

@@ -17,6 +17,45 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def quantize_rgba8(img):
+    """The kernel's VRT_FLAG_OUTPUT_RGBA8 rule restated: (uint)(min(c,1)*255 + 0.5), fp32 mul then add."""
+    c = np.minimum(np.asarray(img, dtype=np.float32), np.float32(1.0))
+    return (c * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+
+
+def _strip_worker(rank, world, port, height, width, strip_rows, as_u8, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    import scenes
+    import volumetricraytracer_amd as v
+    from oracle.binding import OracleScene
+    from volumetricraytracer_amd.tiles import FrameGather, strip_frame_rows
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = scenes.config5_instances(5, 16)
+        p = v.default_params(width, height, scenes.min_cell(sc), 255, shadow=True)
+        fg = FrameGather(height, width, world, rank, torch.device("cpu"), dtype=torch.uint8 if as_u8 else torch.float32,
+                         strip_rows=strip_rows)
+        o = OracleScene(sc)
+        for b in range(2):
+            for local0, frame0, rows in strip_frame_rows(height, world, rank, strip_rows):
+                tile, _ = o.render(p, frame0, rows)  # on the GPU: one vrt_render_strips launch for all strips
+                fg.tiles[b][local0:local0 + rows] = torch.from_numpy(quantize_rgba8(tile) if as_u8 else tile)
+            fg.gather(b, async_op=True).wait()
+            fg.unshuffle(b)
+        if rank == 0:
+            np.save(out_path, fg.frame(1).numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, height, width, out_path):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -65,6 +104,49 @@ def test_row_tiles_gather_matches_single_rank(tmp_path, oracle_lib, world, heigh
     got = np.load(out)
     assert got.shape == (height, width, 4)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("world,height,strip_rows,as_u8", [(2, 54, 8, False), (3, 50, 4, False), (2, 37, 16, True)])
+def test_interleaved_strips_gather_matches_single_rank(tmp_path, oracle_lib, world, height, strip_rows, as_u8):
+    """Strips dealt round-robin to the ranks (ragged last strip, empty strip slots), gathered and
+    un-shuffled: rank 0 holds exactly the single-rank frame (float, or the RGBA8 exchange format)."""
+    import torch.multiprocessing as mp
+
+    import scenes
+    import volumetricraytracer_amd as v
+    from oracle.binding import OracleScene
+
+    width = 96
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_strip_worker, args=(world, _free_port(), height, width, strip_rows, as_u8, out), nprocs=world, join=True)
+    sc = scenes.config5_instances(5, 16)
+    p = v.default_params(width, height, scenes.min_cell(sc), 255, shadow=True)
+    ref, _ = OracleScene(sc).render(p)
+    if as_u8:
+        ref = quantize_rgba8(ref)
+    got = np.load(out)
+    assert got.shape == (height, width, 4) and got.dtype == ref.dtype
+    assert np.array_equal(got, ref)
+
+
+def test_strip_layout_partition():
+    from volumetricraytracer_amd.tiles import strip_frame_rows, strip_layout
+
+    for h in (0, 1, 31, 32, 33, 1080, 2160, 3054):
+        for w in (1, 2, 3, 4, 8):
+            for sr in (1, 16, 32):
+                total, per = strip_layout(h, w, sr)
+                assert total == (h + sr - 1) // sr and per * w >= total and (per - 1) * w < max(total, 1)
+                cover = []
+                for r in range(w):
+                    for local0, frame0, rows in strip_frame_rows(h, w, r, sr):
+                        assert local0 % sr == 0 and local0 // sr < per and 0 < rows <= sr
+                        assert (frame0 // sr) % w == r  # strip index dealt round-robin
+                        cover += list(range(frame0, frame0 + rows))
+                assert sorted(cover) == list(range(h))
+    assert strip_layout(3054, 8, 32) == (96, 12)  # 8x the 1080p ray count at 16:9 -> 12 strips of 32 rows per GPU
+    with pytest.raises(ValueError):
+        strip_layout(10, 2, 0)
 
 
 def test_tile_rows_partition():

@@ -35,6 +35,7 @@ MODE_CUBE_NOTEX = 6
 MODE_CUBE_NOTEX_UNLIT = 7
 
 FLAG_DIAG_TIMELINE = 4
+FLAG_OUTPUT_RGBA8 = 8
 
 PATH_AUTO = 0
 PATH_DENSE = 1
@@ -148,6 +149,7 @@ SYMBOLS = {
     "vrt_scene_set": (C.c_int, [C.c_void_p, C.POINTER(vrt_scene)]),
     "vrt_render": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_void_p]),
     "vrt_render_rows": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vrt_render_strips": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vrt_last_timing": (C.c_int, [C.c_void_p, C.POINTER(vrt_timing)]),
     "vrt_timing_history": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "vrt_debug_wave_records": (C.c_longlong, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]),

@@ -466,7 +466,7 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
     if (p->mode < VRT_MODE_INTERP || p->mode > VRT_MODE_CUBE_NOTEX_UNLIT) return VRT_ERR_INVALID;
     if (p->mode >= VRT_MODE_CUBE) return VRT_ERR_UNSUPPORTED; /* Cube* modes: SURVEY §8f */
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_BRICK_LDS) return VRT_ERR_INVALID;
-    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE)) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
+    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8)) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
     if (!ctx->have_scene) return VRT_ERR_NOT_READY;
     return VRT_OK;
 }
@@ -479,8 +479,15 @@ int resolve_path(int path, bool single) {
     return path;
 }
 
-void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, int row0, int rows, float* out,
+/* Rows of one launch: contiguous [row0, row0+rows), or (strip_rows > 0) n_strips interleaved strips. */
+struct RowSet {
+    int row0 = 0, rows = 0;
+    int strip_rows = 0, strip_first = 0, strip_stride = 0;
+};
+
+void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, const RowSet& rs, float* out,
                  unsigned* stats, DFrame& F) {
+    const int row0 = rs.row0, rows = rs.rows;
     memset(&F, 0, sizeof F);
     pack_camera(ctx->scene, p->width, p->height, F);
     F.light_dir[0] = ctx->scene.light_dir[0];
@@ -504,6 +511,10 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.tiles_y = (rows + 15) / 16;
     F.tile_map = p->flags & 3;
     F.diag = (p->flags & VRT_FLAG_DIAG_TIMELINE) ? 1 : 0;
+    F.rgba8 = (p->flags & VRT_FLAG_OUTPUT_RGBA8) ? 1 : 0;
+    F.strip_rows = rs.strip_rows;
+    F.strip_first = rs.strip_first;
+    F.strip_stride = rs.strip_stride;
     /* the lean kernel covers directional light + shadow; the full closest hit is only launched when the
        frame can need it: extra lights, or bounces allowed and some instanced material mirrors (roughness < 0.3) */
     bool smooth = false;
@@ -528,10 +539,10 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
 }
 
 /* Enqueue one tile on one device.  No allocation, no host sync. */
-int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, int row0, int rows, float* out, hipStream_t stream,
+int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet& rs, float* out, hipStream_t stream,
                  int ring) {
     DFrame F;
-    build_frame(ctx, D, p, row0, rows, out, D.d_stats, F);
+    build_frame(ctx, D, p, rs, out, D.d_stats, F);
     if ((long long)F.tiles_x * F.tiles_y > kMaxBlocks / 2) return VRT_ERR_INVALID;
     D.last_blocks = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     D.last_diag = F.diag != 0;
@@ -688,7 +699,10 @@ int vrt_render_rows(vrt_ctx* ctx, const vrt_params* params, int row0, int rows, 
     DeviceState& D = ctx->dev[0];
     HIP_TRY(hipSetDevice(D.ordinal));
     const int ring = (int)(ctx->launches % kRing);
-    rc = enqueue_rows(ctx, D, params, row0, rows, static_cast<float*>(device_rgba), static_cast<hipStream_t>(hip_stream), ring);
+    RowSet rs;
+    rs.row0 = row0;
+    rs.rows = rows;
+    rc = enqueue_rows(ctx, D, params, rs, static_cast<float*>(device_rgba), static_cast<hipStream_t>(hip_stream), ring);
     if (rc != VRT_OK) return rc;
     ctx->launches++;
     ctx->last_devices = 1;
@@ -699,12 +713,38 @@ int vrt_render_rows(vrt_ctx* ctx, const vrt_params* params, int row0, int rows, 
     return VRT_OK;
 }
 
+int vrt_render_strips(vrt_ctx* ctx, const vrt_params* params, int strip_rows, int first_strip, int strip_stride, int n_strips,
+                      void* device_rgba, void* hip_stream) {
+    int rc = check_params(ctx, params);
+    if (rc != VRT_OK) return rc;
+    if (strip_rows < 1 || strip_stride < 1 || first_strip < 0 || first_strip >= strip_stride || n_strips < 0 ||
+        (long long)n_strips * strip_rows > 16384 || (!device_rgba && n_strips > 0))
+        return VRT_ERR_INVALID;
+    DeviceState& D = ctx->dev[0];
+    HIP_TRY(hipSetDevice(D.ordinal));
+    const int ring = (int)(ctx->launches % kRing);
+    RowSet rs;
+    rs.rows = n_strips * strip_rows;
+    rs.strip_rows = strip_rows;
+    rs.strip_first = first_strip;
+    rs.strip_stride = strip_stride;
+    rc = enqueue_rows(ctx, D, params, rs, static_cast<float*>(device_rgba), static_cast<hipStream_t>(hip_stream), ring);
+    if (rc != VRT_OK) return rc;
+    ctx->launches++;
+    ctx->last_devices = 1;
+    ctx->last_w = (uint32_t)params->width;
+    ctx->last_h = (uint32_t)rs.rows;
+    ctx->last_gather_ms = 0.f;
+    ctx->last_total_ms = 0.f;
+    return VRT_OK;
+}
+
 int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null) {
     int rc = check_params(ctx, params);
     if (rc != VRT_OK) return rc;
     const int n = (int)ctx->dev.size();
     const int W = params->width, H = params->height;
-    const size_t row_bytes = (size_t)W * 4 * sizeof(float);
+    const size_t row_bytes = (size_t)W * ((params->flags & VRT_FLAG_OUTPUT_RGBA8) ? 4 : 4 * sizeof(float));
     auto t0 = std::chrono::steady_clock::now();
 
     /* contiguous row tiles, GPU g renders rows [g*H/n, (g+1)*H/n)   */
@@ -740,7 +780,10 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
     for (int g = 0; g < n; g++) {
         DeviceState& D = ctx->dev[(size_t)g];
         HIP_TRY(hipSetDevice(D.ordinal));
-        rc = enqueue_rows(ctx, D, params, r0[(size_t)g], r0[(size_t)g + 1] - r0[(size_t)g], D.fb, D.stream, ring);
+        RowSet rs;
+        rs.row0 = r0[(size_t)g];
+        rs.rows = r0[(size_t)g + 1] - r0[(size_t)g];
+        rc = enqueue_rows(ctx, D, params, rs, D.fb, D.stream, ring);
         if (rc != VRT_OK) return rc;
     }
     ctx->launches++;

@@ -111,7 +111,11 @@ struct DFrame {
     int32_t tile_map;          /* kMapSupertile / kMapBand / kMapLinear */
     int32_t diag;              /* 1: diagnostic kernel build that stamps per-wave timeline records */
     int32_t full;              /* 1: full closest hit needed (point/spot lights, or bounces allowed and a smooth material in the scene) */
-    int32_t pad1_;
+    int32_t rgba8;             /* 1: store R8G8B8A8_UNORM (4 B/pixel) instead of float4 */
+    /* interleaved strips (multi-GPU load balance): local row l of the compact tile is frame row
+       ((l / strip_rows) * strip_stride + strip_first) * strip_rows + l % strip_rows; strip_rows == 0:
+       contiguous rows row0 + l */
+    int32_t strip_rows, strip_first, strip_stride, pad1_;
     /* scene arrays */
     int32_t n_inst, n_nodes;
     int32_t n_point, n_spot;
@@ -123,7 +127,7 @@ struct DFrame {
     const uint8_t* env;        /* 6 x S x S RGBA8 or null */
     int32_t env_size;
     int32_t pad_;
-    float* out;                /* rows x width float4 */
+    float* out;                /* rows x width float4 (or uint32 R8G8B8A8 when rgba8) */
     unsigned* stats;           /* one 8-word record per wave (4 per workgroup): primary_rays, shadow_rays,
                                   bounce_rays, primary_steps, shadow_steps, hits, 0, 0 */
     unsigned* diag_buf;        /* diagnostic build only: 8 words per wave {start, end (100 MHz), hw_id, xcc,

@@ -684,9 +684,28 @@ __device__ __forceinline__ F3 shadow_origin(F3 o, F3 d, float t_hit) {
     return f3(hp.x - d.x * 0.1f, hp.y - d.y * 0.1f, hp.z - d.z * 0.1f);
 }
 
+/* UNORM8 of a tone-mapped channel in [0,1]: round to nearest, the D3D float→UNORM rule (the reference's
+   render target is 8-bit UNORM, DXConstants.cpp:21).  Plain mul + add, no fma, so numpy restates it exactly. */
+__device__ __forceinline__ unsigned unorm8(float c) {
+    return (unsigned)(fminf(c, 1.0f) * 255.0f + 0.5f);
+}
+
 __device__ __forceinline__ void store_pixel(const DFrame& F, int px, int pyl, F3 color) {
-    float4 outp = make_float4(tonemap(color.x), tonemap(color.y), tonemap(color.z), 1.0f);
-    reinterpret_cast<float4*>(F.out)[(size_t)pyl * F.width + px] = outp;
+    const float r = tonemap(color.x), g = tonemap(color.y), b = tonemap(color.z);
+    if (F.rgba8) {
+        reinterpret_cast<unsigned*>(F.out)[(size_t)pyl * F.width + px] = unorm8(r) | unorm8(g) << 8 | unorm8(b) << 16 | 0xff000000u;
+    } else {
+        reinterpret_cast<float4*>(F.out)[(size_t)pyl * F.width + px] = make_float4(r, g, b, 1.0f);
+    }
+}
+
+/* Frame row of local row pyl of this launch's tile (contiguous rows, or interleaved strips). */
+__device__ __forceinline__ int frame_row(const DFrame& F, int pyl) {
+    if (F.strip_rows > 0) {
+        const int s = pyl / F.strip_rows;
+        return (s * F.strip_stride + F.strip_first) * F.strip_rows + (pyl - s * F.strip_rows);
+    }
+    return F.row0 + pyl;
 }
 
 template <int PATH, bool SINGLE, bool DIAG>
@@ -700,8 +719,8 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
     const int lane = (int)threadIdx.x & 63;
     const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
     const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const int py = F.row0 + pyl;
-    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows;
+    const int py = frame_row(F, pyl);
+    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows && py < F.height;
 
     Counters k;
     DiagAcc dg;
@@ -751,8 +770,8 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_full(const DFrame 
     const int lane = (int)threadIdx.x & 63;
     const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
     const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const int py = F.row0 + pyl;
-    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows;
+    const int py = frame_row(F, pyl);
+    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows && py < F.height;
 
     Counters k;
     DiagAcc dg;
@@ -1044,8 +1063,8 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame 
     const int lane = (int)threadIdx.x & 63;
     const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
     const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const int py = F.row0 + pyl;
-    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows;
+    const int py = frame_row(F, pyl);
+    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows && py < F.height;
 
     float* slots = s_slots[wave];
     unsigned* tags = s_tags[wave];

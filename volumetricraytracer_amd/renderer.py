@@ -66,11 +66,12 @@ class VHipRenderer:
         self.Width, self.Height = int(width), int(height)
 
     def Render(self) -> np.ndarray:
-        """One frame: sync scene → device, march, return the float RGBA image [H, W, 4]."""
+        """One frame: sync scene → device, march, return the RGBA image [H, W, 4] (float32, or uint8 when
+        params_override sets FLAG_OUTPUT_RGBA8)."""
         self._require()
         self.SyncWithScene()
         p = self.make_params()
-        out = np.empty((p.height, p.width, 4), dtype=np.float32)
+        out = np.empty((p.height, p.width, 4), dtype=np.uint8 if p.flags & _abi.FLAG_OUTPUT_RGBA8 else np.float32)
         _abi.check(self._lib.vrt_render(self._ctx, C.byref(p), out.ctypes.data_as(C.c_void_p)), "vrt_render")
         return out
 
@@ -140,6 +141,13 @@ class VHipRenderer:
         _abi.check(self._lib.vrt_render_rows(self._ctx, C.byref(params), row0, rows, C.c_void_p(device_ptr),
                                              C.c_void_p(stream)), "vrt_render_rows")
 
+    def render_strips(self, params: _abi.vrt_params, strip_rows: int, first_strip: int, strip_stride: int, n_strips: int,
+                      device_ptr: int, stream: int = 0) -> None:
+        """Asynchronous render of interleaved strips into a compact device tile (vrt_render_strips)."""
+        self._require()
+        _abi.check(self._lib.vrt_render_strips(self._ctx, C.byref(params), strip_rows, first_strip, strip_stride, n_strips,
+                                               C.c_void_p(device_ptr), C.c_void_p(stream)), "vrt_render_strips")
+
     def last_timing(self) -> dict:
         self._require()
         t = _abi.vrt_timing()
@@ -180,6 +188,7 @@ class VHipRenderer:
 
 
 def algorithmic_bytes(t: dict, bytes_per_pixel: int = 16) -> int:
-    """32 B per trilinear sample, 6 samples per hit normal, framebuffer store."""
+    """32 B per trilinear sample, 6 samples per hit normal, one framebuffer store per pixel
+    rendered (= primary ray)."""
     samples = t["primary_steps"] + t["shadow_steps"]
-    return 32 * samples + 32 * 6 * t["hits"] + bytes_per_pixel * t["width"] * t["height"]
+    return 32 * samples + 32 * 6 * t["hits"] + bytes_per_pixel * t["primary_rays"]

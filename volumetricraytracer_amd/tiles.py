@@ -1,10 +1,16 @@
-"""Row-tile partition of a frame across ranks and the gather of the tiles onto rank 0 — the
-multi-GPU step of the hot path (the reference is single-adapter, NodeMask = 0).
+"""Partition of a frame across ranks and the gather of the tiles onto rank 0 — the multi-GPU step
+of the hot path (the reference is single-adapter, NodeMask = 0).
 
-Every rank renders rows [row0, row0+rows) of the same frame from global pixel coordinates, so the
-tiles are seamless.  The tiles are equal-sized buffers (rows_per = ceil(H / world)), gathered with
-ONE collective (`torch.distributed.gather`; backend "nccl" is RCCL over xGMI on MI355X, "gloo" on
-CPU for tests) and trimmed to H rows on the destination."""
+Two partitions, both seamless because every rank renders from global pixel coordinates:
+
+* rows   — rank g renders the contiguous rows [row0, row0+rows) (`vrt_render_rows`);
+* strips — the frame is cut into strips of `strip_rows` rows and rank g renders strips g, g+n, g+2n …
+           into a compact tile (`vrt_render_strips`).  Contiguous tiles put every object row on the
+           middle GPUs and sky on the outer ones; interleaving evens the load (SURVEY §8e "risk").
+
+The tiles are equal-sized buffers gathered with ONE collective (`torch.distributed.gather`; backend
+"nccl" is RCCL over xGMI on MI355X, "gloo" on CPU for tests).  For strips rank 0 then un-shuffles the
+gathered [rank, strip] order into frame order with one strided device copy."""
 from __future__ import annotations
 
 from typing import List, Optional, Tuple
@@ -21,19 +27,54 @@ def tile_rows(height: int, world: int, rank: int) -> Tuple[int, int, int]:
     return rows_per, row0, rows
 
 
-class FrameGather:
-    """Owns the destination frame(s) on rank 0 and issues the gather of one tile per rank."""
+def strip_layout(height: int, world: int, strip_rows: int) -> Tuple[int, int]:
+    """(strips in the frame, strips per rank).  Every rank owns the same number of strip slots; slots
+    whose rows fall beyond the frame stay empty (the kernel skips them)."""
+    if height < 0 or world < 1 or strip_rows < 1:
+        raise ValueError("bad strip request")
+    total = (height + strip_rows - 1) // strip_rows
+    return total, (total + world - 1) // world
 
-    def __init__(self, height: int, width: int, world: int, rank: int, device, dtype=None, buffers: int = 2):
+
+def strip_frame_rows(height: int, world: int, rank: int, strip_rows: int) -> List[Tuple[int, int, int]]:
+    """[(local_row0, frame_row0, rows)] of the strips rank `rank` renders (clipped to the frame)."""
+    if not 0 <= rank < world:
+        raise ValueError("bad rank")
+    _, per = strip_layout(height, world, strip_rows)
+    out = []
+    for s in range(per):
+        fr = (s * world + rank) * strip_rows
+        rows = max(0, min(strip_rows, height - fr))
+        if rows > 0:
+            out.append((s * strip_rows, fr, rows))
+    return out
+
+
+class FrameGather:
+    """Owns this rank's tile buffers and, on rank 0, the gathered frame(s); issues the gather of one
+    tile per rank.  `strip_rows` = 0: contiguous row tiles; > 0: interleaved strips of that height.
+    `dtype` float32 → [rows, W, 4] float RGBA; uint8 → [rows, W, 4] R8G8B8A8."""
+
+    def __init__(self, height: int, width: int, world: int, rank: int, device, dtype=None, buffers: int = 2,
+                 strip_rows: int = 0):
         import torch
 
         self.height, self.width, self.world, self.rank = height, width, world, rank
-        self.rows_per, self.row0, self.rows = tile_rows(height, world, rank)
+        self.strip_rows = int(strip_rows)
+        if self.strip_rows > 0:
+            self.total_strips, self.strips_per = strip_layout(height, world, self.strip_rows)
+            self.rows_per = self.strips_per * self.strip_rows
+            self.row0, self.rows = 0, self.rows_per  # compact tile; see strip_frame_rows for the frame rows
+        else:
+            self.rows_per, self.row0, self.rows = tile_rows(height, world, rank)
         dtype = dtype or torch.float32
         self.tiles = [torch.zeros((self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
-        self.frames: Optional[List] = None
+        self.frames: Optional[List] = None  # gathered tiles, rank-major
+        self.final: Optional[List] = None   # strips only: frame-ordered copies
         if world > 1 and rank == 0:
-            self.frames = [torch.empty((world * self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
+            self.frames = [torch.zeros((world * self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
+            if self.strip_rows > 0:
+                self.final = [torch.zeros((world * self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
 
     def gather(self, b: int, async_op: bool = False):
         """Gather tile buffer `b` of every rank into frame buffer `b` on rank 0."""
@@ -46,10 +87,21 @@ class FrameGather:
             glist = [self.frames[b][k * self.rows_per:(k + 1) * self.rows_per] for k in range(self.world)]
         return dist.gather(self.tiles[b], glist, dst=0, async_op=async_op)
 
+    def unshuffle(self, b: int) -> None:
+        """Strips, rank 0: gathered [rank, strip, row] order → frame order, one strided copy on the
+        current stream (after the gather of buffer `b` has completed)."""
+        if self.strip_rows == 0 or self.world == 1 or self.rank != 0:
+            return
+        n, per, sr, w = self.world, self.strips_per, self.strip_rows, self.width
+        src = self.frames[b].view(n, per, sr, w, 4).permute(1, 0, 2, 3, 4)
+        self.final[b].view(per, n, sr, w, 4).copy_(src)
+
     def frame(self, b: int):
-        """The assembled H x W x 4 frame (rank 0 only; for world == 1 it is the tile itself)."""
+        """The assembled H x W x 4 frame (rank 0 only; for strips call unshuffle(b) first)."""
         if self.world == 1:
             return self.tiles[b][: self.height]
         if self.rank != 0:
             return None
+        if self.strip_rows > 0:
+            return self.final[b][: self.height]
         return self.frames[b][: self.height]
