@@ -231,9 +231,9 @@ int vrt_timing_history(vrt_ctx* ctx, int n, float* kernel_ms_out);
 /* Diagnostics: per-wave records of the last launch on the first device, 8 words each, record
  * index = blockIdx*4 + wave.  which = 0: counters {primary_rays, shadow_rays, bounce_rays,
  * primary_steps, shadow_steps, hits, 0, 0}.  which = 1 (only after a VRT_FLAG_DIAG_TIMELINE launch):
- * {start, end (100 MHz ticks), tap fetches, XCC_ID | HW_ID<<4, longest per-lane sample chain, tap-fetch
- * cycles, march-loop cycles, march-loop iterations} of the lane with the longest chain.  Returns the number of words available and
- * copies min(max_words, that). */
+ * {start, end (100 MHz ticks), iterations whose taps were back within 450 cycles, XCC_ID | HW_ID<<4, longest
+ * per-lane sample chain, tap-fetch cycles, march-loop cycles, march-loop iterations} of the lane with the longest
+ * chain.  Returns the number of words available and copies min(max_words, that). */
 long long vrt_debug_wave_records(vrt_ctx* ctx, int which, uint32_t* out, long long max_words);
 
 const char* vrt_strerror(int status);

@@ -1,0 +1,6 @@
+for w in c3 c3sdf c2 c5; do python bench.py --no-cpu-baseline --workload $w 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        o=json.loads(l); print('$w', 'kernel_us', round(o['roofline']['kernel_ms']*1e3,1), 'Grays/s', round(o['value']/1e3,2), 'frac', o['roofline']['frac'])
+"; done

@@ -130,7 +130,7 @@ struct DFrame {
     float* out;                /* rows x width float4 (or uint32 R8G8B8A8 when rgba8) */
     unsigned* stats;           /* one 8-word record per wave (4 per workgroup): primary_rays, shadow_rays,
                                   bounce_rays, primary_steps, shadow_steps, hits, 0, 0 */
-    unsigned* diag_buf;        /* diagnostic build only: 8 words per wave {start, end (100 MHz), hw_id, xcc,
+    unsigned* diag_buf;        /* diagnostic build only: 8 words per wave {start, end (100 MHz), fast fetches, xcc|hw_id,
                                   longest sample chain, load+lerp cycles, loop cycles, loop iterations} */
 };
 

@@ -184,7 +184,7 @@ struct DiagAcc {
     unsigned long long mem = 0;   /* address ready → interpolated value available (loads + lerps) */
     unsigned long long loop = 0;  /* whole march-loop iterations */
     unsigned iters = 0;           /* march-loop iterations of this lane */
-    unsigned fetches = 0;         /* iterations that had to load a new cell's taps */
+    unsigned fetches = 0;         /* iterations whose taps were back within kDiagFastFetch cycles (every lane hit a cache) */
 };
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
@@ -378,8 +378,9 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
         if constexpr (DIAG) {
             asm volatile("s_waitcnt vmcnt(0)" ::"v"(taps.y00a), "v"(taps.y00b), "v"(taps.y01a), "v"(taps.y01b), "v"(taps.y10a),
                          "v"(taps.y10b), "v"(taps.y11a), "v"(taps.y11b));
-            dg->mem += stamp() - st1; /* address arithmetic + 4 loads until the data is back */
-            dg->fetches++;
+            const unsigned long long lat = stamp() - st1;
+            dg->mem += lat; /* address arithmetic + 4 loads until the data is back */
+            dg->fetches += lat < 450 ? 1u : 0u;
         }
         const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
         if constexpr (DIAG) {
