@@ -56,7 +56,7 @@ enum vrt_status {
     VRT_ERR_OOM = -4,
     VRT_ERR_SLOT = -5,        /* volume slot out of range or empty */
     VRT_ERR_NOT_READY = -6,   /* render without scene / volume */
-    VRT_ERR_UNSUPPORTED = -7  /* render mode not implemented (Cube* modes) */
+    VRT_ERR_UNSUPPORTED = -7  /* feature not implemented (reserved; every EVRenderMode is implemented) */
 };
 
 /* EVRenderMode, Renderer/Public/Renderer.h:32-42 (same numeric values). */

@@ -124,6 +124,9 @@ struct Volume {
        to the surface (capped at 255).  Empty: no leaping. */
     int nb = 0;
     std::vector<uint8_t> skip;
+    /* Cube modes: per brick the Chebyshev distance, in bricks, to the nearest brick that holds a solid
+       voxel (density <= 0 at one of its 4^3 cell-origin voxels); 0 = this brick holds one.  Built on demand. */
+    std::vector<uint8_t> cube_skip;
 };
 
 struct Instance {
@@ -162,35 +165,9 @@ Instance build_instance(const vrt_instance& in) {
     return r;
 }
 
-/*
- * Empty-space table (restates, for the sphere-trace, what the reference's collapsed octree did for
- * its DDA: Voxel/Private/Octree.cpp:70-107,181-262 merges cells without surface).  A brick is
- * "near" when any of its 5^3 samples satisfies density*density_scale < step_max, i.e. holds a
- * trustworthy distance below the clamp.  D[b] = Chebyshev distance in bricks from b to the nearest
- * near brick.  From any point of a brick with D >= 2 the ray may advance (D-1) brick edges: that
- * cannot reach a near brick, and the interpolant is below the clamp only inside near bricks.
- */
-void build_skip_table(Volume& v) {
-    const int nb = v.nb, N = v.N;
-    std::vector<uint8_t> cur((size_t)nb * nb * nb, 255);
-    for (int bx = 0; bx < nb; bx++)
-        for (int bz = 0; bz < nb; bz++)
-            for (int by = 0; by < nb; by++) {
-                bool near = false;
-                for (int lx = 0; lx < 5 && !near; lx++)
-                    for (int lz = 0; lz < 5 && !near; lz++)
-                        for (int ly = 0; ly < 5 && !near; ly++) {
-                            int x = bx * 4 + lx, y = by * 4 + ly, z = bz * 4 + lz;
-                            x = x > N - 1 ? N - 1 : x;
-                            y = y > N - 1 ? N - 1 : y;
-                            z = z > N - 1 ? N - 1 : z;
-                            near = v.den[((size_t)x * N + z) * N + y] * v.density_scale < v.step_max;
-                        }
-                if (near) cur[((size_t)bx * nb + bz) * nb + by] = 0;
-            }
-    /* exact Chebyshev distance transform: three separable passes of a 1-D "distance to the nearest
-       zero, but as a max-combination" do not apply to Chebyshev balls, so dilate instead: D = k for
-       the bricks first covered by the k-th 3x3x3 dilation of the near set. */
+/* In place: entries 0 are seeds, 255 unknown; afterwards D = k for the bricks first covered by the k-th
+   3x3x3 dilation of the seed set (exact Chebyshev distance in bricks, capped at 255). */
+void chebyshev_dilate(std::vector<uint8_t>& cur, int nb) {
     std::vector<uint8_t> nxt(cur.size());
     for (int k = 1; k < 255; k++) {
         bool changed = false;
@@ -218,7 +195,59 @@ void build_skip_table(Volume& v) {
         cur.swap(nxt);
         if (!changed) break;
     }
+}
+
+/*
+ * Empty-space table (restates, for the sphere-trace, what the reference's collapsed octree did for
+ * its DDA: Voxel/Private/Octree.cpp:70-107,181-262 merges cells without surface).  A brick is
+ * "near" when any of its 5^3 samples satisfies density*density_scale < step_max, i.e. holds a
+ * trustworthy distance below the clamp.  D[b] = Chebyshev distance in bricks from b to the nearest
+ * near brick.  From any point of a brick with D >= 2 the ray may advance (D-1) brick edges: that
+ * cannot reach a near brick, and the interpolant is below the clamp only inside near bricks.
+ */
+void build_skip_table(Volume& v) {
+    const int nb = v.nb, N = v.N;
+    std::vector<uint8_t> cur((size_t)nb * nb * nb, 255);
+    for (int bx = 0; bx < nb; bx++)
+        for (int bz = 0; bz < nb; bz++)
+            for (int by = 0; by < nb; by++) {
+                bool near = false;
+                for (int lx = 0; lx < 5 && !near; lx++)
+                    for (int lz = 0; lz < 5 && !near; lz++)
+                        for (int ly = 0; ly < 5 && !near; ly++) {
+                            int x = bx * 4 + lx, y = by * 4 + ly, z = bz * 4 + lz;
+                            x = x > N - 1 ? N - 1 : x;
+                            y = y > N - 1 ? N - 1 : y;
+                            z = z > N - 1 ? N - 1 : z;
+                            near = v.den[((size_t)x * N + z) * N + y] * v.density_scale < v.step_max;
+                        }
+                if (near) cur[((size_t)bx * nb + bz) * nb + by] = 0;
+            }
+    chebyshev_dilate(cur, nb);
     v.skip.swap(cur);
+}
+
+/* Cube modes (SH/Raytracing_Cube*.hlsl): voxel (x,y,z) is the cube [x,x+1)x[y,y+1)x[z,z+1) cells, solid when
+   its density is <= 0 (GetVoxelDensity(currentVoxelPos) <= 0, Raytracing_Cube.hlsl:242).  The table plays the
+   role of the reference's collapsed octree (big empty nodes are crossed in one step). */
+void build_cube_table(Volume& v) {
+    const int nb = v.nb, N = v.N;
+    std::vector<uint8_t> cur((size_t)nb * nb * nb, 255);
+    for (int bx = 0; bx < nb; bx++)
+        for (int bz = 0; bz < nb; bz++)
+            for (int by = 0; by < nb; by++) {
+                bool solid = false;
+                for (int lx = 0; lx < 4 && !solid; lx++)
+                    for (int lz = 0; lz < 4 && !solid; lz++)
+                        for (int ly = 0; ly < 4 && !solid; ly++) {
+                            const int x = bx * 4 + lx, y = by * 4 + ly, z = bz * 4 + lz;
+                            if (x > N - 2 || y > N - 2 || z > N - 2) continue;
+                            solid = v.den[((size_t)x * N + z) * N + y] <= 0.0f;
+                        }
+                if (solid) cur[((size_t)bx * nb + bz) * nb + by] = 0;
+            }
+    chebyshev_dilate(cur, nb);
+    v.cube_skip.swap(cur);
 }
 
 bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env, int env_size,
@@ -248,6 +277,8 @@ bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env
         v.nb = (v.N - 1 + 3) / 4;
         v.skip.clear();
         if (s.step_max > 0.0f) build_skip_table(v);
+        v.cube_skip.clear();
+        if (prm->mode >= VRT_MODE_CUBE) build_cube_table(v);
     }
     P.n_inst = scene->n_instances;
     for (int i = 0; i < P.n_inst; i++) {
@@ -314,9 +345,100 @@ inline bool slab(V3 o, V3 d, float e, float t_cur, float& t_enter, float& t_exit
     return t_exit > t_enter && t_exit >= 0.0f && t_enter <= t_cur;
 }
 
+/*
+ * Cube modes: exact traversal of the voxel grid (SH/Raytracing_Cube.hlsl:142-295; GoToNextVoxel with face
+ * normal, Voxel.hlsli:133-187).  A node is one cell, or — where the table says the nearest solid voxel is D
+ * bricks away — the box of (2D-1)^3 bricks around the current brick, crossed in one step like one of the
+ * reference's merged octree nodes.  The hit is the entry point of the first solid voxel; the normal is the
+ * face the ray came through (the AABB face for the first voxel, (0,0,0) when the ray starts inside the
+ * volume).  One "step" = one node visit.  The crossing axis is chosen in the reference's order (x if
+ * strictly smallest, else y if smaller than z, else z); on that axis the next voxel index is an integer
+ * step, the other two are re-derived from the crossing point and clamped into the node's cross-section.
+ */
+bool march_cube(const Packed& P, int ii, V3 o, V3 d, float t_cur, bool want_normal, float& t_hit, V3& n_world,
+                uint64_t& steps) {
+    const Instance& I = P.inst[ii];
+    const Volume& V = P.vol[I.slot];
+    const float inf = std::numeric_limits<float>::infinity();
+    V3 oo = mul(I.w2o, o - I.pos);
+    V3 od = mul(I.w2o, d);
+    float t_enter, t_exit;
+    if (!slab(oo, od, V.extent, t_cur, t_enter, t_exit)) return false;
+    const float uo[3] = {(oo.x + V.extent) * V.inv_cell, (oo.y + V.extent) * V.inv_cell, (oo.z + V.extent) * V.inv_cell};
+    const V3 udv = od * V.inv_cell;
+    const float ud[3] = {udv.x, udv.y, udv.z};
+    float inv[3];
+    for (int a = 0; a < 3; a++) inv[a] = ud[a] != 0.0f ? 1.0f / ud[a] : inf;
+    const int cmax = V.N - 2;
+    float t = (t_enter > 0.0f ? t_enter : 0.0f) + P.prm.eps_in;
+    const float t_end = minf(t_exit, t_cur);
+    int c[3];
+    for (int a = 0; a < 3; a++) c[a] = (int)minf(maxf(floorf(fmaf(ud[a], t, uo[a])), 0.0f), (float)cmax);
+    int axis_in = -1;
+    for (int i = 0; i < P.prm.max_steps; i++) {
+        if (t > t_end) return false;
+        steps++;
+        const int dist = V.cube_skip[((size_t)(c[0] >> 2) * V.nb + (size_t)(c[2] >> 2)) * V.nb + (size_t)(c[1] >> 2)];
+        int lo[3], hi[3];
+        if (dist == 0) {
+            if (V.den[((size_t)c[0] * V.N + (size_t)c[2]) * V.N + (size_t)c[1]] <= 0.0f) {
+                t_hit = t;
+                if (want_normal) {
+                    V3 n = v3(0.0f, 0.0f, 0.0f);
+                    if (axis_in >= 0) {
+                        const float f = ud[axis_in] > 0.0f ? -1.0f : 1.0f;
+                        n = v3(axis_in == 0 ? f : 0.0f, axis_in == 1 ? f : 0.0f, axis_in == 2 ? f : 0.0f);
+                    } else if (t_enter >= 0.0f) {
+                        /* first voxel of a ray that entered from outside: AABB-face normal (Raytracing_Cube.hlsl:195-212) */
+                        const float tb = t_enter - 0.1f;
+                        V3 rp = v3(fmaf(od.x, tb, oo.x), fmaf(od.y, tb, oo.y), fmaf(od.z, tb, oo.z));
+                        const float e = V.extent;
+                        n.x = rp.x > e ? 1.0f : (rp.x < -e ? -1.0f : 0.0f);
+                        n.y = rp.y > e ? 1.0f : (rp.y < -e ? -1.0f : 0.0f);
+                        n.z = rp.z > e ? 1.0f : (rp.z < -e ? -1.0f : 0.0f);
+                        /* not normalised (the reference normalises only in the interpolated modes) */
+                    }
+                    n_world = mul(I.o2w, n);
+                }
+                return true;
+            }
+            for (int a = 0; a < 3; a++) lo[a] = hi[a] = c[a];
+        } else {
+            for (int a = 0; a < 3; a++) {
+                const int b = c[a] >> 2;
+                lo[a] = (b - (dist - 1)) * 4;
+                hi[a] = (b + (dist - 1)) * 4 + 3;
+                lo[a] = lo[a] < 0 ? 0 : lo[a];
+                hi[a] = hi[a] > cmax ? cmax : hi[a];
+            }
+        }
+        float tx[3];
+        for (int a = 0; a < 3; a++) {
+            const float bound = (float)(ud[a] > 0.0f ? hi[a] + 1 : lo[a]);
+            tx[a] = ud[a] != 0.0f ? (bound - uo[a]) * inv[a] : inf;
+        }
+        const int axis = tx[0] < tx[1] ? (tx[0] < tx[2] ? 0 : 2) : (tx[1] < tx[2] ? 1 : 2);
+        const float t_new = tx[axis];
+        if (!(t_new <= t_end)) return false; /* leaves the march interval (or NaN) before the next node */
+        for (int a = 0; a < 3; a++) {
+            if (a == axis) {
+                c[a] = ud[a] > 0.0f ? hi[a] + 1 : lo[a] - 1;
+            } else {
+                const float u = floorf(fmaf(ud[a], t_new, uo[a]));
+                c[a] = (int)minf(maxf(u, (float)lo[a]), (float)hi[a]);
+            }
+        }
+        if (c[axis] < 0 || c[axis] > cmax) return false;
+        t = maxf(t_new, t);
+        axis_in = axis;
+    }
+    return false;
+}
+
 /* March one instance.  Returns true on hit with t (ray parameter, shared with world space). */
 bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_base, bool want_normal,
                     float& t_hit, V3& n_world, uint64_t& steps) {
+    if (P.prm.mode >= VRT_MODE_CUBE) return march_cube(P, ii, o, d, t_cur, want_normal, t_hit, n_world, steps);
     const Instance& I = P.inst[ii];
     const Volume& V = P.vol[I.slot];
     V3 oo = mul(I.w2o, o - I.pos);
@@ -530,10 +652,14 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
     const Volume& V = P.vol[P.inst[h.inst].slot];
     V3 albedo = v3(V.tint[0], V.tint[1], V.tint[2]);
     int mode = P.prm.mode;
-    if (mode == VRT_MODE_INTERP_UNLIT || mode == VRT_MODE_INTERP_NOTEX_UNLIT) return albedo;
+    if (mode == VRT_MODE_INTERP_UNLIT || mode == VRT_MODE_INTERP_NOTEX_UNLIT || mode == VRT_MODE_CUBE_UNLIT ||
+        mode == VRT_MODE_CUBE_NOTEX_UNLIT)
+        return albedo;
 
     V3 hit_pos = v3(fmaf(d.x, h.t, o.x), fmaf(d.y, h.t, o.y), fmaf(d.z, h.t, o.z));
-    V3 so = v3(hit_pos.x - d.x * 0.1f, hit_pos.y - d.y * 0.1f, hit_pos.z - d.z * 0.1f);
+    /* secondary rays start 0.1 back along the ray (Raytracing.hlsl:52), 0.2 in the Cube modes (Raytracing_Cube.hlsl:52) */
+    const float back = mode >= VRT_MODE_CUBE ? 0.2f : 0.1f;
+    V3 so = v3(hit_pos.x - d.x * back, hit_pos.y - d.y * back, hit_pos.z - d.z * back);
     V3 wo = v3(-d.x, -d.y, -d.z);
     V3 n = h.n_world;
     bool shadows = level < MAX_DEPTH; /* TraceShadowRay's recursion guard, Ray.hlsli:83-86 */
@@ -654,7 +780,7 @@ void render_rows(const Packed& P, int y0, int y1, int row0, float* out, Stats& s
     }
 }
 
-bool mode_supported(int mode) { return mode >= VRT_MODE_INTERP && mode <= VRT_MODE_INTERP_NOTEX_UNLIT; }
+bool mode_supported(int mode) { return mode >= VRT_MODE_INTERP && mode <= VRT_MODE_CUBE_NOTEX_UNLIT; }
 
 }  // namespace
 

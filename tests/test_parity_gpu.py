@@ -88,12 +88,50 @@ def test_unlit_mode_and_modes_without_textures_agree(renderer, oracle_lib):
         lit[mode], _ = assert_parity(renderer, sc, p)
     assert np.array_equal(lit[_abi.MODE_INTERP], lit[_abi.MODE_INTERP_NOTEX])
     assert np.array_equal(lit[_abi.MODE_INTERP_UNLIT], lit[_abi.MODE_INTERP_NOTEX_UNLIT])
-    p = v.default_params(192, 108, cell, 255, mode=_abi.MODE_CUBE)
-    renderer.params_override = p
-    renderer.SetRendererMode(p.mode)
-    with pytest.raises(_abi.VrtError) as e:
-        renderer.Render()
-    assert e.value.status == _abi.VRT_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("scene_name", ["sphere", "torus_shell", "instances", "mirror_lights"])
+def test_cube_modes_parity(renderer, oracle_lib, scene_name):
+    """Cube render modes (SH/Raytracing_Cube*.hlsl): exact voxel-grid traversal with the brick distance table.
+    Same bar as the interpolated modes: <= 1e-4 per channel, node-visit counters exact."""
+    if scene_name == "sphere":
+        sc, w, h = scenes.config2_sphere(), 320, 180
+    elif scene_name == "torus_shell":
+        sc, w, h = scenes.config3_voxelized(6, 16), 320, 180
+    elif scene_name == "instances":
+        sc, w, h = scenes.config5_instances(5, 16), 320, 180
+    else:
+        sc, w, h = scenes.full_closest_hit_scene(), 240, 136
+    cell = scenes.min_cell(sc)
+    imgs = {}
+    for mode in (_abi.MODE_CUBE, _abi.MODE_CUBE_NOTEX, _abi.MODE_CUBE_UNLIT, _abi.MODE_CUBE_NOTEX_UNLIT):
+        p = v.default_params(w, h, cell, 255, shadow=True, mode=mode)
+        p.max_bounces = 2
+        imgs[mode], t = assert_parity(renderer, sc, p, check_stats=(scene_name != "instances" and scene_name != "mirror_lights"))
+        assert t["hits"] > 0
+    assert np.array_equal(imgs[_abi.MODE_CUBE], imgs[_abi.MODE_CUBE_NOTEX])
+    assert np.array_equal(imgs[_abi.MODE_CUBE_UNLIT], imgs[_abi.MODE_CUBE_NOTEX_UNLIT])
+    # the blocky image differs from the interpolated one (the modes really are different paths)
+    p = v.default_params(w, h, cell, 255, shadow=True, mode=_abi.MODE_INTERP_NOTEX)
+    p.max_bounces = 2
+    smooth, _ = gpu_render(renderer, sc, p)
+    assert np.abs(smooth - imgs[_abi.MODE_CUBE_NOTEX]).max() > 0.05
+
+
+def test_cube_mode_edge_cases(renderer, oracle_lib):
+    """Camera inside the volume and inside a solid voxel, 1-step budget, ragged frame, resolution 0 and 1."""
+    sc = scenes.config2_sphere(5, 16)
+    cell = scenes.min_cell(sc)
+    for cam in ((20.0, 3.0, 2.0), (60.0, 1.0, -2.0)):  # inside the solid sphere; inside the volume, outside the sphere
+        sc.Camera = v.VCamera(Position=cam, Rotation=sc.Camera.Rotation)
+        assert_parity(renderer, sc, v.default_params(101, 57, cell, 255, shadow=True, mode=_abi.MODE_CUBE_NOTEX))
+    sc = scenes.config2_sphere(5, 16)
+    assert_parity(renderer, sc, v.default_params(64, 36, cell, 1, mode=_abi.MODE_CUBE_NOTEX))
+    assert_parity(renderer, sc, v.default_params(64, 36, cell, 0, mode=_abi.MODE_CUBE_NOTEX))
+    for res in (0, 1):
+        vol = v.VVoxelVolume(res, 50.0).fill(lambda X, Y, Z: np.sqrt(X * X + Y * Y + Z * Z) - 40.0)
+        s2 = v.VScene(Objects=[v.VVoxelObject(Volume=vol)], Camera=v.look_minus_x_camera(300.0), DirectionalLight=v.demo_light())
+        assert_parity(renderer, s2, v.default_params(64, 36, vol.GetCellSize(), 255, shadow=True, mode=_abi.MODE_CUBE_NOTEX))
 
 
 @pytest.mark.parametrize("name", ["config2_64x36", "config3_96x54", "config5_96x54"])

@@ -7,7 +7,7 @@
  * exactly like VEngine::EngineLoop does (Engine/Private/Engine.cpp:201-232):
  * tick → Renderer->Render() → post-render.  Writes the last frame as a PPM.
  *
- *   vrt_demo [--frames N] [--size WxH] [--scene file.vox] [--out frame.ppm]
+ *   vrt_demo [--frames N] [--size WxH] [--scene file.vox] [--out frame.ppm] [--mode 0..7 (EVRenderMode)]
  */
 #include <chrono>
 #include <cmath>
@@ -59,11 +59,13 @@ int main(int argc, char** argv) {
     int frames = 60;
     unsigned W = 1024, H = 576;
     std::string scenePath, outPath = "vrt_demo.ppm";
+    int mode = 0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--size") && i + 1 < argc) sscanf(argv[++i], "%ux%u", &W, &H);
         else if (!strcmp(argv[i], "--scene") && i + 1 < argc) scenePath = argv[++i];
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) outPath = argv[++i];
+        else if (!strcmp(argv[i], "--mode") && i + 1 < argc) mode = atoi(argv[++i]);
     }
 
     std::shared_ptr<Renderer::VRenderer> renderer = Renderer::VRendererFactory::NewRenderer();
@@ -72,6 +74,7 @@ int main(int argc, char** argv) {
         return 1;
     }
     renderer->ResizeRenderOutput(W, H);
+    if (mode >= 0 && mode <= 7) renderer->SetRendererMode((Renderer::EVRenderMode)mode); /* the reference's F1-F8 switch */
 
     VObjectPtr<Scene::VScene> scene;
     if (!scenePath.empty()) {

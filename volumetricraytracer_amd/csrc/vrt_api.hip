@@ -46,6 +46,7 @@ struct DeviceVolume {
     uint8_t* material = nullptr;
     uint8_t* skip = nullptr;      /* 2 x nb^3 bytes: the empty-space table and its build scratch */
     bool skip_valid = false;      /* table built for the current metric (only when step_max > 0) */
+    uint8_t* cube_skip = nullptr; /* 2 x nb^3 bytes: the Cube modes' distance-to-solid table and its build scratch */
 };
 
 struct DeviceState {
@@ -267,6 +268,7 @@ void fill_dvolume(const HostVolume& h, const DeviceVolume& d, DVolume& out) {
     float r1 = h.mat.roughness + 1.0f;
     out.k = (r1 * r1) / 8.0f; /* RDXVoxelVolume.cpp:383 */
     out.skip = (h.step_max > 0.0f && d.skip_valid) ? d.skip : nullptr;
+    out.cube_skip = d.cube_skip;
 }
 
 /* (Re)builds the empty-space tables of a slot on every device for its current metric. */
@@ -303,6 +305,7 @@ int free_device_volume(DeviceState& D, int slot) {
     if (v.bricks) HIP_TRY(hipFree(v.bricks));
     if (v.material) HIP_TRY(hipFree(v.material));
     if (v.skip) HIP_TRY(hipFree(v.skip));
+    if (v.cube_skip) HIP_TRY(hipFree(v.cube_skip));
     v = DeviceVolume();
     return VRT_OK;
 }
@@ -333,6 +336,7 @@ void destroy_device(DeviceState& D) {
         if (D.vol[i].bricks) (void)hipFree(D.vol[i].bricks);
         if (D.vol[i].material) (void)hipFree(D.vol[i].material);
         if (D.vol[i].skip) (void)hipFree(D.vol[i].skip);
+        if (D.vol[i].cube_skip) (void)hipFree(D.vol[i].cube_skip);
     }
     if (D.d_vols) (void)hipFree(D.d_vols);
     if (D.d_inst) (void)hipFree(D.d_inst);
@@ -387,6 +391,9 @@ int upload_volume(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, cons
                 HIP_TRY(hipMemsetAsync(v.material, 0, count, D.stream));
         }
         HIP_TRY(launch_retile(v.dense, v.bricks, N, nb, D.stream));
+        const size_t nbricks = (size_t)nb * nb * nb;
+        HIP_TRY(hipMalloc(&v.cube_skip, 2 * nbricks));
+        HIP_TRY(launch_cube_table(v.bricks, v.cube_skip, v.cube_skip + nbricks, N, nb, D.stream));
         HIP_TRY(hipStreamSynchronize(D.stream));
     }
     HostVolume& h = ctx->vol[slot];
@@ -464,7 +471,6 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
         !(p->cone_eps >= 0.0f))
         return VRT_ERR_INVALID;
     if (p->mode < VRT_MODE_INTERP || p->mode > VRT_MODE_CUBE_NOTEX_UNLIT) return VRT_ERR_INVALID;
-    if (p->mode >= VRT_MODE_CUBE) return VRT_ERR_UNSUPPORTED; /* Cube* modes: SURVEY §8f */
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_BRICK_LDS) return VRT_ERR_INVALID;
     if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8)) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
     if (!ctx->have_scene) return VRT_ERR_NOT_READY;
@@ -473,7 +479,8 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
 
 /* AUTO picks the fastest measured path; the LDS brick cache is wave-cooperative and currently
  * covers single-instance scenes — multi-instance scenes fall back to bricks in global memory. */
-int resolve_path(int path, bool single) {
+int resolve_path(int path, bool single, int mode) {
+    if (mode >= VRT_MODE_CUBE) return kPathCube; /* exact grid traversal over the bricks, whatever path was asked for */
     if (path == VRT_PATH_AUTO) return VRT_PATH_BRICK;
     if (path == VRT_PATH_BRICK_LDS && !single) return VRT_PATH_BRICK;
     return path;
@@ -501,7 +508,11 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.cone_eps = p->cone_eps;
     F.max_steps = p->max_steps;
     F.shadow = p->shadow ? 1 : 0;
-    F.unlit = (p->mode == VRT_MODE_INTERP_UNLIT || p->mode == VRT_MODE_INTERP_NOTEX_UNLIT) ? 1 : 0;
+    F.unlit = (p->mode == VRT_MODE_INTERP_UNLIT || p->mode == VRT_MODE_INTERP_NOTEX_UNLIT || p->mode == VRT_MODE_CUBE_UNLIT ||
+               p->mode == VRT_MODE_CUBE_NOTEX_UNLIT)
+                  ? 1
+                  : 0;
+    F.back = p->mode >= VRT_MODE_CUBE ? 0.2f : 0.1f; /* Raytracing.hlsl:52 / Raytracing_Cube.hlsl:52 */
     F.max_bounces = p->max_bounces;
     F.width = p->width;
     F.height = p->height;
@@ -552,7 +563,7 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
     }
     HIP_TRY(hipEventRecord(D.ev0[ring], stream));
     const bool single = ctx->scene.n_instances == 1;
-    HIP_TRY(launch_march(F, resolve_path(p->path, single), single, stream));
+    HIP_TRY(launch_march(F, resolve_path(p->path, single, p->mode), single, stream));
     HIP_TRY(hipEventRecord(D.ev1[ring], stream));
     return VRT_OK;
 }

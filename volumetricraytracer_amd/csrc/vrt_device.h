@@ -12,6 +12,7 @@ namespace vrt {
 constexpr int kBrickCells = 4;                 /* cells per brick edge */
 constexpr int kBrickSamples = 5;               /* samples per brick edge (cells + 1 apron) */
 constexpr int kBrickFloats = 128;              /* 125 samples padded to 512 B = 4 x 128-B lines */
+constexpr int kPathCube = 4;                   /* internal data path of the Cube render modes (bricks + cube_skip, exact grid traversal) */
 constexpr int kTile = 8;                       /* one wave = 8x8 pixels */
 constexpr int kBlockThreads = 256;             /* 4 waves = 16x16 pixels */
 constexpr int kMaxBvhNodes = 2 * 64 - 1;
@@ -50,6 +51,8 @@ struct DVolume {
     float pad_[2];
     const uint8_t* skip;   /* nb^3 bytes or null: Chebyshev distance (bricks) to the nearest brick holding a
                               sample closer than step_max to the surface; drives the empty-space leap */
+    const uint8_t* cube_skip; /* nb^3 bytes: Chebyshev distance (bricks) to the nearest brick holding a solid voxel
+                                 (density <= 0 at a cell-origin voxel); the Cube modes' octree stand-in */
 };
 
 struct DInstance {
@@ -115,7 +118,8 @@ struct DFrame {
     /* interleaved strips (multi-GPU load balance): local row l of the compact tile is frame row
        ((l / strip_rows) * strip_stride + strip_first) * strip_rows + l % strip_rows; strip_rows == 0:
        contiguous rows row0 + l */
-    int32_t strip_rows, strip_first, strip_stride, pad1_;
+    int32_t strip_rows, strip_first, strip_stride;
+    float back;                /* secondary rays start this far back along the ray: 0.1, Cube modes 0.2 */
     /* scene arrays */
     int32_t n_inst, n_nodes;
     int32_t n_point, n_spot;

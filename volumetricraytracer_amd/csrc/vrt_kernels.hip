@@ -63,6 +63,7 @@ typedef const uint8_t __attribute__((address_space(1))) * gbyte_p;
 struct VolRef {
     gfloat_p p; /* dense grid or brick pool, by PATH */
     gbyte_p skip; /* empty-space table or null */
+    gbyte_p cube; /* Cube modes: distance-to-solid table */
     int N;
     int nb;
     float extent, inv_cell, dscale, step_max;
@@ -73,6 +74,7 @@ __device__ __forceinline__ VolRef load_vol(const DVolume* __restrict__ v) {
     VolRef r;
     r.p = (gfloat_p)((PATH == VRT_PATH_DENSE) ? v->dense : v->bricks);
     r.skip = (gbyte_p)v->skip;
+    r.cube = (gbyte_p)v->cube_skip;
     r.N = v->N;
     r.nb = v->nb;
     r.extent = v->extent;
@@ -343,6 +345,104 @@ __device__ __forceinline__ F3 hit_normal(const DInstance* __restrict__ I, const 
 }
 
 /*
+ * Cube render modes (SH/Raytracing_Cube*.hlsl:142-295, GoToNextVoxel Voxel.hlsli:133-187): exact traversal of
+ * the voxel grid.  Voxel (x,y,z) is the cube of cell (x,y,z), solid when its density is <= 0.  A node is one
+ * cell, or — where cube_skip says the nearest solid voxel is D bricks away — the box of (2D-1)^3 bricks around
+ * the current brick, crossed in one step like a merged node of the reference's octree.  Hit = entry point of
+ * the first solid voxel, normal = the face the ray came through (AABB face for the first voxel of a ray that
+ * entered from outside, zero when the ray started inside the volume).  One step = one node visit (1 table
+ * byte, + 4 B density in bricks that hold solid voxels).  Restated line by line in oracle march_cube.
+ */
+template <int NORMAL>
+__device__ __forceinline__ bool march_cube(const DFrame& F, const DInstance* __restrict__ I, const DVolume* __restrict__ Vd, F3 o,
+                                           F3 d, float t_cur, float& t_hit, F3& n_world, unsigned& steps) {
+    const VolRef V = load_vol<VRT_PATH_BRICK>(Vd);
+    RaySeg R;
+    if (!setup_ray(F, I, V, o, d, t_cur, 0.0f, R)) return false;
+    const float inf = __builtin_inff();
+    const float ix = R.ud.x != 0.0f ? 1.0f / R.ud.x : inf;
+    const float iy = R.ud.y != 0.0f ? 1.0f / R.ud.y : inf;
+    const float iz = R.ud.z != 0.0f ? 1.0f / R.ud.z : inf;
+    const int cmax = V.N - 2;
+    float t = R.t0;
+    const Cell c0 = cell_at(R, t);
+    int cx = c0.cx, cy = c0.cy, cz = c0.cz;
+    int axis_in = -1;
+    const unsigned nb = (unsigned)V.nb;
+    const int max_steps = F.max_steps;
+    for (int i = 0; i < max_steps; i++) {
+        if (t > R.t_end) return false;
+        steps++;
+        const unsigned brick = mad24(mad24((unsigned)cx >> 2, nb, (unsigned)cz >> 2), nb, (unsigned)cy >> 2);
+        const int dist = (int)V.cube[brick];
+        int lox, hix, loy, hiy, loz, hiz;
+        if (dist == 0) {
+            const unsigned local = ((unsigned)cx & 3u) * 25u + ((unsigned)cz & 3u) * 5u + ((unsigned)cy & 3u);
+            const float den = *(gfloat_p)((gchar_p)V.p + (((brick << 7) + local) << 2));
+            if (den <= 0.0f) {
+                t_hit = t;
+                if constexpr (NORMAL != 0) {
+                    F3 n = f3(0.0f, 0.0f, 0.0f);
+                    if (axis_in >= 0) {
+                        const float udx = axis_in == 0 ? R.ud.x : axis_in == 1 ? R.ud.y : R.ud.z;
+                        const float f = udx > 0.0f ? -1.0f : 1.0f;
+                        n = f3(axis_in == 0 ? f : 0.0f, axis_in == 1 ? f : 0.0f, axis_in == 2 ? f : 0.0f);
+                    } else if (R.t_enter >= 0.0f) {
+                        const float tb = R.t_enter - 0.1f;
+                        const float rx = __builtin_fmaf(R.od.x, tb, R.oo.x);
+                        const float ry = __builtin_fmaf(R.od.y, tb, R.oo.y);
+                        const float rz = __builtin_fmaf(R.od.z, tb, R.oo.z);
+                        const float e = V.extent;
+                        n.x = rx > e ? 1.0f : (rx < -e ? -1.0f : 0.0f);
+                        n.y = ry > e ? 1.0f : (ry < -e ? -1.0f : 0.0f);
+                        n.z = rz > e ? 1.0f : (rz < -e ? -1.0f : 0.0f);
+                    }
+                    n_world = mul33(I->o2w, n);
+                }
+                return true;
+            }
+            lox = hix = cx;
+            loy = hiy = cy;
+            loz = hiz = cz;
+        } else {
+            const int r = dist - 1;
+            lox = ((cx >> 2) - r) * 4;
+            hix = ((cx >> 2) + r) * 4 + 3;
+            loy = ((cy >> 2) - r) * 4;
+            hiy = ((cy >> 2) + r) * 4 + 3;
+            loz = ((cz >> 2) - r) * 4;
+            hiz = ((cz >> 2) + r) * 4 + 3;
+            lox = lox < 0 ? 0 : lox;
+            loy = loy < 0 ? 0 : loy;
+            loz = loz < 0 ? 0 : loz;
+            hix = hix > cmax ? cmax : hix;
+            hiy = hiy > cmax ? cmax : hiy;
+            hiz = hiz > cmax ? cmax : hiz;
+        }
+        const float bx = (float)(R.ud.x > 0.0f ? hix + 1 : lox);
+        const float by = (float)(R.ud.y > 0.0f ? hiy + 1 : loy);
+        const float bz = (float)(R.ud.z > 0.0f ? hiz + 1 : loz);
+        const float tx = R.ud.x != 0.0f ? (bx - R.uo.x) * ix : inf;
+        const float ty = R.ud.y != 0.0f ? (by - R.uo.y) * iy : inf;
+        const float tz = R.ud.z != 0.0f ? (bz - R.uo.z) * iz : inf;
+        const int axis = tx < ty ? (tx < tz ? 0 : 2) : (ty < tz ? 1 : 2);
+        const float t_new = axis == 0 ? tx : axis == 1 ? ty : tz;
+        if (!(t_new <= R.t_end)) return false; /* leaves the march interval (or NaN) before the next node */
+        const float ux = floorf(__builtin_fmaf(R.ud.x, t_new, R.uo.x));
+        const float uy = floorf(__builtin_fmaf(R.ud.y, t_new, R.uo.y));
+        const float uz = floorf(__builtin_fmaf(R.ud.z, t_new, R.uo.z));
+        cx = axis == 0 ? (R.ud.x > 0.0f ? hix + 1 : lox - 1) : (int)__builtin_amdgcn_fmed3f(ux, (float)lox, (float)hix);
+        cy = axis == 1 ? (R.ud.y > 0.0f ? hiy + 1 : loy - 1) : (int)__builtin_amdgcn_fmed3f(uy, (float)loy, (float)hiy);
+        cz = axis == 2 ? (R.ud.z > 0.0f ? hiz + 1 : loz - 1) : (int)__builtin_amdgcn_fmed3f(uz, (float)loz, (float)hiz);
+        const int ca = axis == 0 ? cx : axis == 1 ? cy : cz;
+        if (ca < 0 || ca > cmax) return false;
+        t = maxf_(t_new, t);
+        axis_in = axis;
+    }
+    return false;
+}
+
+/*
  * Sphere-trace one instance (per-lane control flow).  o,d: world-space ray (d normalised).  Returns
  * true on hit and the ray parameter (shared by world and object space — the object-space direction
  * is not re-normalised, DXR semantics).  NORMAL: also produce the world-space normal.
@@ -351,6 +451,9 @@ template <int PATH, int NORMAL /* 0 none, 1 fast length, 2 exact length */, bool
 __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance* __restrict__ I,
                                                const DVolume* __restrict__ Vd, F3 o, F3 d, float t_cur, float t_base,
                                                float& t_hit, F3& n_world, unsigned& steps, DiagAcc* dg = nullptr) {
+    if constexpr (PATH == kPathCube) {
+        return march_cube<NORMAL>(F, I, Vd, o, d, t_cur, t_hit, n_world, steps);
+    } else {
     const VolRef V = load_vol<PATH>(Vd);
     RaySeg R;
     if (!setup_ray(F, I, V, o, d, t_cur, t_base, R)) return false;
@@ -405,6 +508,7 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     if constexpr (NORMAL == 1) n_world = hit_normal<PATH, false>(I, V, R, c, i);
     if constexpr (NORMAL == 2) n_world = hit_normal<PATH, true>(I, V, R, c, i);
     return true;
+    }
 }
 
 /* Closest hit over the scene.  SINGLE: exactly one instance, no BVH, all scene data wave-uniform. */
@@ -679,10 +783,11 @@ __device__ __forceinline__ F3 shade_hit(const DFrame& F, const DVolume* __restri
     return color;
 }
 
-/* Shadow-ray origin: the hit point pulled 0.1 back along the ray (Raytracing.hlsl:51-52). */
-__device__ __forceinline__ F3 shadow_origin(F3 o, F3 d, float t_hit) {
+/* Shadow-ray origin: the hit point pulled 0.1 back along the ray (Raytracing.hlsl:51-52); 0.2 in the Cube
+   modes (Raytracing_Cube.hlsl:52). */
+__device__ __forceinline__ F3 shadow_origin(const DFrame& F, F3 o, F3 d, float t_hit) {
     F3 hp = f3(__builtin_fmaf(d.x, t_hit, o.x), __builtin_fmaf(d.y, t_hit, o.y), __builtin_fmaf(d.z, t_hit, o.z));
-    return f3(hp.x - d.x * 0.1f, hp.y - d.y * 0.1f, hp.z - d.z * 0.1f);
+    return f3(hp.x - d.x * F.back, hp.y - d.y * F.back, hp.z - d.z * F.back);
 }
 
 /* UNORM8 of a tone-mapped channel in [0,1]: round to nearest, the D3D float→UNORM rule (the reference's
@@ -740,7 +845,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
             if (F.shadow && !F.unlit) {
                 k.n_shadow = 1;
                 F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
-                shadowed = trace_any<PATH, SINGLE, DIAG>(F, shadow_origin(o, d, t_hit), ld, 5000.0f, t_hit, k.s_shadow, &dg);
+                shadowed = trace_any<PATH, SINGLE, DIAG>(F, shadow_origin(F, o, d, t_hit), ld, 5000.0f, t_hit, k.s_shadow, &dg);
             }
             color = shade_hit(F, F.vols + F.inst[inst].slot, d, n, shadowed);
         } else {
@@ -802,7 +907,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_full(const DFrame 
                 break;
             }
             const float rough = V->roughness, metal = V->metallic, kk = V->k;
-            const F3 so = shadow_origin(o, d, t_hit);
+            const F3 so = shadow_origin(F, o, d, t_hit);
             const F3 wo = f3(-d.x, -d.y, -d.z);
             const float tb = t_base + t_hit;
             const bool shadows = F.shadow && level < kMaxDepth;
@@ -1105,7 +1210,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame 
         if (want_shadow) {
             k.n_shadow = 1;
             F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
-            act_s = setup_ray(F, I, V, shadow_origin(o, d, t_hit), ld, 5000.0f, t_hit, Rs);
+            act_s = setup_ray(F, I, V, shadow_origin(F, o, d, t_hit), ld, 5000.0f, t_hit, Rs);
         }
         float ts = 0.0f;
         Cell cs = {0, 0, 0, 0.0f, 0.0f, 0.0f};
@@ -1148,6 +1253,26 @@ __global__ __launch_bounds__(128) void skip_seed_kernel(const float* __restrict_
     bool near = false;
     if (l < 125) near = bricks[(size_t)brick * kBrickFloats + l] * density_scale < step_max;
     const unsigned long long any0 = __ballot(near);
+    __shared__ int flag[2];
+    if ((l & 63) == 0) flag[l >> 6] = any0 != 0ull;
+    __syncthreads();
+    if (l == 0) table[brick] = (flag[0] || flag[1]) ? 0 : 255;
+}
+
+/* Cube modes' table, step 1: a brick is a seed (0) when one of its 4^3 cell-origin voxels is solid
+ * (density <= 0); voxels beyond cell N-2 do not exist (only at resolutions < 2, where one brick covers
+ * the volume). */
+__global__ __launch_bounds__(128) void cube_seed_kernel(const float* __restrict__ bricks, uint8_t* __restrict__ table, int N, int nb) {
+    const int brick = (int)blockIdx.x;
+    const int l = (int)threadIdx.x;
+    const int by = brick % nb, bz = (brick / nb) % nb, bx = brick / (nb * nb);
+    bool solid = false;
+    if (l < 125) {
+        const int lx = l / 25, lz = (l / 5) % 5, ly = l % 5;
+        if (lx < 4 && ly < 4 && lz < 4 && bx * 4 + lx <= N - 2 && by * 4 + ly <= N - 2 && bz * 4 + lz <= N - 2)
+            solid = bricks[(size_t)brick * kBrickFloats + l] <= 0.0f;
+    }
+    const unsigned long long any0 = __ballot(solid);
     __shared__ int flag[2];
     if ((l & 63) == 0) flag[l >> 6] = any0 != 0ull;
     __syncthreads();
@@ -1200,6 +1325,15 @@ static hipError_t launch_t(const DFrame& F, hipStream_t stream) {
     return hipGetLastError();
 }
 
+/* Cube modes: no diagnostic instantiation. */
+template <bool SINGLE>
+static hipError_t launch_cube_t(const DFrame& F, hipStream_t stream) {
+    const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
+    if (grid <= 0) return hipSuccess;
+    hipLaunchKernelGGL((march_kernel<kPathCube, SINGLE, false>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
+    return hipGetLastError();
+}
+
 static hipError_t launch_coop(const DFrame& F, hipStream_t stream) {
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
@@ -1219,6 +1353,10 @@ static hipError_t launch_full_t(const DFrame& F, hipStream_t stream) {
 }
 
 hipError_t launch_march(const DFrame& F, int path, bool single, hipStream_t stream) {
+    if (path == kPathCube) {
+        if (F.full) return single ? launch_full_t<kPathCube, true>(F, stream) : launch_full_t<kPathCube, false>(F, stream);
+        return single ? launch_cube_t<true>(F, stream) : launch_cube_t<false>(F, stream);
+    }
     if (F.full) {
         /* full closest hit: per-lane kernels on the dense grid or the bricks */
         if (path == VRT_PATH_DENSE) return single ? launch_full_t<VRT_PATH_DENSE, true>(F, stream) : launch_full_t<VRT_PATH_DENSE, false>(F, stream);
@@ -1234,10 +1372,23 @@ hipError_t launch_retile(const float* dense, float* bricks, int N, int nb, hipSt
     return hipGetLastError();
 }
 
+static hipError_t dilate_table(uint8_t* table, uint8_t* scratch, int nb, hipStream_t stream);
+
 hipError_t launch_skip_table(const float* bricks, uint8_t* table, uint8_t* scratch, int nb, float density_scale, float step_max,
                              hipStream_t stream) {
     const int n = nb * nb * nb;
     hipLaunchKernelGGL(skip_seed_kernel, dim3((unsigned)n), dim3(128), 0, stream, bricks, table, density_scale, step_max);
+    return dilate_table(table, scratch, nb, stream);
+}
+
+hipError_t launch_cube_table(const float* bricks, uint8_t* table, uint8_t* scratch, int N, int nb, hipStream_t stream) {
+    const int n = nb * nb * nb;
+    hipLaunchKernelGGL(cube_seed_kernel, dim3((unsigned)n), dim3(128), 0, stream, bricks, table, N, nb);
+    return dilate_table(table, scratch, nb, stream);
+}
+
+static hipError_t dilate_table(uint8_t* table, uint8_t* scratch, int nb, hipStream_t stream) {
+    const int n = nb * nb * nb;
     uint8_t* cur = table;
     uint8_t* nxt = scratch;
     const int rounds = nb < 254 ? nb : 254;

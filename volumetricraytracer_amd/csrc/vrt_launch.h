@@ -8,12 +8,14 @@
 
 namespace vrt {
 
-/* path: VRT_PATH_DENSE / VRT_PATH_BRICK / VRT_PATH_BRICK_LDS (already resolved, never AUTO). */
+/* path: VRT_PATH_DENSE / VRT_PATH_BRICK / VRT_PATH_BRICK_LDS / kPathCube (already resolved, never AUTO). */
 hipError_t launch_march(const DFrame& frame, int path, bool single_instance, hipStream_t stream);
 hipError_t launch_retile(const float* dense, float* bricks, int N, int nb, hipStream_t stream);
 /* Builds the nb^3-byte empty-space table from the brick pool (scratch: another nb^3 bytes). */
 hipError_t launch_skip_table(const float* bricks, uint8_t* table, uint8_t* scratch, int nb, float density_scale, float step_max,
                              hipStream_t stream);
+/* Cube modes: nb^3-byte Chebyshev distance (bricks) to the nearest brick holding a solid voxel. */
+hipError_t launch_cube_table(const float* bricks, uint8_t* table, uint8_t* scratch, int N, int nb, hipStream_t stream);
 hipError_t launch_split_voxels(const void* voxels, float* density, uint8_t* material, size_t count,
                                hipStream_t stream);
 
