@@ -43,6 +43,7 @@ extern "C" {
 #define VRT_MAX_SPOT_LIGHTS  5  /* RaytracingHlsl.h:113 */
 #define VRT_MAX_INSTANCES    64
 #define VRT_MAX_DEVICES      8
+#define VRT_MAX_TEXTURES     64   /* 2D material textures resident at once (3 per volume slot + spare) */
 #define VRT_FLAG_DIAG_TIMELINE 4 /* run the diagnostic kernel build that stamps per-wave timeline records */
 #define VRT_FLAG_OUTPUT_RGBA8 8  /* store R8G8B8A8_UNORM pixels (4 B, R in the low byte, A = 255) instead of float4:
                                    the reference's back-buffer precision (B8G8R8A8_UNORM, DXConstants.cpp:21);
@@ -196,6 +197,20 @@ int vrt_volume_set_material(vrt_ctx* ctx, int slot, const vrt_material* material
  * safe to take from any sample (<= 0: unbounded). */
 int vrt_volume_set_metric(vrt_ctx* ctx, int slot, float density_scale, float step_max);
 int vrt_volume_free(vrt_ctx* ctx, int slot);
+
+/* 2D material textures — VRenderer::InitializeTexture / UploadToGPU(VTexture) (Renderer/Public/Renderer.h:54-57)
+ * and the scene's geometry-texture table (VRDXScene, RDXScene.cpp:771-800, 905-925).  R8G8B8A8_UNORM, mip 0,
+ * row-major (DXTexture2D.cpp:78-81); sampled with the reference's geometry sampler: point filter, wrap
+ * addressing (RDXScene.cpp:262-270).  id in [0, VRT_MAX_TEXTURES); uploading to a used id replaces it.  Image
+ * decoding (the reference's WIC/DDS loaders, TextureFactory.cpp:58-125) stays with the caller. */
+int vrt_texture_upload(vrt_ctx* ctx, int id, int width, int height, const uint8_t* rgba8);
+int vrt_texture_free(vrt_ctx* ctx, int id);
+
+/* VMaterial::{AlbedoTexturePath, NormalTexturePath, RMTexturePath, TextureScale} (Core/Public/Material.h:29-33;
+ * indices into the texture table, RDXVoxelVolume.cpp:388-391).  id -1 = unbound: an exact identity (white
+ * albedo, factors (1,1), untouched normal).  Only the textured render modes (Interp, Interp_Unlit, Cube,
+ * Cube_Unlit) read them.  scale must be non-zero (default 100, 100). */
+int vrt_volume_set_textures(vrt_ctx* ctx, int slot, int albedo_id, int normal_id, int rm_id, float scale_u, float scale_v);
 
 /* 6 faces (+X,-X,+Y,-Y,+Z,-Z), each face_size^2 RGBA8, row-major, D3D cube-face orientation.
  * NULL / 0 removes the environment (misses read black, like an unbound SRV). */

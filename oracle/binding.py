@@ -20,6 +20,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libvrt_oracle.so")
 
 
+class vrto_texture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
 class vrto_volume(C.Structure):
     _fields_ = [
         ("density", C.c_void_p),
@@ -28,6 +32,10 @@ class vrto_volume(C.Structure):
         ("density_scale", C.c_float),
         ("step_max", C.c_float),
         ("material", _abi.vrt_material),
+        ("albedo_tex", vrto_texture),
+        ("normal_tex", vrto_texture),
+        ("rm_tex", vrto_texture),
+        ("tex_scale", C.c_float * 2),
     ]
 
 
@@ -93,6 +101,14 @@ class OracleScene:
             o.density_scale = v.density_scale
             o.step_max = v.step_max
             o.material = v.Material.to_abi()
+            for name, img in zip(("albedo_tex", "normal_tex", "rm_tex"), v.Material.textures()):
+                if img is not None:
+                    self._keep.append(img)
+                    t = getattr(o, name)
+                    t.rgba8 = img.ctypes.data
+                    t.width, t.height = img.shape[1], img.shape[0]
+            o.tex_scale[0] = float(v.Material.TextureScale[0])
+            o.tex_scale[1] = float(v.Material.TextureScale[1])
         self.env = None
         self.env_size = 0
         if scene.EnvironmentMap is not None:

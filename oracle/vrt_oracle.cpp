@@ -119,6 +119,10 @@ struct Volume {
     int N;
     float extent, cell, inv_cell, density_scale, step_max;
     float tint[3], roughness, metallic, k;
+    float roughness_raw, metallic_raw; /* unclamped material values: the textured modes clamp after the RM texture */
+    vrto_texture tex[3];               /* albedo, normal, rm */
+    float tex_scale[2];
+    bool textured;                     /* any of the three bound */
     /* empty-space table of volumes with a bounded step (step_max finite): per 4^3-cell brick the
        Chebyshev distance, in bricks, to the nearest brick that holds a sample closer than step_max
        to the surface (capped at 255).  Empty: no leaping. */
@@ -272,6 +276,18 @@ bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env
         v.tint[2] = s.material.tint[2];
         v.roughness = minf(maxf(s.material.roughness, 0.0f), 1.0f);
         v.metallic = minf(maxf(s.material.metallic, 0.0f), 1.0f);
+        v.roughness_raw = s.material.roughness;
+        v.metallic_raw = s.material.metallic;
+        v.tex[0] = s.albedo_tex;
+        v.tex[1] = s.normal_tex;
+        v.tex[2] = s.rm_tex;
+        v.tex_scale[0] = s.tex_scale[0];
+        v.tex_scale[1] = s.tex_scale[1];
+        v.textured = false;
+        for (int ti = 0; ti < 3; ti++) {
+            if (v.tex[ti].rgba8 && (v.tex[ti].width <= 0 || v.tex[ti].height <= 0)) return false;
+            v.textured = v.textured || v.tex[ti].rgba8 != nullptr;
+        }
         float r1 = s.material.roughness + 1.0f;
         v.k = (r1 * r1) / 8.0f; /* RDXVoxelVolume.cpp:383, from the unclamped roughness */
         v.nb = (v.N - 1 + 3) / 4;
@@ -635,6 +651,89 @@ void radiance(V3 Li, V3 wi, V3 wo, V3 n, V3 albedo, float rough, float metal, fl
     out = v3((brdf.x * Li.x) * ndwi, (brdf.y * Li.y) * ndwi, (brdf.z * Li.z) * ndwi);
 }
 
+/* ---- tri-planar material textures (SH/Include/Textures.hlsli:16-59, Quaternion.hlsli:18-82) ------------- */
+
+/* Geometry sampler: point filter, wrap addressing (RDXScene.cpp:262-270): texel (floor(frac(u)*W), floor(frac(v)*H)). */
+inline V3 tex_point_wrap(const vrto_texture& T, float u, float v) {
+    float fu = u - floorf(u), fv = v - floorf(v);
+    int x = (int)(fu * (float)T.width), y = (int)(fv * (float)T.height);
+    x = x > T.width - 1 ? T.width - 1 : (x < 0 ? 0 : x);   /* frac can round to 1.0; NaN -> 0 */
+    y = y > T.height - 1 ? T.height - 1 : (y < 0 ? 0 : y);
+    const uint8_t* px = T.rgba8 + ((size_t)y * (size_t)T.width + (size_t)x) * 4;
+    return v3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+}
+
+/* TriSampleTexture: three planar projections of the object-space position, blended by |normal|. */
+inline V3 tri_sample(const vrto_texture& T, const float scale[2], V3 op, V3 blend, bool as_normal) {
+    V3 tx = tex_point_wrap(T, op.z / scale[0], op.y / scale[1]);
+    V3 ty = tex_point_wrap(T, op.x / scale[0], op.z / scale[1]);
+    V3 tz = tex_point_wrap(T, op.x / scale[0], op.y / scale[1]);
+    if (as_normal) {
+        tx = v3(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f);
+        ty = v3(ty.x * 2.0f - 1.0f, ty.y * 2.0f - 1.0f, ty.z * 2.0f - 1.0f);
+        tz = v3(tz.x * 2.0f - 1.0f, tz.y * 2.0f - 1.0f, tz.z * 2.0f - 1.0f);
+    }
+    return v3((tx.x * blend.x + ty.x * blend.y) + tz.x * blend.z, (tx.y * blend.x + ty.y * blend.y) + tz.y * blend.z,
+              (tx.z * blend.x + ty.z * blend.y) + tz.z * blend.z);
+}
+
+struct Q4 { float x, y, z, w; };
+inline Q4 qmul(Q4 a, Q4 b) { /* Quaternion.hlsli:18-24 */
+    return {(b.x * a.w + a.x * b.w) + (a.y * b.z - a.z * b.y), (b.y * a.w + a.y * b.w) + (a.z * b.x - a.x * b.z),
+            (b.z * a.w + a.z * b.w) + (a.x * b.y - a.y * b.x), a.w * b.w - ((a.x * b.x + a.y * b.y) + a.z * b.z)};
+}
+/* fromX(n) = from_to_rotation((1,0,0), n), Quaternion.hlsli:46-82 */
+inline Q4 quat_from_x(V3 n) {
+    const float d = n.x;
+    if (d < -0.999999f) return {0.0f, 0.0f, -1.0f, -4.371139e-08f}; /* half turn about cross(up, x) = -z: (axis*sin(pi/2), cos(pi/2)) in fp32 */
+    if (d > 0.999999f) return {0.0f, 0.0f, 0.0f, 1.0f};
+    Q4 q = {0.0f, -n.z, n.y, 1.0f + d}; /* (cross((1,0,0), n), 1 + d) */
+    const float inv = 1.0f / sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+    return {q.x * inv, q.y * inv, q.z * inv, q.w * inv};
+}
+inline V3 rotate_vector(V3 v, Q4 r) { /* Quaternion.hlsli:26-30 */
+    Q4 rc = {-r.x, -r.y, -r.z, r.w};
+    Q4 t = qmul(r, qmul(Q4{v.x, v.y, v.z, 0.0f}, rc));
+    return v3(t.x, t.y, t.z);
+}
+
+/* Material at a hit in the textured modes.  n_world is the march's normal; the object-space normal the
+   projections are blended by is w2o * n_world (the inverse of the transform that produced it).  Unbound slots
+   are exact identities (white albedo, (1,1) roughness/metal factors, untouched normal) — the reference's
+   8-bit default normal texel (127,127,255) would tilt every normal by 0.3 degrees; not inherited. */
+struct Surface {
+    V3 albedo, n;
+    float roughness, metallic;
+};
+inline Surface textured_surface(const Volume& V, const Instance& I, V3 hit_world, V3 n_world) {
+    Surface s;
+    const V3 op = mul(I.w2o, hit_world - I.pos);
+    const V3 no = mul(I.w2o, n_world);
+    const V3 an = v3(fabsf(no.x), fabsf(no.y), fabsf(no.z));
+    const float sum = (an.x + an.y) + an.z;
+    const V3 blend = v3(an.x / sum, an.y / sum, an.z / sum);
+    s.albedo = v3(V.tint[0], V.tint[1], V.tint[2]);
+    if (V.tex[0].rgba8) {
+        const V3 t = tri_sample(V.tex[0], V.tex_scale, op, blend, false);
+        s.albedo = v3(s.albedo.x * t.x, s.albedo.y * t.y, s.albedo.z * t.z);
+    }
+    s.roughness = V.roughness;
+    s.metallic = V.metallic;
+    if (V.tex[2].rgba8) {
+        const V3 t = tri_sample(V.tex[2], V.tex_scale, op, blend, false);
+        s.roughness = minf(maxf(V.roughness_raw * t.x, 0.0f), 1.0f);
+        s.metallic = minf(maxf(V.metallic_raw * t.y, 0.0f), 1.0f);
+    }
+    s.n = n_world;
+    if (V.tex[1].rgba8) {
+        V3 t = tri_sample(V.tex[1], V.tex_scale, op, blend, true);
+        t = normalize(t);
+        const V3 tn = v3(t.z, t.x, t.y); /* tNormal.zxy */
+        s.n = mul(I.o2w, rotate_vector(tn, quat_from_x(no)));
+    }
+    return s;
+}
+
 const int MAX_DEPTH = 3; /* MAX_RAY_RECURSION_DEPTH, RaytracingHlsl.h:32 */
 
 /* TraceRadianceRay + VRClosestHit / VRMiss, level = 1 for the primary ray. */
@@ -652,16 +751,27 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
     const Volume& V = P.vol[P.inst[h.inst].slot];
     V3 albedo = v3(V.tint[0], V.tint[1], V.tint[2]);
     int mode = P.prm.mode;
+    V3 hit_pos = v3(fmaf(d.x, h.t, o.x), fmaf(d.y, h.t, o.y), fmaf(d.z, h.t, o.z));
+    V3 n = h.n_world;
+    float rough = V.roughness, metal = V.metallic;
+    /* Interp / Cube (and their Unlit variants) sample the material textures; the NoTex variants do not
+       (Raytracing.hlsl:64-70 vs Raytracing_NoTex.hlsl:64-68).  A material without textures is the same either way. */
+    const bool tex_mode = mode == VRT_MODE_INTERP || mode == VRT_MODE_INTERP_UNLIT || mode == VRT_MODE_CUBE || mode == VRT_MODE_CUBE_UNLIT;
+    if (tex_mode && V.textured) {
+        const Surface sf = textured_surface(V, P.inst[h.inst], hit_pos, n);
+        albedo = sf.albedo;
+        n = sf.n;
+        rough = sf.roughness;
+        metal = sf.metallic;
+    }
     if (mode == VRT_MODE_INTERP_UNLIT || mode == VRT_MODE_INTERP_NOTEX_UNLIT || mode == VRT_MODE_CUBE_UNLIT ||
         mode == VRT_MODE_CUBE_NOTEX_UNLIT)
         return albedo;
 
-    V3 hit_pos = v3(fmaf(d.x, h.t, o.x), fmaf(d.y, h.t, o.y), fmaf(d.z, h.t, o.z));
     /* secondary rays start 0.1 back along the ray (Raytracing.hlsl:52), 0.2 in the Cube modes (Raytracing_Cube.hlsl:52) */
     const float back = mode >= VRT_MODE_CUBE ? 0.2f : 0.1f;
     V3 so = v3(hit_pos.x - d.x * back, hit_pos.y - d.y * back, hit_pos.z - d.z * back);
     V3 wo = v3(-d.x, -d.y, -d.z);
-    V3 n = h.n_world;
     bool shadows = level < MAX_DEPTH; /* TraceShadowRay's recursion guard, Ray.hlsli:83-86 */
     V3 diffuse = v3(0.0f, 0.0f, 0.0f); /* SHADOW_BRIGHTNESS */
 
@@ -675,7 +785,7 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
     if (!shadowed) {
         V3 r;
         V3 Li = v3(P.light_strength, P.light_strength, P.light_strength);
-        radiance(Li, P.light_dir, wo, n, albedo, V.roughness, V.metallic, V.k, r);
+        radiance(Li, P.light_dir, wo, n, albedo, rough, metal, V.k, r);
         diffuse = diffuse + r;
     }
 
@@ -699,7 +809,7 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
             if (!sh) {
                 V3 r;
                 radiance(v3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo,
-                         V.roughness, V.metallic, V.k, r);
+                         rough, metal, V.k, r);
                 diffuse = diffuse + r;
             }
         }
@@ -732,7 +842,7 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
             if (!sh) {
                 V3 r;
                 radiance(v3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo,
-                         V.roughness, V.metallic, V.k, r);
+                         rough, metal, V.k, r);
                 diffuse = diffuse + r;
             }
         }
@@ -740,16 +850,16 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
     /* Mirror bounce (Raytracing.hlsl:79-90).  The reference adds it before the direct light; here it is
        added last so that the kernel can evaluate the recursion as a loop with the same rounding
        (colour = direct + reflection at every level). */
-    if (V.roughness < 0.3f && level <= P.prm.max_bounces && level < MAX_DEPTH) {
+    if (rough < 0.3f && level <= P.prm.max_bounces && level < MAX_DEPTH) {
         float dn = dot(d, n);
         V3 rd = normalize(v3(d.x - (2.0f * dn) * n.x, d.y - (2.0f * dn) * n.y, d.z - (2.0f * dn) * n.z));
         st.bounce_rays++;
         V3 rc = radiance_ray(P, so, rd, level + 1, t_base + h.t, st);
-        float fade = V.roughness * 2.2f;
+        float fade = rough * 2.2f;
         rc = v3(maxf(0.0f, rc.x + (0.0f - rc.x) * fade), maxf(0.0f, rc.y + (0.0f - rc.y) * fade),
                 maxf(0.0f, rc.z + (0.0f - rc.z) * fade));
         V3 r;
-        radiance(rc, rd, wo, n, albedo, V.roughness, V.metallic, V.k, r);
+        radiance(rc, rd, wo, n, albedo, rough, metal, V.k, r);
         diffuse = diffuse + r;
     }
     return diffuse;

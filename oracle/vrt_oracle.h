@@ -22,6 +22,12 @@
 extern "C" {
 #endif
 
+/* 2D material texture, R8G8B8A8_UNORM, row-major, mip 0 (DXTexture2D.cpp:78-81); rgba8 NULL = unbound. */
+typedef struct vrto_texture {
+    const uint8_t* rgba8;
+    int32_t width, height;
+} vrto_texture;
+
 typedef struct vrto_volume {
     const float* density;     /* N^3, index x*N*N + z*N + y; NULL = empty slot */
     int32_t resolution;       /* N = 2^resolution + 1 */
@@ -29,6 +35,8 @@ typedef struct vrto_volume {
     float density_scale;
     float step_max;           /* <= 0: unbounded */
     vrt_material material;
+    vrto_texture albedo_tex, normal_tex, rm_tex; /* VMaterial::{Albedo,Normal,RM}TexturePath, Material.h:29-31 */
+    float tex_scale[2];                          /* VMaterial::TextureScale (default 100,100), Material.h:33 */
 } vrto_volume;
 
 typedef struct vrto_stats {

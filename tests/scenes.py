@@ -4,6 +4,8 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
+
 import volumetricraytracer_amd as v
 
 
@@ -104,3 +106,38 @@ def full_closest_hit_scene(resolution: int = 6, env: int = 32) -> v.VScene:
                         Color=(0.6, 1.0, 0.6, 1.0), AttenuationLinear=0.02, AttenuationExp=0.001, FalloffAngle=25.0, Angle=60.0)
     return v.VScene(Camera=v.look_minus_x_camera(420.0, 40.0), DirectionalLight=v.demo_light(), Objects=objs,
                     PointLights=[point], SpotLights=[spot], EnvironmentMap=v.procedural_skybox(env))
+
+
+def procedural_textures(seed: int = 5):
+    """Seeded stand-ins for the reference's material texture files (none ship with it): an albedo checker with
+    per-texel jitter (13x8), a bumpy normal map (16x16, z-dominant) and a roughness/metal map (4x6)."""
+    rng = np.random.default_rng(seed)
+    alb = np.zeros((8, 13, 4), np.uint8)
+    yy, xx = np.mgrid[0:8, 0:13]
+    alb[..., :3] = np.where(((xx + yy) & 1)[..., None] == 0, 235, 90) + rng.integers(-20, 20, size=(8, 13, 3))
+    alb[..., 3] = 255
+    nrm = np.zeros((16, 16, 4), np.uint8)
+    nrm[..., 0] = 128 + rng.integers(-70, 70, size=(16, 16))
+    nrm[..., 1] = 128 + rng.integers(-70, 70, size=(16, 16))
+    nrm[..., 2] = 230
+    nrm[..., 3] = 255
+    rm = np.zeros((6, 4, 4), np.uint8)
+    rm[..., 0] = rng.integers(40, 256, size=(6, 4))
+    rm[..., 1] = rng.integers(0, 256, size=(6, 4))
+    rm[..., 3] = 255
+    return alb, nrm, rm
+
+
+def textured_scene(resolution: int = 6, env: int = 32) -> v.VScene:
+    """full_closest_hit_scene with material textures: all three on the red mirror sphere, albedo only on the blue one,
+    normal + RM on the scaled/rotated CSG object (exercises the object-space projection), shared images."""
+    sc = full_closest_hit_scene(resolution, env)
+    alb, nrm, rm = procedural_textures()
+    vols = sc.volumes()
+    m = vols[0].Material
+    m.AlbedoTexture, m.NormalTexture, m.RMTexture, m.TextureScale = alb, nrm, rm, (37.0, 23.0)
+    vols[1].Material.AlbedoTexture = alb
+    vols[1].Material.TextureScale = (100.0, 100.0)
+    m = vols[2].Material
+    m.NormalTexture, m.RMTexture, m.TextureScale = nrm, rm, (61.0, 44.0)
+    return sc

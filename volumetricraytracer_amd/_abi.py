@@ -10,6 +10,7 @@ import ctypes as C
 import os
 
 VRT_MAX_VOLUMES = 20
+VRT_MAX_TEXTURES = 64
 VRT_MAX_POINT_LIGHTS = 5
 VRT_MAX_SPOT_LIGHTS = 5
 VRT_MAX_INSTANCES = 64
@@ -144,6 +145,9 @@ SYMBOLS = {
     "vrt_volume_upload_voxels": (C.c_int, [C.c_void_p, C.c_int, C.c_uint8, C.c_float, C.c_void_p]),
     "vrt_volume_set_material": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(vrt_material)]),
     "vrt_volume_set_metric": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float]),
+    "vrt_texture_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vrt_texture_free": (C.c_int, [C.c_void_p, C.c_int]),
+    "vrt_volume_set_textures": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]),
     "vrt_volume_free": (C.c_int, [C.c_void_p, C.c_int]),
     "vrt_env_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vrt_scene_set": (C.c_int, [C.c_void_p, C.POINTER(vrt_scene)]),

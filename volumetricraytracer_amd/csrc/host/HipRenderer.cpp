@@ -2,12 +2,57 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #define V_LOG_ERROR(msg) fprintf(stderr, "[VHipRenderer][error] %s\n", (msg))
 #define V_LOG_WARNING(msg) fprintf(stderr, "[VHipRenderer][warning] %s\n", (msg))
 
 namespace VolumeRaytracer {
+
+VObjectPtr<VTexture2D> VTexture2D::LoadPPM(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return nullptr;
+    auto token = [&](char* buf, size_t n) { /* whitespace-separated header token, '#' comments skipped */
+        int c = fgetc(f);
+        while (c != EOF) {
+            if (c == '#') {
+                while (c != EOF && c != '\n') c = fgetc(f);
+            } else if (c == ' ' || c == '\t' || c == '\n' || c == '\r') {
+                c = fgetc(f);
+            } else {
+                break;
+            }
+        }
+        size_t i = 0;
+        while (c != EOF && c != ' ' && c != '\t' && c != '\n' && c != '\r' && i + 1 < n) {
+            buf[i++] = (char)c;
+            c = fgetc(f);
+        }
+        buf[i] = 0;
+        return i > 0;
+    };
+    char magic[8], ws[16], hs[16], ms[16];
+    VObjectPtr<VTexture2D> out;
+    if (token(magic, sizeof magic) && !strcmp(magic, "P6") && token(ws, sizeof ws) && token(hs, sizeof hs) && token(ms, sizeof ms)) {
+        const long w = atol(ws), h = atol(hs), maxv = atol(ms);
+        if (w > 0 && h > 0 && w <= 16384 && h <= 16384 && maxv == 255) {
+            std::vector<uint8_t> rgb((size_t)w * h * 3), rgba((size_t)w * h * 4);
+            if (fread(rgb.data(), 1, rgb.size(), f) == rgb.size()) {
+                for (size_t i = 0; i < (size_t)w * h; i++) {
+                    rgba[i * 4 + 0] = rgb[i * 3 + 0];
+                    rgba[i * 4 + 1] = rgb[i * 3 + 1];
+                    rgba[i * 4 + 2] = rgb[i * 3 + 2];
+                    rgba[i * 4 + 3] = 255;
+                }
+                out = std::make_shared<VTexture2D>((size_t)w, (size_t)h, std::move(rgba));
+            }
+        }
+    }
+    fclose(f);
+    return out;
+}
+
 namespace Renderer {
 
 std::shared_ptr<VRenderer> VRendererFactory::NewRenderer() { return std::make_shared<Hip::VHipRenderer>(); }
@@ -40,6 +85,8 @@ void VHipRenderer::Stop() {
     Ctx = nullptr;
     Uploaded.clear();
     UploadedEnv = nullptr;
+    TextureIds.clear();
+    for (auto& kv : Textures) kv.second.Id = -1;
 }
 
 void VHipRenderer::ResizeRenderOutput(unsigned int width, unsigned int height) {
@@ -66,6 +113,49 @@ void VHipRenderer::UploadToGPU(VObjectPtr<VTextureCube> texture) {
     if (ok(vrt_env_upload(Ctx, (int)texture->GetWidth(), texture->GetPixels().data()), "vrt_env_upload")) UploadedEnv = texture.get();
 }
 
+void VHipRenderer::InitializeTexture(VObjectPtr<VTexture2D>) { /* nothing to create ahead of the upload */ }
+
+void VHipRenderer::UploadToGPU(VObjectPtr<VTexture2D> texture) {
+    if (!Ctx) {
+        V_LOG_WARNING("UploadToGPU on an inactive renderer");
+        return;
+    }
+    if (!texture || TextureIds.count(texture.get())) return;
+    if (texture->GetPixels().size() != texture->GetWidth() * texture->GetHeight() * 4 || texture->GetWidth() == 0) {
+        V_LOG_ERROR("2D texture must hold width*height RGBA8 texels");
+        return;
+    }
+    const int id = (int)TextureIds.size();
+    if (id >= VRT_MAX_TEXTURES) {
+        V_LOG_ERROR("too many material textures");
+        return;
+    }
+    if (ok(vrt_texture_upload(Ctx, id, (int)texture->GetWidth(), (int)texture->GetHeight(), texture->GetPixels().data()), "vrt_texture_upload"))
+        TextureIds[texture.get()] = id;
+}
+
+void VHipRenderer::RegisterTexture(const std::string& path, VObjectPtr<VTexture2D> texture) {
+    TextureEntry e;
+    e.Texture = std::move(texture);
+    Textures[path] = e;
+}
+
+/* Device texture id of the image a material path names, -1 = unbound. */
+int VHipRenderer::ResolveTexture(const std::string& path) {
+    if (path.empty()) return -1;
+    auto it = Textures.find(path);
+    if (it == Textures.end()) {
+        TextureEntry e;
+        e.Texture = VTexture2D::LoadPPM(path);
+        if (!e.Texture) fprintf(stderr, "[VHipRenderer][warning] material texture '%s' is neither registered nor a binary PPM; left unbound\n", path.c_str());
+        it = Textures.emplace(path, e).first;
+    }
+    if (!it->second.Texture) return -1;
+    UploadToGPU(it->second.Texture);
+    auto id = TextureIds.find(it->second.Texture.get());
+    return id == TextureIds.end() ? -1 : id->second;
+}
+
 bool VHipRenderer::SyncWithScene(Scene::VScene& scene) {
     /* geometry: upload new / dirty volumes, free vanished slots (VRDXScene::UpdateSceneGeometry) */
     const auto volumes = scene.GetAllRegisteredVolumes();
@@ -88,6 +178,9 @@ bool VHipRenderer::SyncWithScene(Scene::VScene& scene) {
         vrt_material mat = {{m.AlbedoColor.R, m.AlbedoColor.G, m.AlbedoColor.B, m.AlbedoColor.A}, m.Roughness, m.Metallic};
         if (!ok(vrt_volume_set_material(Ctx, (int)slot, &mat), "vrt_volume_set_material")) return false;
         if (!ok(vrt_volume_set_metric(Ctx, (int)slot, v.DensityScale, v.StepMax), "vrt_volume_set_metric")) return false;
+        const int ta = ResolveTexture(m.AlbedoTexturePath), tn = ResolveTexture(m.NormalTexturePath), tr = ResolveTexture(m.RMTexturePath);
+        const float su = m.TextureScale.X != 0.f ? m.TextureScale.X : 100.f, sv = m.TextureScale.Y != 0.f ? m.TextureScale.Y : 100.f;
+        if (!ok(vrt_volume_set_textures(Ctx, (int)slot, ta, tn, tr, su, sv), "vrt_volume_set_textures")) return false;
         MinCell = (MinCell == 0.f || v.GetCellSize() < MinCell) ? v.GetCellSize() : MinCell;
     }
     for (size_t slot = volumes.size(); slot < Uploaded.size(); slot++)

@@ -9,6 +9,8 @@
  * Error convention of the reference: Start() returns bool, everything else logs and returns.
  */
 #pragma once
+#include <map>
+#include <string>
 #include <vector>
 #include "../../../include/vrt.h"
 #include "HostRenderer.h"
@@ -28,7 +30,14 @@ public:
     bool IsActive() const override { return Ctx != nullptr; }
     void InitializeTexture(VObjectPtr<VTextureCube> texture) override;
     void UploadToGPU(VObjectPtr<VTextureCube> texture) override;
+    void InitializeTexture(VObjectPtr<VTexture2D> texture) override;
+    void UploadToGPU(VObjectPtr<VTexture2D> texture) override;
     void ResizeRenderOutput(unsigned int width, unsigned int height) override;
+
+    /* Material textures are looked up by the path a VMaterial names (the reference's path-keyed table,
+       RDXScene.cpp:771-800, 905-925).  An application that decodes its own images registers them here; paths
+       nobody registered are tried once as binary PPM files and otherwise stay unbound (logged). */
+    void RegisterTexture(const std::string& path, VObjectPtr<VTexture2D> texture);
 
     /* backend-specific */
     void SetDevices(const std::vector<int>& hipOrdinals) { Devices = hipOrdinals; } /* before Start(); default {0} */
@@ -50,6 +59,13 @@ private:
     std::vector<float> Frame;
     std::vector<const Voxel::VVoxelVolume*> Uploaded; /* per slot */
     const VTextureCube* UploadedEnv = nullptr;
+    struct TextureEntry {
+        VObjectPtr<VTexture2D> Texture; /* null: lookup failed, do not retry */
+        int Id = -1;                    /* index in the device table once uploaded */
+    };
+    std::map<std::string, TextureEntry> Textures;
+    std::map<const VTexture2D*, int> TextureIds;
+    int ResolveTexture(const std::string& path);
     float MinCell = 1.f;
 };
 

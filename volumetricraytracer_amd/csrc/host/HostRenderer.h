@@ -1,7 +1,7 @@
 /*
  * HostRenderer.h — the reference's abstract renderer surface, verbatim in shape:
  * Renderer/Public/Renderer.h:32-66 (EVRenderMode, VRenderer), Renderer/Public/RendererFactory.h:24-28.
- * VTexture is reduced to VTextureCube (HostScene.h); 2D/3D textures are out of scope.
+ * VTexture is reduced to VTextureCube (sky) and VTexture2D (material textures), HostScene.h.
  */
 #pragma once
 #include <memory>
@@ -31,6 +31,8 @@ public:
     virtual void SetSceneToRender(VObjectPtr<Scene::VScene> scene) { SceneRef = scene; }
     virtual void InitializeTexture(VObjectPtr<VTextureCube> texture) = 0;
     virtual void UploadToGPU(VObjectPtr<VTextureCube> texture) = 0;
+    virtual void InitializeTexture(VObjectPtr<VTexture2D> texture) = 0;
+    virtual void UploadToGPU(VObjectPtr<VTexture2D> texture) = 0;
     virtual void ResizeRenderOutput(unsigned int width, unsigned int height) = 0;
     void SetRendererMode(const EVRenderMode& renderMode) { RenderMode = renderMode; }
 

@@ -36,6 +36,23 @@ private:
     std::vector<uint8_t> Pixels;
 };
 
+/* VTexture2D reduced to what the closest-hit shader samples: one mip of R8G8B8A8_UNORM, row-major
+   (Renderer/DX/Private/DXTexture2D.cpp:63-81).  Decoding image files (the reference's WIC/DDS path,
+   Renderer/Private/TextureFactory.cpp:58-125) is the application's job; LoadPPM covers binary PPM (P6). */
+class VTexture2D {
+public:
+    VTexture2D(size_t width, size_t height, std::vector<uint8_t> rgba8) : Width(width), Height(height), Pixels(std::move(rgba8)) {}
+    size_t GetWidth() const { return Width; }
+    size_t GetHeight() const { return Height; }
+    const std::vector<uint8_t>& GetPixels() const { return Pixels; }
+    /* nullptr when the file is missing or not an 8-bit P6 image */
+    static VObjectPtr<VTexture2D> LoadPPM(const std::string& path);
+
+private:
+    size_t Width, Height;
+    std::vector<uint8_t> Pixels;
+};
+
 namespace Scene {
 
 class VScene;

@@ -38,6 +38,13 @@ struct HostVolume {
     float density_scale = 1.f;
     float step_max = 0.f; /* <= 0: unbounded */
     vrt_material mat = {{0.8f, 0.8f, 0.8f, 1.0f}, 0.8f, 0.0f};
+    int tex[3] = {-1, -1, -1};            /* albedo, normal, rm texture ids; -1 unbound */
+    float tex_scale[2] = {100.f, 100.f};  /* VMaterial::TextureScale default, Material.h:33 */
+};
+
+struct HostTexture {
+    bool used = false;
+    int width = 0, height = 0;
 };
 
 struct DeviceVolume {
@@ -59,6 +66,7 @@ struct DeviceState {
     DPointLight* d_point = nullptr;
     DSpotLight* d_spot = nullptr;
     uint8_t* d_env = nullptr;
+    uint8_t* tex[VRT_MAX_TEXTURES] = {};
     float* fb = nullptr;
     size_t fb_bytes = 0;
     unsigned* d_stats = nullptr; /* kMaxBlocks x 4 x kStatRecord: per-wave records of the last launch */
@@ -75,6 +83,7 @@ struct DeviceState {
 struct vrt_ctx {
     std::vector<DeviceState> dev;
     HostVolume vol[VRT_MAX_VOLUMES];
+    HostTexture tex[VRT_MAX_TEXTURES];
     int env_size = 0;
     bool have_scene = false;
     vrt_scene scene;
@@ -248,9 +257,21 @@ int build_bvh(std::vector<int>& ids, int begin, int end, const std::vector<Box>&
     return me;
 }
 
-void fill_dvolume(const HostVolume& h, const DeviceVolume& d, DVolume& out) {
+void fill_dvolume(const vrt_ctx* ctx, const DeviceState& D, const HostVolume& h, const DeviceVolume& d, DVolume& out) {
     memset(&out, 0, sizeof out);
     if (!h.used) return;
+    for (int i = 0; i < 3; i++) {
+        const int id = h.tex[i];
+        if (id >= 0 && ctx->tex[id].used) {
+            out.tex_px[i] = D.tex[id];
+            out.tex_w[i] = ctx->tex[id].width;
+            out.tex_h[i] = ctx->tex[id].height;
+        }
+    }
+    out.tex_scale[0] = h.tex_scale[0];
+    out.tex_scale[1] = h.tex_scale[1];
+    out.roughness_raw = h.mat.roughness;
+    out.metallic_raw = h.mat.metallic;
     out.dense = d.dense;
     out.bricks = d.bricks;
     out.N = h.N;
@@ -291,7 +312,7 @@ int rebuild_skip(vrt_ctx* ctx, int slot) {
 int sync_volume_table(vrt_ctx* ctx) {
     DVolume table[VRT_MAX_VOLUMES];
     for (auto& D : ctx->dev) {
-        for (int i = 0; i < VRT_MAX_VOLUMES; i++) fill_dvolume(ctx->vol[i], D.vol[i], table[i]);
+        for (int i = 0; i < VRT_MAX_VOLUMES; i++) fill_dvolume(ctx, D, ctx->vol[i], D.vol[i], table[i]);
         HIP_TRY(hipSetDevice(D.ordinal));
         HIP_TRY(hipMemcpy(D.d_vols, table, sizeof table, hipMemcpyHostToDevice));
     }
@@ -344,6 +365,8 @@ void destroy_device(DeviceState& D) {
     if (D.d_point) (void)hipFree(D.d_point);
     if (D.d_spot) (void)hipFree(D.d_spot);
     if (D.d_env) (void)hipFree(D.d_env);
+    for (int i = 0; i < VRT_MAX_TEXTURES; i++)
+        if (D.tex[i]) (void)hipFree(D.tex[i]);
     if (D.fb) (void)hipFree(D.fb);
     if (D.d_stats) (void)hipFree(D.d_stats);
     if (D.d_diag) (void)hipFree(D.d_diag);
@@ -407,6 +430,8 @@ int upload_volume(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, cons
         h.density_scale = 1.0f;
         h.step_max = 0.0f;
         h.mat = vrt_material{{0.8f, 0.8f, 0.8f, 1.0f}, 0.8f, 0.0f};
+        h.tex[0] = h.tex[1] = h.tex[2] = -1;
+        h.tex_scale[0] = h.tex_scale[1] = 100.f;
     }
     int rc = rebuild_skip(ctx, slot);
     if (rc != VRT_OK) return rc;
@@ -533,7 +558,16 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
         const HostVolume& hv = ctx->vol[ctx->scene.instances[i].volume_slot];
         smooth = smooth || std::min(std::max(hv.mat.roughness, 0.0f), 1.0f) < 0.3f;
     }
-    F.full = (ctx->scene.n_point_lights > 0 || ctx->scene.n_spot_lights > 0 || (p->max_bounces > 0 && smooth)) ? 1 : 0;
+    /* textured modes read the material textures; a frame needs that code only when a bound texture is in sight */
+    const bool tex_mode = p->mode == VRT_MODE_INTERP || p->mode == VRT_MODE_INTERP_UNLIT || p->mode == VRT_MODE_CUBE ||
+                          p->mode == VRT_MODE_CUBE_UNLIT;
+    bool textured = false;
+    for (int i = 0; tex_mode && i < ctx->scene.n_instances; i++) {
+        const HostVolume& hv = ctx->vol[ctx->scene.instances[i].volume_slot];
+        for (int k = 0; k < 3; k++) textured = textured || (hv.tex[k] >= 0 && ctx->tex[hv.tex[k]].used);
+    }
+    F.textured = textured ? 1 : 0;
+    F.full = (ctx->scene.n_point_lights > 0 || ctx->scene.n_spot_lights > 0 || (p->max_bounces > 0 && smooth) || textured) ? 1 : 0;
     F.n_inst = ctx->scene.n_instances;
     F.n_nodes = ctx->n_nodes;
     F.n_point = std::min(ctx->scene.n_point_lights, VRT_MAX_POINT_LIGHTS);
@@ -647,6 +681,58 @@ int vrt_volume_set_metric(vrt_ctx* ctx, int slot, float density_scale, float ste
     ctx->vol[slot].step_max = step_max;
     int rc = rebuild_skip(ctx, slot);
     if (rc != VRT_OK) return rc;
+    return sync_volume_table(ctx);
+}
+
+int vrt_texture_upload(vrt_ctx* ctx, int id, int width, int height, const uint8_t* rgba8) {
+    if (!ctx || id < 0 || id >= VRT_MAX_TEXTURES || width < 1 || height < 1 || width > 16384 || height > 16384 || !rgba8)
+        return VRT_ERR_INVALID;
+    const size_t bytes = (size_t)width * height * 4;
+    for (auto& D : ctx->dev) {
+        HIP_TRY(hipSetDevice(D.ordinal));
+        HIP_TRY(hipDeviceSynchronize()); /* frames in flight may still sample the old image */
+        if (D.tex[id]) {
+            HIP_TRY(hipFree(D.tex[id]));
+            D.tex[id] = nullptr;
+        }
+        HIP_TRY(hipMalloc(&D.tex[id], bytes));
+        HIP_TRY(hipMemcpy(D.tex[id], rgba8, bytes, hipMemcpyHostToDevice));
+    }
+    ctx->tex[id].used = true;
+    ctx->tex[id].width = width;
+    ctx->tex[id].height = height;
+    return sync_volume_table(ctx);
+}
+
+int vrt_texture_free(vrt_ctx* ctx, int id) {
+    if (!ctx || id < 0 || id >= VRT_MAX_TEXTURES) return VRT_ERR_INVALID;
+    if (!ctx->tex[id].used) return VRT_ERR_SLOT;
+    for (auto& D : ctx->dev) {
+        HIP_TRY(hipSetDevice(D.ordinal));
+        HIP_TRY(hipDeviceSynchronize());
+        if (D.tex[id]) HIP_TRY(hipFree(D.tex[id]));
+        D.tex[id] = nullptr;
+    }
+    ctx->tex[id] = HostTexture();
+    return sync_volume_table(ctx); /* volumes that referenced it read as unbound */
+}
+
+int vrt_volume_set_textures(vrt_ctx* ctx, int slot, int albedo_id, int normal_id, int rm_id, float scale_u, float scale_v) {
+    if (!ctx || scale_u == 0.0f || scale_v == 0.0f || !(scale_u == scale_u) || !(scale_v == scale_v)) return VRT_ERR_INVALID;
+    if (!valid_slot(slot) || !ctx->vol[slot].used) return VRT_ERR_SLOT;
+    const int ids[3] = {albedo_id, normal_id, rm_id};
+    for (int i = 0; i < 3; i++) {
+        if (ids[i] < -1 || ids[i] >= VRT_MAX_TEXTURES) return VRT_ERR_INVALID;
+        if (ids[i] >= 0 && !ctx->tex[ids[i]].used) return VRT_ERR_SLOT;
+    }
+    for (auto& D : ctx->dev) {
+        HIP_TRY(hipSetDevice(D.ordinal));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    HostVolume& h = ctx->vol[slot];
+    for (int i = 0; i < 3; i++) h.tex[i] = ids[i];
+    h.tex_scale[0] = scale_u;
+    h.tex_scale[1] = scale_v;
     return sync_volume_table(ctx);
 }
 

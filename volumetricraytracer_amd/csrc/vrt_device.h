@@ -51,6 +51,11 @@ struct DVolume {
     float pad_[2];
     const uint8_t* skip;   /* nb^3 bytes or null: Chebyshev distance (bricks) to the nearest brick holding a
                               sample closer than step_max to the surface; drives the empty-space leap */
+    /* material textures (textured render modes): R8G8B8A8, point/wrap; px null = unbound */
+    const uint8_t* tex_px[3];  /* albedo, normal, rm */
+    int32_t tex_w[3], tex_h[3];
+    float tex_scale[2];
+    float roughness_raw, metallic_raw; /* unclamped: the textured modes clamp after the RM factor */
     const uint8_t* cube_skip; /* nb^3 bytes: Chebyshev distance (bricks) to the nearest brick holding a solid voxel
                                  (density <= 0 at a cell-origin voxel); the Cube modes' octree stand-in */
 };
@@ -119,6 +124,7 @@ struct DFrame {
        ((l / strip_rows) * strip_stride + strip_first) * strip_rows + l % strip_rows; strip_rows == 0:
        contiguous rows row0 + l */
     int32_t strip_rows, strip_first, strip_stride;
+    int32_t textured;          /* 1: textured render mode and some instanced volume has a texture bound */
     float back;                /* secondary rays start this far back along the ray: 0.1, Cube modes 0.2 */
     /* scene arrays */
     int32_t n_inst, n_nodes;

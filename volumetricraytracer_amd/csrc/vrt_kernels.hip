@@ -856,6 +856,92 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
     write_records<DIAG>(F, b, wave, lane, k, dg, t_start);
 }
 
+/* ---- tri-planar material textures (SH/Include/Textures.hlsli:16-59, Quaternion.hlsli:18-82) ----------
+ * Restated line by line in the oracle (textured_surface); everything here feeds discrete decisions
+ * (texel choice, the bounce direction), so divisions and square roots are the correctly rounded ones. */
+
+/* Geometry sampler: point filter, wrap addressing (RDXScene.cpp:262-270). */
+__device__ __forceinline__ F3 tex_point_wrap(const uint8_t* __restrict__ px, int W, int H, float u, float v) {
+    const float fu = u - floorf(u), fv = v - floorf(v);
+    int x = (int)(fu * (float)W), y = (int)(fv * (float)H);
+    x = x > W - 1 ? W - 1 : (x < 0 ? 0 : x);
+    y = y > H - 1 ? H - 1 : (y < 0 ? 0 : y);
+    const unsigned t = *(const unsigned __attribute__((address_space(1)))*)(px + ((size_t)y * (size_t)W + (size_t)x) * 4);
+    return f3((float)(t & 0xffu) / 255.0f, (float)((t >> 8) & 0xffu) / 255.0f, (float)((t >> 16) & 0xffu) / 255.0f);
+}
+
+__device__ __forceinline__ F3 tri_sample(const DVolume* __restrict__ V, int which, F3 op, F3 blend, bool as_normal) {
+    const uint8_t* px = V->tex_px[which];
+    const int W = V->tex_w[which], H = V->tex_h[which];
+    const float su = V->tex_scale[0], sv = V->tex_scale[1];
+    F3 tx = tex_point_wrap(px, W, H, op.z / su, op.y / sv);
+    F3 ty = tex_point_wrap(px, W, H, op.x / su, op.z / sv);
+    F3 tz = tex_point_wrap(px, W, H, op.x / su, op.y / sv);
+    if (as_normal) {
+        tx = f3(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f);
+        ty = f3(ty.x * 2.0f - 1.0f, ty.y * 2.0f - 1.0f, ty.z * 2.0f - 1.0f);
+        tz = f3(tz.x * 2.0f - 1.0f, tz.y * 2.0f - 1.0f, tz.z * 2.0f - 1.0f);
+    }
+    return f3((tx.x * blend.x + ty.x * blend.y) + tz.x * blend.z, (tx.y * blend.x + ty.y * blend.y) + tz.y * blend.z,
+              (tx.z * blend.x + ty.z * blend.y) + tz.z * blend.z);
+}
+
+struct Q4 {
+    float x, y, z, w;
+};
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+    Q4 r;
+    r.x = (b.x * a.w + a.x * b.w) + (a.y * b.z - a.z * b.y);
+    r.y = (b.y * a.w + a.y * b.w) + (a.z * b.x - a.x * b.z);
+    r.z = (b.z * a.w + a.z * b.w) + (a.x * b.y - a.y * b.x);
+    r.w = a.w * b.w - ((a.x * b.x + a.y * b.y) + a.z * b.z);
+    return r;
+}
+__device__ __forceinline__ Q4 quat_from_x(F3 n) {
+    const float d = n.x;
+    Q4 q;
+    if (d < -0.999999f) {
+        q.x = 0.0f; q.y = 0.0f; q.z = -1.0f; q.w = -4.371139e-08f;
+    } else if (d > 0.999999f) {
+        q.x = 0.0f; q.y = 0.0f; q.z = 0.0f; q.w = 1.0f;
+    } else {
+        q.x = 0.0f; q.y = -n.z; q.z = n.y; q.w = 1.0f + d;
+        const float inv = 1.0f / sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+        q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
+    }
+    return q;
+}
+__device__ __forceinline__ F3 rotate_vector(F3 v, Q4 r) {
+    Q4 rc = {-r.x, -r.y, -r.z, r.w};
+    Q4 vq = {v.x, v.y, v.z, 0.0f};
+    const Q4 t = qmul(r, qmul(vq, rc));
+    return f3(t.x, t.y, t.z);
+}
+
+/* Material at a hit in the textured modes (unbound slots are exact identities). */
+__device__ __forceinline__ void textured_surface(const DVolume* __restrict__ V, const DInstance* __restrict__ I, F3 hit_world,
+                                                 F3& albedo, F3& n, float& rough, float& metal) {
+    const F3 op = mul33(I->w2o, f3(hit_world.x - I->pos[0], hit_world.y - I->pos[1], hit_world.z - I->pos[2]));
+    const F3 no = mul33(I->w2o, n);
+    const F3 an = f3(fabsf(no.x), fabsf(no.y), fabsf(no.z));
+    const float sum = (an.x + an.y) + an.z;
+    const F3 blend = f3(an.x / sum, an.y / sum, an.z / sum);
+    if (V->tex_px[0] != nullptr) {
+        const F3 t = tri_sample(V, 0, op, blend, false);
+        albedo = f3(albedo.x * t.x, albedo.y * t.y, albedo.z * t.z);
+    }
+    if (V->tex_px[2] != nullptr) {
+        const F3 t = tri_sample(V, 2, op, blend, false);
+        rough = minf_(maxf_(V->roughness_raw * t.x, 0.0f), 1.0f);
+        metal = minf_(maxf_(V->metallic_raw * t.y, 0.0f), 1.0f);
+    }
+    if (V->tex_px[1] != nullptr) {
+        F3 t = tri_sample(V, 1, op, blend, true);
+        t = normalize3(t);
+        n = mul33(I->o2w, rotate_vector(f3(t.z, t.x, t.y), quat_from_x(no)));
+    }
+}
+
 /*
  * Full closest hit (SH/Raytracing_NoTex.hlsl:41-139): directional + ≤5 point + ≤5 spot lights, each
  * with its own shadow ray, and the mirror bounce of smooth materials (roughness < 0.3) down to
@@ -901,12 +987,17 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_full(const DFrame 
             }
             k.n_hits++;
             const DVolume* V = F.vols + F.inst[inst].slot;
-            const F3 albedo = f3(V->tint[0], V->tint[1], V->tint[2]);
+            F3 albedo = f3(V->tint[0], V->tint[1], V->tint[2]);
+            float rough = V->roughness, metal = V->metallic;
+            if (F.textured) {
+                const F3 hp = f3(__builtin_fmaf(d.x, t_hit, o.x), __builtin_fmaf(d.y, t_hit, o.y), __builtin_fmaf(d.z, t_hit, o.z));
+                textured_surface(V, F.inst + inst, hp, albedo, n, rough, metal);
+            }
             if (F.unlit) {
                 color = albedo;
                 break;
             }
-            const float rough = V->roughness, metal = V->metallic, kk = V->k;
+            const float kk = V->k;
             const F3 so = shadow_origin(F, o, d, t_hit);
             const F3 wo = f3(-d.x, -d.y, -d.z);
             const float tb = t_base + t_hit;

@@ -32,6 +32,8 @@ class VHipRenderer:
         self.MaxSteps = 255  # Raytracing.hlsl:229
         self.MaxBounces = 2  # MAX_RAY_RECURSION_DEPTH 3 = primary + 2 mirror bounces (RaytracingHlsl.h:32)
         self._env_id = None
+        self._tex_ids: Dict[int, int] = {}   # id(image array) -> texture id on the device
+        self._tex_keep: Dict[int, np.ndarray] = {}  # keeps the keyed arrays alive so id() stays unique
 
     # -- VRenderer surface -------------------------------------------------------------------
     def Start(self) -> bool:
@@ -52,6 +54,8 @@ class VHipRenderer:
             self._ctx = C.c_void_p()
             self._uploaded.clear()
             self._env_id = None
+            self._tex_ids.clear()
+            self._tex_keep.clear()
 
     def IsActive(self) -> bool:
         return bool(self._ctx)
@@ -118,8 +122,28 @@ class VHipRenderer:
         _abi.check(self._lib.vrt_volume_set_material(self._ctx, slot, C.byref(mat)), "vrt_volume_set_material")
         _abi.check(self._lib.vrt_volume_set_metric(self._ctx, slot, float(vol.density_scale), float(vol.step_max)),
                    "vrt_volume_set_metric")
+        ids = [self.upload_texture(t) if t is not None else -1 for t in vol.Material.textures()]
+        _abi.check(self._lib.vrt_volume_set_textures(self._ctx, slot, ids[0], ids[1], ids[2], float(vol.Material.TextureScale[0]),
+                                                     float(vol.Material.TextureScale[1])), "vrt_volume_set_textures")
         self._uploaded[slot] = id(vol)
         vol.dirty = False
+
+    def upload_texture(self, image: np.ndarray) -> int:
+        """VRenderer::InitializeTexture + UploadToGPU for a 2D material texture (uint8 [H, W, 4]); images are
+        shared between volumes by identity, like the reference's path-keyed texture table (RDXScene.cpp:905-925)."""
+        self._require()
+        key = id(image)
+        if key in self._tex_ids:
+            return self._tex_ids[key]
+        tid = len(self._tex_ids)
+        if tid >= _abi.VRT_MAX_TEXTURES:
+            raise RuntimeError("too many material textures")
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        _abi.check(self._lib.vrt_texture_upload(self._ctx, tid, img.shape[1], img.shape[0], img.ctypes.data_as(C.c_void_p)),
+                   "vrt_texture_upload")
+        self._tex_ids[key] = tid
+        self._tex_keep[key] = image
+        return tid
 
     # -- parameters / raw launches ---------------------------------------------------------------
     def make_params(self) -> _abi.vrt_params:

@@ -80,9 +80,30 @@ def quat_from_euler_deg(roll: float, yaw: float, pitch: float) -> np.ndarray:
 
 @dataclass
 class VMaterial:
+    """VMaterial, Core/Public/Material.h:21-45.  The texture *paths* travel in .vox files; the decoded images
+    (uint8 [H, W, 4], R8G8B8A8) are attached by the caller — the reference decodes them with WIC/DDS loaders
+    (Renderer/Private/TextureFactory.cpp:58-125), which this build leaves to the application."""
     AlbedoColor: Sequence[float] = (0.8, 0.8, 0.8, 1.0)
     Roughness: float = 0.8
     Metallic: float = 0.0
+    AlbedoTexturePath: str = ""
+    NormalTexturePath: str = ""
+    RMTexturePath: str = ""
+    TextureScale: Sequence[float] = (100.0, 100.0)
+    AlbedoTexture: Optional[np.ndarray] = None
+    NormalTexture: Optional[np.ndarray] = None
+    RMTexture: Optional[np.ndarray] = None
+
+    def textures(self):
+        """(albedo, normal, rm) images or None, validated."""
+        out = []
+        for t in (self.AlbedoTexture, self.NormalTexture, self.RMTexture):
+            if t is not None:
+                t = np.ascontiguousarray(t, dtype=np.uint8)
+                if t.ndim != 3 or t.shape[2] != 4 or t.shape[0] < 1 or t.shape[1] < 1:
+                    raise ValueError("material textures must be uint8 [H, W, 4]")
+            out.append(t)
+        return out
 
     def to_abi(self) -> _abi.vrt_material:
         m = _abi.vrt_material()

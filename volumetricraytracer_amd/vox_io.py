@@ -91,10 +91,15 @@ def _material_archive(m: VMaterial) -> Archive:
     a.props["Color"] = Archive(struct.pack("<4f", *[float(c) for c in m.AlbedoColor]))
     a.props["Roughness"] = Archive(struct.pack("<f", m.Roughness))
     a.props["Metallic"] = Archive(struct.pack("<f", m.Metallic))
-    a.props["TextureScale"] = Archive(struct.pack("<2f", 100.0, 100.0))
-    for k in ("AlbedoTexture", "NormalTexture", "RMTexture"):
-        a.props[k] = _cstring("")
+    a.props["TextureScale"] = Archive(struct.pack("<2f", float(m.TextureScale[0]), float(m.TextureScale[1])))
+    a.props["AlbedoTexture"] = _cstring(m.AlbedoTexturePath)
+    a.props["NormalTexture"] = _cstring(m.NormalTexturePath)
+    a.props["RMTexture"] = _cstring(m.RMTexturePath)
     return a
+
+
+def _read_cstring(a: Archive) -> str:
+    return bytes(a.buffer).split(b"\0", 1)[0].decode(errors="replace")
 
 
 def volume_archive(v: VVoxelVolume) -> Archive:
@@ -115,6 +120,11 @@ def volume_from_archive(a: Archive) -> VVoxelVolume:
     m = a["Material"]
     v.Material = VMaterial(tuple(m["Color"].unpack("<4f")), m["Roughness"].unpack("<f"),
                            m["Metallic"].unpack("<f") if "Metallic" in m else 0.0)
+    if "TextureScale" in m:
+        v.Material.TextureScale = tuple(m["TextureScale"].unpack("<2f"))
+    for key, attr in (("AlbedoTexture", "AlbedoTexturePath"), ("NormalTexture", "NormalTexturePath"), ("RMTexture", "RMTexturePath")):
+        if key in m:
+            setattr(v.Material, attr, _read_cstring(m[key]))
     return v
 
 
