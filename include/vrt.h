@@ -32,6 +32,7 @@
 #ifndef VRT_H
 #define VRT_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -196,6 +197,19 @@ int vrt_volume_set_material(vrt_ctx* ctx, int slot, const vrt_material* material
  * extraction threshold for its shell volumes).  step_max: largest object-space step that is
  * safe to take from any sample (<= 0: unbounded). */
 int vrt_volume_set_metric(vrt_ctx* ctx, int slot, float density_scale, float step_max);
+/* The Voxelizer's hot loop on the device: VVolumeConverter::ConvertMeshInfoToVoxelVolume / VoxelizeFace
+ * (Voxelizer/Private/VolumeConverter.cpp:30-84, 161-252): fills slot with the unsigned shell field of a triangle
+ * mesh — density = dist/thr - 0.5 (thr = cell*sqrt 3) in every triangle's (bbox +- thr +- 1 voxel) index box,
+ * minimum over triangles, background 2*extent, material = (density <= 0) — and sets the slot's metric to
+ * (thr, thr/2).  positions: 3 floats per vertex in volume space; resolution / extent as the converter derives
+ * them from the mesh name and bounds (:32-49).  Degenerate triangles and out-of-range indices are skipped and
+ * counted.  Bit-identical to the CPU converter of this build (same source, csrc/voxelize_core.h). */
+int vrt_voxelize_mesh(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, const float* positions, size_t n_vertices,
+                      const uint32_t* indices, size_t n_indices, size_t* skipped_or_null);
+
+/* Reads a slot back as N^3 VVoxel records (index x*N*N + z*N + y), e.g. to write the .vox file. */
+int vrt_volume_download(vrt_ctx* ctx, int slot, vrt_voxel* out);
+
 int vrt_volume_free(vrt_ctx* ctx, int slot);
 
 /* 2D material textures — VRenderer::InitializeTexture / UploadToGPU(VTexture) (Renderer/Public/Renderer.h:54-57)

@@ -188,6 +188,69 @@ def test_texture_table_through_the_abi(oracle_lib):
         r.Stop()
 
 
+@pytest.mark.parametrize("mesh,resolution", [("cube", 5), ("torus", 6), ("torus", 8)])
+def test_device_voxelizer_matches_the_cpu_converter(mesh, resolution):
+    """vrt_voxelize_mesh (one workgroup per triangle, atomicMin on ordered keys) against the C++ CPU converter
+    (VVolumeConverter, csrc/host/VolumeConverter.cpp): every density and material of the volume, bit for bit —
+    the reference's config 1 (unit cube -> 32^3) and the config 3 mesh at 64^3 and 256^3."""
+    from volumetricraytracer_amd import voxelizer as vx
+
+    pos, _, idx = vx.cube_mesh() if mesh == "cube" else vx.torus_mesh(0.55, 0.22, 128, 64)
+    p, be = vx.importer_space(pos)
+    cpu = vx.convert_mesh(p, idx, be, f"{mesh}_{resolution}")
+    r = v.VHipRenderer()
+    assert r.Start()
+    try:
+        skipped = r.voxelize_mesh(2, p, idx, resolution, cpu.VolumeExtends)
+        gpu = r.download_volume(2, resolution, cpu.VolumeExtends)
+        assert skipped == 0
+        assert np.array_equal(gpu.density, cpu.density)
+        assert np.array_equal(gpu.material_id, cpu.material_id)
+        assert (gpu.density <= 0).sum() > 100 and gpu.density.max() == np.float32(cpu.VolumeExtends * 2)
+        # the slot renders like an uploaded copy of the CPU volume (metric set by the voxelizer itself)
+        if resolution <= 6:
+            cpu.Material = v.VMaterial((0.8, 0.6, 0.2, 1.0), 0.8, 0.0)
+            sc = v.VScene(Camera=v.look_minus_x_camera(cpu.VolumeExtends * 3.0), DirectionalLight=v.demo_light(), Objects=[v.VVoxelObject(Volume=cpu)])
+            prm = v.default_params(160, 90, cpu.GetCellSize(), 255, shadow=True)
+            want, _ = gpu_render(r, sc, prm)                      # slot 0: uploaded CPU volume
+            abi_scene = sc.to_abi()
+            abi_scene.instances[0].volume_slot = 2                # same scene, instance points at the voxelized slot
+            mat = cpu.Material.to_abi()
+            _abi.check(r._lib.vrt_volume_set_material(r._ctx, 2, C.byref(mat)), "vrt_volume_set_material")
+            _abi.check(r._lib.vrt_scene_set(r._ctx, C.byref(abi_scene)), "vrt_scene_set")
+            got = np.empty_like(want)
+            _abi.check(r._lib.vrt_render(r._ctx, C.byref(prm), got.ctypes.data_as(C.c_void_p)), "vrt_render")
+            assert np.array_equal(got, want)
+        # degenerate and out-of-range triangles are skipped and counted, like the CPU converter does
+        bad = np.concatenate([idx.reshape(-1), np.array([0, 0, 1, 0, 1, len(p) + 5], np.uint32)])
+        assert r.voxelize_mesh(3, p, bad, min(resolution, 5), cpu.VolumeExtends) == 2
+    finally:
+        r.Stop()
+
+
+def test_voxelizer_cli_on_the_device_writes_the_same_file(tmp_path):
+    """`voxelizer --gpu scene.gltf` (glTF import and .vox export on the host, the per-triangle loop through
+    vrt_voxelize_mesh + vrt_volume_download) against the plain CPU run of the same tool: identical bytes."""
+    import subprocess
+
+    from volumetricraytracer_amd import voxelizer as vx
+
+    pos, nrm, idx = vx.torus_mesh(0.55, 0.22, 64, 32)
+    cpos, cnrm, cidx = vx.cube_mesh(0.5)
+    gltf = str(tmp_path / "scene.gltf")
+    nodes = [{"name": "Torus", "mesh": 0, "translation": [0.0, 0.0, 1.0]}, {"name": "Cube", "mesh": 1, "scale": [1.0, 2.0, 0.5]},
+             {"name": "Light_Sun", "rotation": [0.0, 0.0, 0.0, 1.0], "extras": {"strength": 6.0}}]
+    vx.write_gltf(gltf, [("torus_6", pos, nrm, idx, None), ("cube_5", cpos, cnrm, cidx, None)], nodes)
+    exe = os.path.join(os.path.dirname(_abi.LIB_PATH), "voxelizer")
+    cpu_out, gpu_out = str(tmp_path / "cpu.vox"), str(tmp_path / "gpu.vox")
+    r1 = subprocess.run([exe, "--out", cpu_out, gltf], capture_output=True, text=True, timeout=300)
+    r2 = subprocess.run([exe, "--gpu", "--out", gpu_out, gltf], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and "host voxelizer" in r1.stdout, r1.stderr
+    assert r2.returncode == 0 and "device voxelizer" in r2.stdout and "failed" not in r2.stdout, r2.stdout + r2.stderr
+    a, b = open(cpu_out, "rb").read(), open(gpu_out, "rb").read()
+    assert len(a) > 2_000_000 and a == b
+
+
 def test_cube_mode_edge_cases(renderer, oracle_lib):
     """Camera inside the volume and inside a solid voxel, 1-step budget, ragged frame, resolution 0 and 1."""
     sc = scenes.config2_sphere(5, 16)

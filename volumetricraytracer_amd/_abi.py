@@ -148,6 +148,9 @@ SYMBOLS = {
     "vrt_texture_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vrt_texture_free": (C.c_int, [C.c_void_p, C.c_int]),
     "vrt_volume_set_textures": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]),
+    "vrt_voxelize_mesh": (C.c_int, [C.c_void_p, C.c_int, C.c_uint8, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                    C.POINTER(C.c_size_t)]),
+    "vrt_volume_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vrt_volume_free": (C.c_int, [C.c_void_p, C.c_int]),
     "vrt_env_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "vrt_scene_set": (C.c_int, [C.c_void_p, C.POINTER(vrt_scene)]),

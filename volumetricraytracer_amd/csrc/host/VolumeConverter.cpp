@@ -1,77 +1,32 @@
 #include "VolumeConverter.h"
 
+#include "../../../include/vrt.h"
+#include "../voxelize_core.h"
+
 #include <cmath>
 #include <iostream>
+#include <vector>
 
 namespace VolumeRaytracer {
 namespace Voxelizer {
 
 namespace {
 
-/* Everything about one triangle that the per-voxel classification needs. */
-struct TriangleFrame {
-    VVector v[3];       /* V1, V2, V3 */
-    VVector normal;     /* A: unit face normal */
-    VVector along[3];   /* unit edge directions  B: V1→V3, C: V3→V2, D: V2→V1 */
-    float length[3];    /* |B|, |C|, |D| */
-    VVector inward[3];  /* in-plane unit normals of the edges, pointing into the triangle: E (of B), F (of C), G (of D) */
-};
+using vrt_vox::TriangleFrame;
 
-bool make_frame(const VVector& v1, const VVector& v2, const VVector& v3, TriangleFrame& t) {
-    t.v[0] = v1;
-    t.v[1] = v2;
-    t.v[2] = v3;
-    VVector n = VVector::Cross(v2 - v1, v3 - v1);
-    const float area2 = n.Length();
-    if (!(area2 > 0.f)) return false; /* degenerate: the reference would hit its unreachable assert (:779) */
-    t.normal = n / area2;
-    const VVector e[3] = {v3 - v1, v2 - v3, v1 - v2};
-    for (int k = 0; k < 3; k++) {
-        t.length[k] = e[k].Length();
-        if (!(t.length[k] > 0.f)) return false;
-        t.along[k] = e[k] / t.length[k];
-        t.inward[k] = VVector::Cross(t.along[k], t.normal).GetNormalized();
-    }
-    return true;
-}
+inline vrt_vox::V3 to_v3(const VVector& v) { return vrt_vox::v3(v.X, v.Y, v.Z); }
 
-/* Distance from p to the triangle, by the region p projects into (face, 3 edges, 3 vertices). */
-float region_distance(const TriangleFrame& t, const VVector& p) {
-    const VVector r1 = p - t.v[0], r2 = p - t.v[1], r3 = p - t.v[2];
-    const float a = r1.Dot(t.normal);                              /* signed plane distance */
-    const float b = r1.Dot(t.along[0]), e = r1.Dot(t.inward[0]);   /* edge V1→V3 */
-    const float c = r3.Dot(t.along[1]), f = r3.Dot(t.inward[1]);   /* edge V3→V2 */
-    const float d = r2.Dot(t.along[2]), g = r2.Dot(t.inward[2]);   /* edge V2→V1 */
-    if (e >= 0.f && f >= 0.f && g >= 0.f) return std::fabs(a);                       /* R1: over the face */
-    if (d >= t.length[2] && b <= 0.f) return r1.Length();                            /* R5: vertex V1 */
-    if (b >= t.length[0] && c <= 0.f) return r3.Length();                            /* R7: vertex V3 */
-    if (c >= t.length[1] && d <= 0.f) return r2.Length();                            /* R6: vertex V2 */
-    if (g <= 0.f && d >= 0.f && d <= t.length[2]) return std::sqrt(a * a + g * g);   /* R2: edge V2→V1 */
-    if (e <= 0.f && b >= 0.f && b <= t.length[0]) return std::sqrt(a * a + e * e);   /* R4: edge V1→V3 */
-    if (f <= 0.f && c >= 0.f && c <= t.length[1]) return std::sqrt(a * a + f * f);   /* R3: edge V3→V2 */
-    /* numerically between regions (the reference asserts here): nearest of the three vertices */
-    return std::fmin(r1.Length(), std::fmin(r2.Length(), r3.Length()));
-}
-
+/* One triangle into the volume: every voxel of its index box keeps the smaller of its density and the
+   shell density of its distance to this triangle (VoxelizeFace, VolumeConverter.cpp:161-252).  The
+   arithmetic lives in ../voxelize_core.h, shared with the HIP kernel. */
 void voxelize_face(Voxel::VVoxelVolume& volume, const TriangleFrame& t, float threshold) {
-    /* index box: triangle bounds, grown by the threshold, rounded to voxels, grown by one voxel
-       (GetTriangleBoundingBox + GetVoxelizedBoundingBox, VolumeConverter.cpp:681-701) */
-    const VVector lo = VVector::Min(t.v[0], VVector::Min(t.v[1], t.v[2]));
-    const VVector hi = VVector::Max(t.v[0], VVector::Max(t.v[1], t.v[2]));
-    const VVector half = (hi - lo) * 0.5f;
-    const VAABB box(half + lo, half.Abs());
-    VIntVector imin = volume.RelativePositionToVoxelIndex(box.GetMin() - VVector::ONE * threshold) - VIntVector(1, 1, 1);
-    VIntVector imax = volume.RelativePositionToVoxelIndex(box.GetMax() + VVector::ONE * threshold) + VIntVector(1, 1, 1);
-    const int last = (int)volume.GetSize() - 1;
-    imin = VIntVector(std::max(imin.X, 0), std::max(imin.Y, 0), std::max(imin.Z, 0));
-    imax = VIntVector(std::min(imax.X, last), std::min(imax.Y, last), std::min(imax.Z, last));
-    for (int x = imin.X; x <= imax.X; x++)
-        for (int y = imin.Y; y <= imax.Y; y++)
-            for (int z = imin.Z; z <= imax.Z; z++) {
+    const float cell = volume.GetCellSize(), extent = volume.GetVolumeExtends();
+    for (int x = t.lo[0]; x <= t.hi[0]; x++)
+        for (int y = t.lo[1]; y <= t.hi[1]; y++)
+            for (int z = t.lo[2]; z <= t.hi[2]; z++) {
                 const VIntVector idx(x, y, z);
-                const float dist = region_distance(t, volume.VoxelIndexToRelativePosition(idx));
-                float density = 1.f - (dist / threshold);
-                density = -1.f * density + 0.5f;
+                const float dist = vrt_vox::region_distance(t, vrt_vox::voxel_position(x, y, z, cell, extent));
+                const float density = vrt_vox::shell_density(dist, threshold);
                 Voxel::VVoxel voxel = volume.GetVoxel(idx);
                 if (density < voxel.Density) {
                     voxel.Density = density;
@@ -82,6 +37,9 @@ void voxelize_face(Voxel::VVoxelVolume& volume, const TriangleFrame& t, float th
 }
 
 }  // namespace
+
+static vrt_ctx* g_device_ctx = nullptr;
+void VVolumeConverter::UseDevice(vrt_ctx* ctx) { g_device_ctx = ctx; }
 
 bool VVolumeConverter::ExtractResolutionFromName(const std::string& name, uint8_t& outResolution) {
     const size_t at = name.rfind('_');
@@ -120,17 +78,42 @@ std::shared_ptr<Voxel::VVoxelVolume> VVolumeConverter::ConvertMeshInfoToVoxelVol
 
     const float threshold = ExtractionThreshold(*volume);
     size_t skipped = 0;
-    for (size_t i = 0; i + 3 <= meshInfo.Indices.size(); i += 3) {
+    bool on_device = false;
+    if (g_device_ctx) {
+        /* the same loop on the GPU: upload the mesh, voxelize into a scratch slot, read the voxels back */
+        constexpr int kScratchSlot = VRT_MAX_VOLUMES - 1;
+        std::vector<float> pos(meshInfo.Vertices.size() * 3);
+        for (size_t i = 0; i < meshInfo.Vertices.size(); i++) {
+            pos[3 * i] = meshInfo.Vertices[i].Position.X;
+            pos[3 * i + 1] = meshInfo.Vertices[i].Position.Y;
+            pos[3 * i + 2] = meshInfo.Vertices[i].Position.Z;
+        }
+        std::vector<uint32_t> idx(meshInfo.Indices.size());
+        for (size_t i = 0; i < idx.size(); i++) idx[i] = meshInfo.Indices[i] > 0xfffffffeull ? 0xffffffffu : (uint32_t)meshInfo.Indices[i];
+        static_assert(sizeof(Voxel::VVoxel) == sizeof(vrt_voxel), "VVoxel must match the wire record");
+        int rc = vrt_voxelize_mesh(g_device_ctx, kScratchSlot, resolution, extends, pos.data(), meshInfo.Vertices.size(), idx.data(), idx.size(), &skipped);
+        if (rc == VRT_OK) rc = vrt_volume_download(g_device_ctx, kScratchSlot, reinterpret_cast<vrt_voxel*>(volume->GetVoxels().data()));
+        if (rc == VRT_OK) {
+            (void)vrt_volume_free(g_device_ctx, kScratchSlot);
+            on_device = true;
+        } else {
+            std::cout << "[WARNING] device Voxelizer failed (" << vrt_strerror(rc) << "); converting " << meshInfo.MeshName << " on the host" << std::endl;
+            volume->FillVolume(background);
+            skipped = 0;
+        }
+    }
+    for (size_t i = 0; !on_device && i + 3 <= meshInfo.Indices.size(); i += 3) {
         const size_t a = meshInfo.Indices[i], b = meshInfo.Indices[i + 1], c = meshInfo.Indices[i + 2];
         if (a >= meshInfo.Vertices.size() || b >= meshInfo.Vertices.size() || c >= meshInfo.Vertices.size()) {
             skipped++;
             continue;
         }
         TriangleFrame t;
-        if (!make_frame(meshInfo.Vertices[a].Position, meshInfo.Vertices[b].Position, meshInfo.Vertices[c].Position, t)) {
+        if (!vrt_vox::make_frame(to_v3(meshInfo.Vertices[a].Position), to_v3(meshInfo.Vertices[b].Position), to_v3(meshInfo.Vertices[c].Position), t)) {
             skipped++;
             continue;
         }
+        vrt_vox::index_box(t, threshold, volume->GetVolumeExtends(), volume->GetCellSize(), (int)volume->GetSize());
         voxelize_face(*volume, t, threshold);
     }
     if (skipped) std::cout << "[WARNING] Skipped " << skipped << " degenerate or out-of-range triangle(s) of " << meshInfo.MeshName << std::endl;

@@ -14,12 +14,18 @@
 #include "HostVoxel.h"
 #include "VoxelizerTypes.h"
 
+struct vrt_ctx; /* include/vrt.h */
+
 namespace VolumeRaytracer {
 namespace Voxelizer {
 
 class VVolumeConverter {
 public:
     static std::shared_ptr<Voxel::VVoxelVolume> ConvertMeshInfoToVoxelVolume(const VMeshInfo& meshInfo, const VTextureLibrary& textureLib);
+    /* Run the per-triangle loop on the GPU (vrt_voxelize_mesh, include/vrt.h) instead of on the host: same
+       volume, bit for bit (both builds compile csrc/voxelize_core.h).  ctx = a live vrt_ctx, or nullptr to go
+       back to the CPU loop.  The converter uses (and overwrites) volume slot 19 of that context. */
+    static void UseDevice(::vrt_ctx* ctx);
     static bool ExtractResolutionFromName(const std::string& name, uint8_t& outResolution);
     /* extraction threshold of a volume: cell size · √3 (VolumeConverter.cpp:57) */
     static float ExtractionThreshold(const Voxel::VVoxelVolume& volume);

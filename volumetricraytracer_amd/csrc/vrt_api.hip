@@ -24,6 +24,7 @@
 #include "../../include/vrt.h"
 #include "vrt_device.h"
 #include "vrt_launch.h"
+#include "voxelize_core.h"
 
 using namespace vrt;
 
@@ -382,11 +383,17 @@ bool valid_slot(int slot) { return slot >= 0 && slot < VRT_MAX_VOLUMES; }
 
 /* Uploads N^3 densities (already on the host as fp32, or as VVoxel records) to every device,
  * then re-tiles them into bricks on the device. */
+/* A triangle mesh prepared for the device Voxelizer: one frame (+ voxel index box) per usable triangle. */
+struct MeshSource {
+    std::vector<vrt_vox::TriangleFrame> frames;
+    float threshold = 0.f;
+};
+
 int upload_volume(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, const float* density,
-                  const uint8_t* material, const vrt_voxel* voxels) {
+                  const uint8_t* material, const vrt_voxel* voxels, const MeshSource* mesh = nullptr) {
     if (!ctx) return VRT_ERR_INVALID;
     if (!valid_slot(slot)) return VRT_ERR_SLOT;
-    if (resolution > 10 || !(extent > 0.0f) || (!density && !voxels)) return VRT_ERR_INVALID;
+    if (resolution > 10 || !(extent > 0.0f) || (!density && !voxels && !mesh)) return VRT_ERR_INVALID;
     const int N = (1 << resolution) + 1; /* VoxelVolume.cpp:23 */
     const int nb = (N - 1 + kBrickCells - 1) / kBrickCells;
     const size_t count = (size_t)N * N * N;
@@ -398,7 +405,22 @@ int upload_volume(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, cons
         HIP_TRY(hipMalloc(&v.dense, count * sizeof(float)));
         HIP_TRY(hipMalloc(&v.material, count));
         HIP_TRY(hipMalloc(&v.bricks, (size_t)nb * nb * nb * kBrickFloats * sizeof(float)));
-        if (voxels) {
+        if (mesh) {
+            /* device Voxelizer: background 2*extent everywhere, then the minimum over the triangles */
+            void* d_frames = nullptr;
+            const size_t fbytes = mesh->frames.size() * sizeof(vrt_vox::TriangleFrame);
+            hipError_t e = hipSuccess;
+            if (fbytes > 0) {
+                e = hipMalloc(&d_frames, fbytes);
+                if (e == hipSuccess) e = hipMemcpyAsync(d_frames, mesh->frames.data(), fbytes, hipMemcpyHostToDevice, D.stream);
+            }
+            const float cell = (extent * 2.0f) / (float)(N - 1);
+            if (e == hipSuccess)
+                e = launch_voxelize(d_frames, mesh->frames.size(), v.dense, v.material, N, cell, extent, mesh->threshold, D.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(D.stream);
+            if (d_frames) (void)hipFree(d_frames);
+            HIP_TRY(e);
+        } else if (voxels) {
             void* staging = nullptr;
             HIP_TRY(hipMalloc(&staging, count * sizeof(vrt_voxel)));
             hipError_t e = hipMemcpyAsync(staging, voxels, count * sizeof(vrt_voxel), hipMemcpyHostToDevice, D.stream);
@@ -660,6 +682,56 @@ int vrt_volume_upload(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, 
 int vrt_volume_upload_voxels(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, const vrt_voxel* voxels) {
     if (!ctx || !voxels) return VRT_ERR_INVALID;
     return upload_volume(ctx, slot, resolution, extent, nullptr, nullptr, voxels);
+}
+
+int vrt_voxelize_mesh(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, const float* positions, size_t n_vertices,
+                      const uint32_t* indices, size_t n_indices, size_t* skipped_or_null) {
+    if (!ctx || (!positions && n_vertices > 0) || (!indices && n_indices > 0)) return VRT_ERR_INVALID;
+    if (!valid_slot(slot)) return VRT_ERR_SLOT;
+    if (resolution > 10 || !(extent > 0.0f)) return VRT_ERR_INVALID;
+    const int N = (1 << resolution) + 1;
+    const float cell = (extent * 2.0f) / (float)(N - 1);
+    MeshSource mesh;
+    mesh.threshold = cell * sqrtf(3.f); /* extraction threshold, VolumeConverter.cpp:57 */
+    size_t skipped = 0;
+    mesh.frames.reserve(n_indices / 3);
+    for (size_t i = 0; i + 3 <= n_indices; i += 3) {
+        const size_t a = indices[i], b = indices[i + 1], c = indices[i + 2];
+        vrt_vox::TriangleFrame t;
+        if (a >= n_vertices || b >= n_vertices || c >= n_vertices ||
+            !vrt_vox::make_frame(vrt_vox::v3(positions[3 * a], positions[3 * a + 1], positions[3 * a + 2]),
+                                 vrt_vox::v3(positions[3 * b], positions[3 * b + 1], positions[3 * b + 2]),
+                                 vrt_vox::v3(positions[3 * c], positions[3 * c + 1], positions[3 * c + 2]), t)) {
+            skipped++; /* out-of-range index or degenerate triangle, like the CPU converter */
+            continue;
+        }
+        vrt_vox::index_box(t, mesh.threshold, extent, cell, N);
+        mesh.frames.push_back(t);
+    }
+    if (skipped_or_null) *skipped_or_null = skipped;
+    int rc = upload_volume(ctx, slot, resolution, extent, nullptr, nullptr, nullptr, &mesh);
+    if (rc != VRT_OK) return rc;
+    /* the shell's metric (VolumeConverter sets it on the CPU volume): density*thr is a distance below thr */
+    return vrt_volume_set_metric(ctx, slot, mesh.threshold, 0.5f * mesh.threshold);
+}
+
+int vrt_volume_download(vrt_ctx* ctx, int slot, vrt_voxel* out) {
+    if (!ctx || !out) return VRT_ERR_INVALID;
+    if (!valid_slot(slot) || !ctx->vol[slot].used) return VRT_ERR_SLOT;
+    DeviceState& D = ctx->dev[0];
+    const DeviceVolume& v = D.vol[slot];
+    const size_t count = (size_t)ctx->vol[slot].N * ctx->vol[slot].N * ctx->vol[slot].N;
+    HIP_TRY(hipSetDevice(D.ordinal));
+    std::vector<float> den(count);
+    std::vector<uint8_t> mat(count);
+    HIP_TRY(hipMemcpy(den.data(), v.dense, count * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mat.data(), v.material, count, hipMemcpyDeviceToHost));
+    memset(out, 0, count * sizeof(vrt_voxel));
+    for (size_t i = 0; i < count; i++) {
+        out[i].material = mat[i];
+        out[i].density = den[i];
+    }
+    return VRT_OK;
 }
 
 int vrt_volume_set_material(vrt_ctx* ctx, int slot, const vrt_material* material) {

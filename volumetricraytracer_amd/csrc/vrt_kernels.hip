@@ -21,6 +21,7 @@
 #include <math.h>
 #include "vrt_device.h"
 #include "vrt_launch.h"
+#include "voxelize_core.h"
 
 namespace vrt {
 
@@ -1391,6 +1392,45 @@ __global__ void skip_dilate_kernel(const uint8_t* __restrict__ cur, uint8_t* __r
     nxt[i] = d;
 }
 
+/* ---- device Voxelizer (Voxelizer/Private/VolumeConverter.cpp:161-252; arithmetic in voxelize_core.h) ------
+ * One workgroup per triangle walks the triangle's voxel index box; every voxel keeps the minimum shell
+ * density over all triangles.  The minimum is order-independent, so an integer atomicMin on order-preserving
+ * keys reproduces the CPU converter's sequential "keep if smaller" bit for bit.  The keys live in the dense
+ * density buffer itself and are turned back into floats (and materials) by voxelize_finish_kernel. */
+__global__ void voxelize_fill_kernel(int* __restrict__ keys, size_t count, int key) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) keys[i] = key;
+}
+
+__global__ __launch_bounds__(256) void voxelize_kernel(const vrt_vox::TriangleFrame* __restrict__ tris, int* __restrict__ keys, int N,
+                                                       float cell, float extent, float threshold) {
+    const vrt_vox::TriangleFrame t = tris[blockIdx.x];
+    const int nx = t.hi[0] - t.lo[0] + 1, ny = t.hi[1] - t.lo[1] + 1, nz = t.hi[2] - t.lo[2] + 1;
+    if (nx <= 0 || ny <= 0 || nz <= 0) return;
+    const long long total = (long long)nx * ny * nz;
+    for (long long j = threadIdx.x; j < total; j += blockDim.x) {
+        /* y fastest: neighbouring lanes hit neighbouring addresses of the x*N*N + z*N + y layout */
+        const int ly = (int)(j % ny);
+        const int lz = (int)((j / ny) % nz);
+        const int lx = (int)(j / ((long long)ny * nz));
+        const int x = t.lo[0] + lx, y = t.lo[1] + ly, z = t.lo[2] + lz;
+        const float dist = vrt_vox::region_distance(t, vrt_vox::voxel_position(x, y, z, cell, extent));
+        const float density = vrt_vox::shell_density(dist, threshold);
+        atomicMin(&keys[((size_t)x * N + z) * N + y], vrt_vox::ordered_key(density));
+    }
+}
+
+__global__ void voxelize_finish_kernel(float* __restrict__ density, uint8_t* __restrict__ material, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) {
+        const float d = vrt_vox::from_ordered_key(__float_as_int(density[i]));
+        density[i] = d;
+        material[i] = d <= 0.0f ? 1 : 0; /* VolumeConverter.cpp:206-207; untouched voxels keep material 0 */
+    }
+}
+
 /* VVoxel records (8 B: u8 material, pad, f32 density) → dense fp32 densities + u8 materials. */
 __global__ void split_voxels_kernel(const uint2* __restrict__ voxels, float* __restrict__ density,
                                     uint8_t* __restrict__ material, size_t count) {
@@ -1493,6 +1533,19 @@ static hipError_t dilate_table(uint8_t* table, uint8_t* scratch, int nb, hipStre
         hipError_t e = hipMemcpyAsync(table, cur, (size_t)n, hipMemcpyDeviceToDevice, stream);
         if (e != hipSuccess) return e;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_voxelize(const void* frames, size_t n_frames, float* density, uint8_t* material, int N, float cell, float extent,
+                           float threshold, hipStream_t stream) {
+    const size_t count = (size_t)N * N * N;
+    /* background: VVoxel{material 0, density 2*extent} (VolumeConverter.cpp:51-55) */
+    hipLaunchKernelGGL(voxelize_fill_kernel, dim3(2048), dim3(256), 0, stream, reinterpret_cast<int*>(density), count,
+                       vrt_vox::ordered_key(extent * 2.f));
+    if (n_frames > 0)
+        hipLaunchKernelGGL(voxelize_kernel, dim3((unsigned)n_frames), dim3(256), 0, stream,
+                           reinterpret_cast<const vrt_vox::TriangleFrame*>(frames), reinterpret_cast<int*>(density), N, cell, extent, threshold);
+    hipLaunchKernelGGL(voxelize_finish_kernel, dim3(2048), dim3(256), 0, stream, density, material, count);
     return hipGetLastError();
 }
 

@@ -16,6 +16,9 @@ hipError_t launch_skip_table(const float* bricks, uint8_t* table, uint8_t* scrat
                              hipStream_t stream);
 /* Cube modes: nb^3-byte Chebyshev distance (bricks) to the nearest brick holding a solid voxel. */
 hipError_t launch_cube_table(const float* bricks, uint8_t* table, uint8_t* scratch, int N, int nb, hipStream_t stream);
+/* Device Voxelizer: frames = n_frames vrt_vox::TriangleFrame records (device memory); writes N^3 densities + materials. */
+hipError_t launch_voxelize(const void* frames, size_t n_frames, float* density, uint8_t* material, int N, float cell, float extent,
+                           float threshold, hipStream_t stream);
 hipError_t launch_split_voxels(const void* voxels, float* density, uint8_t* material, size_t count,
                                hipStream_t stream);
 

@@ -128,6 +128,29 @@ class VHipRenderer:
         self._uploaded[slot] = id(vol)
         vol.dirty = False
 
+    def voxelize_mesh(self, slot: int, positions: np.ndarray, indices: np.ndarray, resolution: int, extent: float) -> int:
+        """The Voxelizer's hot loop on the device (vrt_voxelize_mesh): fills `slot` with the shell field of a
+        triangle mesh given in volume space; returns the number of skipped (degenerate) triangles.  The slot is
+        not tracked by SyncWithScene: pair it with download_volume() or instance it through a raw vrt_scene."""
+        self._require()
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        skipped = C.c_size_t(0)
+        _abi.check(self._lib.vrt_voxelize_mesh(self._ctx, slot, resolution, float(extent), pos.ctypes.data_as(C.c_void_p), len(pos),
+                                               idx.ctypes.data_as(C.c_void_p), len(idx), C.byref(skipped)), "vrt_voxelize_mesh")
+        self._uploaded.pop(slot, None)
+        return int(skipped.value)
+
+    def download_volume(self, slot: int, resolution: int, extent: float) -> VVoxelVolume:
+        """vrt_volume_download: the slot as a VVoxelVolume (densities + materials)."""
+        self._require()
+        vol = VVoxelVolume(resolution, extent)
+        rec = np.zeros(vol.N ** 3, dtype=np.dtype([("material", "u1"), ("pad", "u1", 3), ("density", "<f4")]))
+        _abi.check(self._lib.vrt_volume_download(self._ctx, slot, rec.ctypes.data_as(C.c_void_p)), "vrt_volume_download")
+        vol.density = np.ascontiguousarray(rec["density"].reshape(vol.N, vol.N, vol.N))
+        vol.material_id = np.ascontiguousarray(rec["material"].reshape(vol.N, vol.N, vol.N))
+        return vol
+
     def upload_texture(self, image: np.ndarray) -> int:
         """VRenderer::InitializeTexture + UploadToGPU for a 2D material texture (uint8 [H, W, 4]); images are
         shared between volumes by identity, like the reference's path-keyed texture table (RDXScene.cpp:905-925)."""
