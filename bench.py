@@ -69,6 +69,9 @@ def main() -> None:
     ap.add_argument("--output", default="auto", choices=["auto", "f32", "rgba8"],
                     help="tile pixel format; auto = float4 on one GPU, RGBA8 (the exchange format) on several")
     ap.add_argument("--strip-rows", type=int, default=32, help="N>1: rows per interleaved strip; 0 = contiguous row tiles")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="frames launched before the first one must have finished, each on its own HIP stream and tile buffer "
+                         "(the reference keeps 3 in flight, DXConstants.cpp:23)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
@@ -124,33 +127,40 @@ def main() -> None:
 
     # tile of this rank + (rank 0) the gathered frames
     pix = torch.uint8 if rgba8 else torch.float32
-    fg = FrameGather(H, W, world, rank, torch.device("cpu") if rehearsal else dev, dtype=pix, buffers=2, strip_rows=strip_rows)
+    # Frames in flight: K tile buffers, K HIP streams.  A frame's last ~90 us are a few hundred latency-bound waves
+    # on an otherwise idle chip; the next frame's march fills it.  Within a buffer, frame i+K follows
+    # frame i in stream order, so a tile is never overwritten before it has been consumed.
+    K = args.frames_in_flight
+    fg = FrameGather(H, W, world, rank, torch.device("cpu") if rehearsal else dev, dtype=pix, buffers=K, strip_rows=strip_rows)
     row0, rows = fg.row0, fg.rows
     march_tiles = [torch.zeros_like(x, device=dev) for x in fg.tiles] if rehearsal else fg.tiles
-    pending = [None, None]
-    stream = torch.cuda.current_stream()
+    pending = [None] * K
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(K - 1)]
+    stream = streams[0]
 
     def step(i: int) -> None:
-        b = i & 1
-        if pending[b] is not None:
-            pending[b].wait()  # tile buffer b is free again (its gather finished)
-            pending[b] = None
-            fg.unshuffle(b)  # rank 0, strips: gathered order -> frame order (one strided device copy)
-        if strip_rows > 0:
-            r.render_strips(p, strip_rows, rank, world, fg.strips_per, march_tiles[b].data_ptr(), stream.cuda_stream)
-        else:
-            r.render_rows(p, row0, rows, march_tiles[b].data_ptr(), stream.cuda_stream)
-        if rehearsal:
-            fg.tiles[b].copy_(march_tiles[b])
-        if world > 1:
-            pending[b] = fg.gather(b, async_op=True)  # RCCL gather over xGMI, overlaps the next frame's march
+        b = i % K
+        with torch.cuda.stream(streams[b]):
+            if pending[b] is not None:
+                pending[b].wait()  # tile buffer b is free again (its gather finished); stream b waits, not the host
+                pending[b] = None
+                fg.unshuffle(b)  # rank 0, strips: gathered order -> frame order (one strided device copy)
+            if strip_rows > 0:
+                r.render_strips(p, strip_rows, rank, world, fg.strips_per, march_tiles[b].data_ptr(), streams[b].cuda_stream)
+            else:
+                r.render_rows(p, row0, rows, march_tiles[b].data_ptr(), streams[b].cuda_stream)
+            if rehearsal:
+                fg.tiles[b].copy_(march_tiles[b])
+            if world > 1:
+                pending[b] = fg.gather(b, async_op=True)  # RCCL gather over xGMI, overlaps the following frames' march
 
     def drain() -> None:
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
-                fg.unshuffle(b)
+        for b in range(K):
+            with torch.cuda.stream(streams[b]):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
+                    fg.unshuffle(b)
         torch.cuda.synchronize()
 
     def barrier() -> None:
@@ -183,7 +193,7 @@ def main() -> None:
         whole = torch.empty((H, W, 4), dtype=pix, device=dev)
         r.render_rows(p, 0, H, whole.data_ptr(), stream.cuda_stream)
         torch.cuda.synchronize()
-        got = fg.frame((args.steps - 1) & 1)
+        got = fg.frame((args.steps - 1) % K)
         verified = bool(torch.equal(got.cpu(), whole.cpu()))
         if not verified:
             raise SystemExit("[bench] gathered frame differs from the single-GPU frame")
@@ -229,6 +239,7 @@ def main() -> None:
             "config": {"workload": label, "width": W, "height": H, "volume": f"{sc.volumes()[0].N - 1}^3 cells",
                        "max_steps": max_steps, "shadow": bool(shadow), "data_path": args.path,
                        "output": "rgba8 (R8G8B8A8_UNORM tiles; march and shading in f32)" if rgba8 else "f32 (float4)",
+                       "frames_in_flight": K,
                        "parallelism": ("1 GPU" if world == 1 else
                                        (f"{strip_rows}-row interleaved strips" if strip_rows else "contiguous row tiles") +
                                        f" x{world} + " + ("gloo gather, REHEARSAL on one GPU" if rehearsal else "RCCL gather to rank 0")),

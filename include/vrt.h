@@ -237,7 +237,9 @@ int vrt_scene_set(vrt_ctx* ctx, const vrt_scene* scene);
 int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null);
 /* Render rows [row0, row0+rows) of the frame on the context's first device into a caller-owned
  * *device* buffer of rows*width float4 (uint32 R8G8B8A8 with VRT_FLAG_OUTPUT_RGBA8), asynchronously on `hip_stream` (a hipStream_t, may be
- * NULL).  No host synchronisation, no allocation: safe to capture into a hipGraph. */
+ * NULL).  No host synchronisation and — after the first launch of a given size — no allocation: safe to capture
+ * into a hipGraph.  Up to 4 launches may be in flight at once on different streams (the reference keeps 3 frames
+ * in flight, DXConstants.cpp:23): each uses its own counter buffer and event pair. */
 int vrt_render_rows(vrt_ctx* ctx, const vrt_params* params, int row0, int rows,
                     void* device_rgba, void* hip_stream);
 

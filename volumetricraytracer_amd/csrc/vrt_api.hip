@@ -30,6 +30,7 @@ using namespace vrt;
 
 namespace {
 
+constexpr int kStatSlots = 4; /* launches that may be in flight at once without sharing a counter buffer */
 constexpr int kRing = 256; /* per-launch event pairs + stat slots kept for vrt_timing_history */
 
 struct HostVolume {
@@ -70,7 +71,12 @@ struct DeviceState {
     uint8_t* tex[VRT_MAX_TEXTURES] = {};
     float* fb = nullptr;
     size_t fb_bytes = 0;
-    unsigned* d_stats = nullptr; /* kMaxBlocks x 4 x kStatRecord: per-wave records of the last launch */
+    /* per-wave records of the last kStatSlots launches (launch l uses slot l % kStatSlots): frames may be in
+       flight on different streams — the reference keeps 3 (DXConstants.cpp:23) — without sharing a buffer.
+       Grown on demand to the launch's block count. */
+    unsigned* d_stats[kStatSlots] = {};
+    size_t stats_cap[kStatSlots] = {}; /* blocks */
+    int last_slot = 0;
     unsigned* d_diag = nullptr;  /* allocated on first use of VRT_FLAG_DIAG_TIMELINE (never in a capture) */
     int last_blocks = 0;
     bool last_diag = false;
@@ -342,7 +348,6 @@ int init_device(DeviceState& D, int ordinal) {
     HIP_TRY(hipMalloc(&D.d_nodes, sizeof(DBvhNode) * kMaxBvhNodes));
     HIP_TRY(hipMalloc(&D.d_point, sizeof(DPointLight) * VRT_MAX_POINT_LIGHTS));
     HIP_TRY(hipMalloc(&D.d_spot, sizeof(DSpotLight) * VRT_MAX_SPOT_LIGHTS));
-    HIP_TRY(hipMalloc(&D.d_stats, sizeof(unsigned) * kStatRecord * 4 * (size_t)kMaxBlocks));
     for (int i = 0; i < kRing; i++) {
         HIP_TRY(hipEventCreate(&D.ev0[i]));
         HIP_TRY(hipEventCreate(&D.ev1[i]));
@@ -369,7 +374,8 @@ void destroy_device(DeviceState& D) {
     for (int i = 0; i < VRT_MAX_TEXTURES; i++)
         if (D.tex[i]) (void)hipFree(D.tex[i]);
     if (D.fb) (void)hipFree(D.fb);
-    if (D.d_stats) (void)hipFree(D.d_stats);
+    for (int i = 0; i < kStatSlots; i++)
+        if (D.d_stats[i]) (void)hipFree(D.d_stats[i]);
     if (D.d_diag) (void)hipFree(D.d_diag);
     if (D.events_ok)
         for (int i = 0; i < kRing; i++) {
@@ -609,9 +615,19 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
 int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet& rs, float* out, hipStream_t stream,
                  int ring) {
     DFrame F;
-    build_frame(ctx, D, p, rs, out, D.d_stats, F);
+    build_frame(ctx, D, p, rs, out, nullptr, F);
     if ((long long)F.tiles_x * F.tiles_y > kMaxBlocks / 2) return VRT_ERR_INVALID;
     D.last_blocks = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
+    const int slot = (int)(ctx->launches % kStatSlots);
+    if (D.stats_cap[slot] < (size_t)D.last_blocks) { /* first launch of this size in this slot: the only allocation on this path */
+        if (D.d_stats[slot]) HIP_TRY(hipFree(D.d_stats[slot]));
+        D.d_stats[slot] = nullptr;
+        D.stats_cap[slot] = 0;
+        HIP_TRY(hipMalloc(&D.d_stats[slot], sizeof(unsigned) * kStatRecord * 4 * (size_t)D.last_blocks));
+        D.stats_cap[slot] = (size_t)D.last_blocks;
+    }
+    D.last_slot = slot;
+    F.stats = D.d_stats[slot];
     D.last_diag = F.diag != 0;
     if (F.diag) {
         if (!D.d_diag) HIP_TRY(hipMalloc(&D.d_diag, sizeof(unsigned) * kDiagRecord * 4 * (size_t)kMaxBlocks));
@@ -1014,7 +1030,7 @@ int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out) {
         kernel_ms = std::max(kernel_ms, ms);
         std::vector<unsigned> rec((size_t)D.last_blocks * 4 * kStatRecord);
         if (D.last_blocks > 0)
-            HIP_TRY(hipMemcpy(rec.data(), D.d_stats, rec.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(rec.data(), D.d_stats[D.last_slot], rec.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
         for (size_t w = 0; w < (size_t)D.last_blocks * 4; w++)
             for (int k = 0; k < kStatWords; k++) tot[k] += rec[w * kStatRecord + k];
     }
@@ -1058,7 +1074,7 @@ long long vrt_debug_wave_records(vrt_ctx* ctx, int which, uint32_t* out, long lo
     if (out && max_words > 0) {
         HIP_TRY(hipSetDevice(D.ordinal));
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(out, which == 0 ? D.d_stats : D.d_diag, sizeof(uint32_t) * (size_t)std::min(words, max_words),
+        HIP_TRY(hipMemcpy(out, which == 0 ? D.d_stats[D.last_slot] : D.d_diag, sizeof(uint32_t) * (size_t)std::min(words, max_words),
                           hipMemcpyDeviceToHost));
     }
     return words;
