@@ -7,7 +7,7 @@ out="$here/../lib"
 tmp="${VRT_BUILD_TMP:-/tmp/vrtbuild}"
 mkdir -p "$out" "$tmp"
 cd "$tmp"
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -Wall -Wextra \
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -std=c++17 -Wall -Wextra \
       -save-temps=obj \
       -o "$out/libvrt_hip.so" "$here/vrt_api.hip" "$here/vrt_kernels.hip"
 # -save-temps=obj drops the intermediates next to the output; keep the ISA in $tmp, drop the rest

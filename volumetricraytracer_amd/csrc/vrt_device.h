@@ -49,8 +49,8 @@ struct DVolume {
     float metallic;        /* clamped to [0,1] */
     float k;               /* (roughness+1)^2 / 8 from the unclamped roughness */
     float pad_[2];
-    const uint8_t* skip;   /* nb^3 bytes or null: Chebyshev distance (bricks) to the nearest brick holding a
-                              sample closer than step_max to the surface; drives the empty-space leap */
+    const uint8_t* skip;   /* nb^3 bytes or null: leap count max(D-1, 0), D = Chebyshev distance (bricks) to the nearest
+                              brick holding a sample closer than step_max to the surface; drives the empty-space leap */
     /* material textures (textured render modes): R8G8B8A8, point/wrap; px null = unbound */
     const uint8_t* tex_px[3];  /* albedo, normal, rm */
     int32_t tex_w[3], tex_h[3];

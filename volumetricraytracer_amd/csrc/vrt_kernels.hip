@@ -99,6 +99,30 @@ __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
     return r;
 }
 
+/* Index of the brick that holds cell (cx,cy,cz) — also the index into the brick tables (skip, cube_skip). */
+__device__ __forceinline__ unsigned brick_index(const VolRef& V, int cx, int cy, int cz) {
+    const unsigned nb = (unsigned)V.nb;
+    return mad24(mad24((unsigned)cx >> 2, nb, (unsigned)cz >> 2), nb, (unsigned)cy >> 2);
+}
+
+/* Taps of a cell from its brick (the brick index is passed in so that the march computes it once for the
+ * taps and the empty-space table). */
+__device__ __forceinline__ Taps fetch8_brick(const VolRef& V, unsigned brick, int cx, int cy, int cz) {
+    const unsigned local = ((unsigned)cx & 3u) * 25u + ((unsigned)cz & 3u) * 5u + ((unsigned)cy & 3u);
+    const unsigned off = ((brick << 7) + local) << 2; /* bytes */
+    const gfloat_p b = (gfloat_p)((gchar_p)V.p + off);
+    Taps t;
+    t.y00a = b[0];
+    t.y00b = b[1];
+    t.y01a = b[5];
+    t.y01b = b[6];
+    t.y10a = b[25];
+    t.y10b = b[26];
+    t.y11a = b[30];
+    t.y11b = b[31];
+    return t;
+}
+
 /* Fetch the taps of cell (cx,cy,cz).  Offsets are unsigned 32-bit byte offsets from the volume
  * base (≤ 4 GiB pools), built with 24-bit multiplies (cells < 2^10, bricks < 2^24). */
 template <int PATH>
@@ -118,32 +142,25 @@ __device__ __forceinline__ Taps fetch8(const VolRef& V, int cx, int cy, int cz) 
         t.y11a = b[NN + N];
         t.y11b = b[NN + N + 1];
     } else {
-        const unsigned nb = (unsigned)V.nb;
-        const unsigned brick = mad24(mad24((unsigned)cx >> 2, nb, (unsigned)cz >> 2), nb, (unsigned)cy >> 2);
-        const unsigned local = ((unsigned)cx & 3u) * 25u + ((unsigned)cz & 3u) * 5u + ((unsigned)cy & 3u);
-        const unsigned off = ((brick << 7) + local) << 2; /* bytes */
-        const gfloat_p b = (gfloat_p)((gchar_p)V.p + off);
-        t.y00a = b[0];
-        t.y00b = b[1];
-        t.y01a = b[5];
-        t.y01b = b[6];
-        t.y10a = b[25];
-        t.y10b = b[26];
-        t.y11a = b[30];
-        t.y11b = b[31];
+        t = fetch8_brick(V, brick_index(V, cx, cy, cz), cx, cy, cz);
     }
     return t;
 }
 
-/* Trilinear interpolant from the taps: y-lerps, z-lerps, x-lerp (each lerp is one sub + one fma). */
+/* Trilinear interpolant from the taps: y-lerps, z-lerps, x-lerp (each lerp is one sub + one fma, exactly as the
+ * oracle does them).  A dwordx2 load delivers the two operands of ONE y-lerp, so the four y-lerps are scalar
+ * ops straight on the loaded pairs; their results are placed so that the two z-lerps are one packed sub and
+ * one packed fma (v_pk_*_f32 does two fp32 lanes per issue slot — the march is VALU-issue bound). */
+typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float lerp8(const Taps& t, float fx, float fy, float fz) {
-    float a00 = lerp1(t.y00a, t.y00b, fy);
-    float a01 = lerp1(t.y01a, t.y01b, fy);
-    float a10 = lerp1(t.y10a, t.y10b, fy);
-    float a11 = lerp1(t.y11a, t.y11b, fy);
-    float c0 = lerp1(a00, a01, fz);
-    float c1 = lerp1(a10, a11, fz);
-    return lerp1(c0, c1, fx);
+    float2v a0, a1; /* a0 = (z0 at x0, z0 at x1), a1 = (z1 at x0, z1 at x1) */
+    a0.x = lerp1(t.y00a, t.y00b, fy);
+    a1.x = lerp1(t.y01a, t.y01b, fy);
+    a0.y = lerp1(t.y10a, t.y10b, fy);
+    a1.y = lerp1(t.y11a, t.y11b, fy);
+    const float2v w = {fz, fz};
+    const float2v c = __builtin_elementwise_fma(w, a1 - a0, a0); /* (c0, c1) = lerp over z at x0 and x1 */
+    return lerp1(c.x, c.y, fx);
 }
 
 template <int PATH>
@@ -262,21 +279,16 @@ __device__ __forceinline__ Cell cell_at(const RaySeg& R, float t) {
 /* Empty-space leap (ray-parameter units) from cell c: (D-1) brick edges when the nearest brick that
  * can hold surface is D bricks away (Chebyshev), else 0.  The byte comes from a small L2-resident
  * table and is requested together with the taps. */
-__device__ __forceinline__ float leap_at(const VolRef& V, const RaySeg& R, const Cell& c) {
-    const unsigned nb = (unsigned)V.nb;
-    const unsigned brick = mad24(mad24((unsigned)c.cx >> 2, nb, (unsigned)c.cz >> 2), nb, (unsigned)c.cy >> 2);
-    const int d = (int)V.skip[brick];
-    return (float)(d > 1 ? d - 1 : 0) * R.leap_unit;
+__device__ __forceinline__ float leap_at(const VolRef& V, const RaySeg& R, unsigned brick) {
+    return (float)V.skip[brick] * R.leap_unit; /* the device table holds the leap count max(D-1, 0) */
 }
 
 /* Empty-space table byte of cell c's brick and its conversion to a leap (used by the hybrid march; the
  * per-lane kernels use leap_at). */
 __device__ __forceinline__ unsigned leap_byte(const VolRef& V, const Cell& c) {
-    const unsigned nb = (unsigned)V.nb;
-    const unsigned brick = mad24(mad24((unsigned)c.cx >> 2, nb, (unsigned)c.cz >> 2), nb, (unsigned)c.cy >> 2);
-    return (unsigned)V.skip[brick];
+    return (unsigned)V.skip[brick_index(V, c.cx, c.cy, c.cz)];
 }
-__device__ __forceinline__ float leap_from(const RaySeg& R, unsigned d) { return (float)(d > 1u ? d - 1u : 0u) * R.leap_unit; }
+__device__ __forceinline__ float leap_from(const RaySeg& R, unsigned d) { return (float)d * R.leap_unit; }
 
 constexpr int kRefine = 3; /* secant samples spent on a hit that overshot into the surface */
 
@@ -476,9 +488,16 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
             asm volatile("" ::"v"(c.cx), "v"(c.cy), "v"(c.cz), "v"(c.fx), "v"(c.fy), "v"(c.fz));
             st1 = stamp();
         }
-        const Taps taps = fetch8<PATH>(V, c.cx, c.cy, c.cz);
+        Taps taps;
         float leap = 0.0f;
-        if (V.skip != nullptr) leap = leap_at(V, R, c);
+        if constexpr (PATH == VRT_PATH_DENSE) {
+            taps = fetch8<PATH>(V, c.cx, c.cy, c.cz);
+            if (V.skip != nullptr) leap = leap_at(V, R, brick_index(V, c.cx, c.cy, c.cz));
+        } else {
+            const unsigned brick = brick_index(V, c.cx, c.cy, c.cz);
+            taps = fetch8_brick(V, brick, c.cx, c.cy, c.cz);
+            if (V.skip != nullptr) leap = leap_at(V, R, brick);
+        }
         if constexpr (DIAG) {
             asm volatile("s_waitcnt vmcnt(0)" ::"v"(taps.y00a), "v"(taps.y00b), "v"(taps.y01a), "v"(taps.y01b), "v"(taps.y10a),
                          "v"(taps.y10b), "v"(taps.y11a), "v"(taps.y11b));
@@ -1351,6 +1370,15 @@ __global__ __launch_bounds__(128) void skip_seed_kernel(const float* __restrict_
     if (l == 0) table[brick] = (flag[0] || flag[1]) ? 0 : 255;
 }
 
+/* The march wants the leap count, not the distance: L = max(D-1, 0) (one convert + one multiply per sample). */
+__global__ void skip_to_leap_kernel(uint8_t* __restrict__ table, int n) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n) {
+        const uint8_t d = table[i];
+        table[i] = d > 1 ? (uint8_t)(d - 1) : (uint8_t)0;
+    }
+}
+
 /* Cube modes' table, step 1: a brick is a seed (0) when one of its 4^3 cell-origin voxels is solid
  * (density <= 0); voxels beyond cell N-2 do not exist (only at resolutions < 2, where one brick covers
  * the volume). */
@@ -1509,7 +1537,10 @@ hipError_t launch_skip_table(const float* bricks, uint8_t* table, uint8_t* scrat
                              hipStream_t stream) {
     const int n = nb * nb * nb;
     hipLaunchKernelGGL(skip_seed_kernel, dim3((unsigned)n), dim3(128), 0, stream, bricks, table, density_scale, step_max);
-    return dilate_table(table, scratch, nb, stream);
+    hipError_t e = dilate_table(table, scratch, nb, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(skip_to_leap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, table, n);
+    return hipGetLastError();
 }
 
 hipError_t launch_cube_table(const float* bricks, uint8_t* table, uint8_t* scratch, int N, int nb, hipStream_t stream) {
