@@ -44,6 +44,8 @@ extern "C" {
 #define VRT_MAX_SPOT_LIGHTS  5  /* RaytracingHlsl.h:113 */
 #define VRT_MAX_INSTANCES    64
 #define VRT_MAX_DEVICES      8
+#define VRT_MAX_RESOLUTION   9    /* N = 513: the kernels address a volume with 32-bit byte offsets (brick pool 1.07 GB);
+                                     the reference's own tools stop at 8 (VolumeConverter.cpp:44-49) */
 #define VRT_MAX_TEXTURES     64   /* 2D material textures resident at once (3 per volume slot + spare) */
 #define VRT_FLAG_DIAG_TIMELINE 4 /* run the diagnostic kernel build that stamps per-wave timeline records */
 #define VRT_FLAG_OUTPUT_RGBA8 8  /* store R8G8B8A8_UNORM pixels (4 B, R in the low byte, A = 255) instead of float4:
@@ -185,7 +187,7 @@ typedef struct vrt_ctx vrt_ctx;
 int vrt_create(vrt_ctx** out, int device_count, const int* devices);
 int vrt_destroy(vrt_ctx* ctx);
 
-/* density: N^3 floats, N = 2^resolution + 1, index = x*N*N + z*N + y
+/* resolution <= VRT_MAX_RESOLUTION.  density: N^3 floats, N = 2^resolution + 1, index = x*N*N + z*N + y
  * (Core/Private/MathHelpers (2).cpp:43-46).  material_or_null: N^3 bytes, same indexing. */
 int vrt_volume_upload(vrt_ctx* ctx, int slot, uint8_t resolution, float extent,
                       const float* density, const uint8_t* material_or_null);

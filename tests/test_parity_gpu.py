@@ -251,6 +251,33 @@ def test_voxelizer_cli_on_the_device_writes_the_same_file(tmp_path):
     assert len(a) > 2_000_000 and a == b
 
 
+def test_largest_volume_parity(oracle_lib):
+    """Resolution 9 (N = 513, 135 M voxels: 540 MB dense, 1.07 GB of bricks), the largest the 32-bit addressing
+    takes (VRT_MAX_RESOLUTION): every path against the oracle; resolution 10 is refused."""
+    res = 9
+    N = (1 << res) + 1
+    g = (np.arange(N, dtype=np.float32) * np.float32(200.0 / (N - 1)) - np.float32(100.0))
+    vol = v.VVoxelVolume(res, 100.0)
+    X, Z, Y = g[:, None, None], g[None, :, None], g[None, None, :]  # density axes are (x, z, y)
+    vol.density = (np.sqrt(X * X + Y * Y + Z * Z) - np.float32(70.0)).astype(np.float32)  # sphere that reaches the far corners' bricks
+    vol.Material = v.VMaterial((0.7, 0.8, 0.9, 1.0), 0.8, 0.0)
+    sc = v.VScene(Camera=v.look_minus_x_camera(260.0, 30.0), DirectionalLight=v.demo_light(), Objects=[v.VVoxelObject(Volume=vol)],
+                  EnvironmentMap=v.procedural_skybox(16))
+    r = v.VHipRenderer()
+    assert r.Start()
+    try:
+        for path in (_abi.PATH_BRICK, _abi.PATH_DENSE):
+            p = v.default_params(256, 144, vol.GetCellSize(), 255, shadow=True, path=path)
+            img, t = assert_parity(r, sc, p)
+            assert t["hits"] > 3000
+        p = v.default_params(256, 144, vol.GetCellSize(), 255, shadow=True, mode=_abi.MODE_CUBE_NOTEX)
+        assert_parity(r, sc, p)
+        one = np.zeros(8, np.float32)
+        assert r._lib.vrt_volume_upload(r._ctx, 1, 10, 100.0, one.ctypes.data_as(C.c_void_p), None) == _abi.VRT_ERR_INVALID
+    finally:
+        r.Stop()
+
+
 def test_cube_mode_edge_cases(renderer, oracle_lib):
     """Camera inside the volume and inside a solid voxel, 1-step budget, ragged frame, resolution 0 and 1."""
     sc = scenes.config2_sphere(5, 16)

@@ -11,6 +11,7 @@ import os
 
 VRT_MAX_VOLUMES = 20
 VRT_MAX_TEXTURES = 64
+VRT_MAX_RESOLUTION = 9
 VRT_MAX_POINT_LIGHTS = 5
 VRT_MAX_SPOT_LIGHTS = 5
 VRT_MAX_INSTANCES = 64

@@ -399,7 +399,7 @@ int upload_volume(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, cons
                   const uint8_t* material, const vrt_voxel* voxels, const MeshSource* mesh = nullptr) {
     if (!ctx) return VRT_ERR_INVALID;
     if (!valid_slot(slot)) return VRT_ERR_SLOT;
-    if (resolution > 10 || !(extent > 0.0f) || (!density && !voxels && !mesh)) return VRT_ERR_INVALID;
+    if (resolution > VRT_MAX_RESOLUTION || !(extent > 0.0f) || (!density && !voxels && !mesh)) return VRT_ERR_INVALID;
     const int N = (1 << resolution) + 1; /* VoxelVolume.cpp:23 */
     const int nb = (N - 1 + kBrickCells - 1) / kBrickCells;
     const size_t count = (size_t)N * N * N;
@@ -704,7 +704,7 @@ int vrt_voxelize_mesh(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, 
                       const uint32_t* indices, size_t n_indices, size_t* skipped_or_null) {
     if (!ctx || (!positions && n_vertices > 0) || (!indices && n_indices > 0)) return VRT_ERR_INVALID;
     if (!valid_slot(slot)) return VRT_ERR_SLOT;
-    if (resolution > 10 || !(extent > 0.0f)) return VRT_ERR_INVALID;
+    if (resolution > VRT_MAX_RESOLUTION || !(extent > 0.0f)) return VRT_ERR_INVALID;
     const int N = (1 << resolution) + 1;
     const float cell = (extent * 2.0f) / (float)(N - 1);
     MeshSource mesh;

@@ -122,8 +122,8 @@ class VVoxelVolume:
     """
 
     def __init__(self, resolution: int, extent: float):
-        if not (0 <= resolution <= 10):
-            raise ValueError("resolution must be within 0..10")
+        if not (0 <= resolution <= 9):
+            raise ValueError("resolution must be within 0..9 (VRT_MAX_RESOLUTION)")
         self.Resolution = int(resolution)
         self.VolumeExtends = float(extent)
         self.N = (1 << self.Resolution) + 1                      # VoxelVolume.cpp:23
