@@ -170,3 +170,21 @@ def test_vox_reader_is_order_agnostic_and_rejects_garbage(tmp_path):
         vox_io.load_scene(bad)
     with pytest.raises(RuntimeError):
         vx.voxelize_file(str(tmp_path / "missing.gltf"))
+
+
+def test_glb_container_gives_the_same_scene(tmp_path):
+    """Binary glTF (.glb: JSON chunk + BIN chunk = buffer 0) through the same importer: the .vox is identical to the
+    one from the .gltf + .bin pair."""
+    pos, nrm, idx = vx.cube_mesh(0.5)
+    gltf, glb = str(tmp_path / "scene.gltf"), str(tmp_path / "packed.glb")
+    nodes = [{"name": "Cube", "mesh": 0, "translation": [1.0, 2.0, 3.0]}, {"name": "Light_Sun", "extras": {"strength": 6.0}}]
+    vx.write_gltf(gltf, [("cube_4", pos, nrm, idx, None)], nodes)
+    vx.gltf_to_glb(gltf, glb)
+    out_a, out_b = str(tmp_path / "a.vox"), str(tmp_path / "b.vox")
+    ra = subprocess.run([VOXELIZER, "--out", out_a, gltf], capture_output=True, text=True)
+    rb = subprocess.run([VOXELIZER, "--out", out_b, glb], capture_output=True, text=True)
+    assert ra.returncode == 0 and rb.returncode == 0, ra.stderr + rb.stderr
+    assert open(out_a, "rb").read() == open(out_b, "rb").read()
+    # a truncated container is an error, not a crash
+    open(glb, "r+b").truncate(40)
+    assert subprocess.run([VOXELIZER, "--out", out_b, glb], capture_output=True, text=True).returncode == 1

@@ -1,6 +1,7 @@
 #include "GltfImporter.h"
 
 #include <cstring>
+#include <algorithm>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -102,8 +103,40 @@ VLightInfo light_from_node(const minijson::Value& node) {
 
 }  // namespace
 
+/* Binary glTF container (.glb, glTF 2.0 spec §4.4): 12-byte header (magic "glTF", version 2, total length), then
+   chunks of (u32 length, u32 type, payload): the first is JSON, an optional second one is BIN = buffer 0 when that
+   buffer has no uri.  The reference gets this from the Microsoft glTF SDK's GLBResourceReader. */
+bool split_glb(const std::string& file, std::string& json, std::string& bin) {
+    auto u32 = [&](size_t at) {
+        return (uint32_t)(unsigned char)file[at] | (uint32_t)(unsigned char)file[at + 1] << 8 | (uint32_t)(unsigned char)file[at + 2] << 16 |
+               (uint32_t)(unsigned char)file[at + 3] << 24;
+    };
+    if (file.size() < 12 || u32(0) != 0x46546C67u) return false; /* "glTF" */
+    if (u32(4) != 2) throw std::runtime_error("unsupported .glb container version");
+    const size_t total = std::min<size_t>(u32(8), file.size());
+    size_t at = 12;
+    bool have_json = false;
+    while (at + 8 <= total) {
+        const size_t len = u32(at);
+        const uint32_t type = u32(at + 4);
+        if (at + 8 + len > total) throw std::runtime_error("truncated .glb chunk");
+        if (type == 0x4E4F534Au && !have_json) { /* "JSON" */
+            json = file.substr(at + 8, len);
+            have_json = true;
+        } else if (type == 0x004E4942u && bin.empty()) { /* "BIN\0" */
+            bin = file.substr(at + 8, len);
+        }
+        at += 8 + ((len + 3) & ~(size_t)3);
+    }
+    if (!have_json) throw std::runtime_error(".glb without a JSON chunk");
+    return true;
+}
+
 std::shared_ptr<VSceneInfo> VGLTFImporter::ImportScene(const std::string& gltfPath) {
-    const minijson::ValuePtr root = minijson::Parse(read_file(gltfPath, false));
+    const std::string file = read_file(gltfPath, true);
+    std::string json, glb_bin;
+    const bool is_glb = split_glb(file, json, glb_bin);
+    const minijson::ValuePtr root = minijson::Parse(is_glb ? json : file);
     const minijson::Value& doc = *root;
     if (!doc.IsObject()) throw std::runtime_error("glTF manifest is not a JSON object");
 
@@ -116,8 +149,10 @@ std::shared_ptr<VSceneInfo> VGLTFImporter::ImportScene(const std::string& gltfPa
             buffers.data.push_back(base64_decode(uri.substr(comma + 1)));
         } else if (!uri.empty()) {
             buffers.data.push_back(read_file(dir_of(gltfPath) + uri, true));
+        } else if (is_glb && i == 0) {
+            buffers.data.push_back(glb_bin); /* the container's BIN chunk */
         } else {
-            throw std::runtime_error("buffer without a uri (.glb is not supported)");
+            throw std::runtime_error("buffer without a uri outside a .glb container");
         }
     }
 

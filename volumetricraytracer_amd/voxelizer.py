@@ -176,3 +176,22 @@ def write_gltf(path: str, meshes, nodes, materials=None, embed: bool = False) ->
     if not embed:
         with open(os.path.join(os.path.dirname(path), bin_name), "wb") as f:
             f.write(bytes(blob))
+
+
+def gltf_to_glb(gltf_path: str, glb_path: str) -> None:
+    """Packs a .gltf with ONE external .bin buffer into a binary .glb container (glTF 2.0 spec §4.4)."""
+    import json
+    import struct
+
+    doc = json.load(open(gltf_path))
+    if len(doc.get("buffers", [])) != 1 or doc["buffers"][0].get("uri", "").startswith("data:"):
+        raise ValueError("expects exactly one external buffer")
+    blob = open(os.path.join(os.path.dirname(gltf_path), doc["buffers"][0].pop("uri")), "rb").read()
+    js = json.dumps(doc, separators=(",", ":")).encode()
+    js += b" " * (-len(js) % 4)
+    blob += b"\0" * (-len(blob) % 4)
+    total = 12 + 8 + len(js) + 8 + len(blob)
+    with open(glb_path, "wb") as f:
+        f.write(struct.pack("<4sII", b"glTF", 2, total))
+        f.write(struct.pack("<II", len(js), 0x4E4F534A) + js)
+        f.write(struct.pack("<II", len(blob), 0x004E4942) + blob)
