@@ -590,7 +590,7 @@ def test_cpp_host_adaptor_renders_the_demo_scene(renderer, tmp_path):
 
 def test_cpp_host_adaptor_binds_material_textures_from_a_vox_scene(renderer, tmp_path):
     """A .vox scene whose material names texture files (VMaterial::AlbedoTexturePath / RMTexturePath, Material.h:29-31):
-    the C++ adaptor resolves the paths (binary PPM here; the reference decodes with WIC/DDS), uploads them through
+    the C++ adaptor resolves the paths (a PNG and a binary PPM here; the reference decodes with WIC/DDS), uploads them through
     vrt_texture_upload and binds them with vrt_volume_set_textures.  Same frame as the Python host with the same images."""
     import subprocess
 
@@ -603,8 +603,10 @@ def test_cpp_host_adaptor_binds_material_textures_from_a_vox_scene(renderer, tmp
             f.write(b"P6\n# material texture\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
             f.write(np.ascontiguousarray(img[..., :3]).tobytes())
 
-    alb_path, rm_path = str(tmp_path / "albedo.ppm"), str(tmp_path / "rm.ppm")
-    write_ppm(alb_path, alb)
+    from test_voxelizer import _write_png
+
+    alb_path, rm_path = str(tmp_path / "albedo.png"), str(tmp_path / "rm.ppm")
+    _write_png(alb_path, alb[..., :3], 2)  # one texture through the PNG decoder, one through the PPM reader
     write_ppm(rm_path, rm)
     rm_rgb = rm.copy()
     rm_rgb[..., 3] = 255

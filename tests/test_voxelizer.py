@@ -188,3 +188,95 @@ def test_glb_container_gives_the_same_scene(tmp_path):
     # a truncated container is an error, not a crash
     open(glb, "r+b").truncate(40)
     assert subprocess.run([VOXELIZER, "--out", out_b, glb], capture_output=True, text=True).returncode == 1
+
+
+def _write_png(path, img, colour, filters=(0, 1, 2, 3, 4), palette=None, idat_split=3):
+    """Minimal PNG writer (8 bit, non-interlaced) that applies the given row filters in turn — exercises every
+    un-filter path of the reader."""
+    import struct
+    import zlib
+
+    h, w = img.shape[:2]
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[colour]
+    rows = img.reshape(h, w * ch).astype(np.int32)
+    raw = bytearray()
+    prev = np.zeros(w * ch, np.int32)
+    for y in range(h):
+        ft = filters[y % len(filters)]
+        cur = rows[y]
+        a = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+        c = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+        if ft == 0:
+            pred = 0
+        elif ft == 1:
+            pred = a
+        elif ft == 2:
+            pred = prev
+        elif ft == 3:
+            pred = (a + prev) // 2
+        else:
+            p = a + prev - c
+            pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        raw.append(ft)
+        raw.extend(((cur - pred) & 0xff).astype(np.uint8).tobytes())
+        prev = cur
+    z = zlib.compress(bytes(raw), 6)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, colour, 0, 0, 0)))
+        if palette is not None:
+            f.write(chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes()))
+        f.write(chunk(b"tEXt", b"Comment\0test"))
+        step = max(1, len(z) // idat_split)
+        for i in range(0, len(z), step):
+            f.write(chunk(b"IDAT", z[i:i + step]))
+        f.write(chunk(b"IEND", b""))
+
+
+def test_png_and_ppm_texture_loader(tmp_path):
+    """The C++ host's material-texture decoder (VTexture2D::LoadFromFile: PNG via zlib, binary PPM): every colour type
+    and every row filter, split IDAT chunks, ancillary chunks; rejects what it does not support."""
+    rng = np.random.default_rng(11)
+    h, w = 13, 9
+    rgba = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    p = str(tmp_path / "t.png")
+    _write_png(p, rgba, 6)
+    assert np.array_equal(vx.load_texture(p), rgba)
+    _write_png(p, rgba[..., :3], 2, filters=(4, 3, 1))
+    got = vx.load_texture(p)
+    assert np.array_equal(got[..., :3], rgba[..., :3]) and (got[..., 3] == 255).all()
+    _write_png(p, rgba[..., 0], 0, filters=(2,))
+    got = vx.load_texture(p)
+    assert all(np.array_equal(got[..., c], rgba[..., 0]) for c in range(3)) and (got[..., 3] == 255).all()
+    _write_png(p, rgba[..., :2], 4)
+    got = vx.load_texture(p)
+    assert np.array_equal(got[..., 0], rgba[..., 0]) and np.array_equal(got[..., 3], rgba[..., 1])
+    pal = rng.integers(0, 256, size=(7, 3), dtype=np.uint8)
+    idx = rng.integers(0, 7, size=(h, w), dtype=np.uint8)
+    _write_png(p, idx, 3, palette=pal)
+    got = vx.load_texture(p)
+    assert np.array_equal(got[..., :3], pal[idx]) and (got[..., 3] == 255).all()
+    try:  # an encoder that is not this test's own
+        from PIL import Image
+        Image.fromarray(rgba, "RGBA").save(p, optimize=True)
+        assert np.array_equal(vx.load_texture(p), rgba)
+    except ImportError:
+        pass
+    ppm = str(tmp_path / "t.ppm")
+    with open(ppm, "wb") as f:
+        f.write(b"P6\n# c\n%d %d\n255\n" % (w, h) + rgba[..., :3].tobytes())
+    got = vx.load_texture(ppm)
+    assert np.array_equal(got[..., :3], rgba[..., :3])
+    # unsupported / broken files are refused
+    _write_png(p, idx, 3, palette=pal[:2])  # palette index out of range
+    with pytest.raises(RuntimeError):
+        vx.load_texture(p)
+    open(p, "wb").write(open(ppm, "rb").read()[:20])
+    with pytest.raises(RuntimeError):
+        vx.load_texture(p)
+    with pytest.raises(RuntimeError):
+        vx.load_texture(str(tmp_path / "missing.png"))

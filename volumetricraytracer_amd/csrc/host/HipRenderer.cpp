@@ -4,6 +4,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
+
+#include <zlib.h>
 
 #define V_LOG_ERROR(msg) fprintf(stderr, "[VHipRenderer][error] %s\n", (msg))
 #define V_LOG_WARNING(msg) fprintf(stderr, "[VHipRenderer][warning] %s\n", (msg))
@@ -51,6 +54,86 @@ VObjectPtr<VTexture2D> VTexture2D::LoadPPM(const std::string& path) {
     }
     fclose(f);
     return out;
+}
+
+namespace {
+uint32_t be32(const unsigned char* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | (uint32_t)p[3]; }
+int paeth(int a, int b, int c) {
+    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+}  // namespace
+
+VObjectPtr<VTexture2D> VTexture2D::LoadPNG(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return nullptr;
+    std::vector<unsigned char> file;
+    unsigned char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + n);
+    fclose(f);
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (file.size() < 8 + 25 || memcmp(file.data(), sig, 8) != 0) return nullptr;
+    uint32_t w = 0, h = 0;
+    int colour = -1;
+    std::vector<unsigned char> idat, palette;
+    for (size_t at = 8; at + 12 <= file.size();) {
+        const uint32_t len = be32(&file[at]);
+        const unsigned char* type = &file[at + 4];
+        if (at + 12 + (size_t)len > file.size()) return nullptr;
+        const unsigned char* data = &file[at + 8];
+        if (!memcmp(type, "IHDR", 4) && len >= 13) {
+            w = be32(data);
+            h = be32(data + 4);
+            if (data[8] != 8 || data[10] != 0 || data[11] != 0 || data[12] != 0) return nullptr; /* 8 bit, no interlace */
+            colour = data[9];
+        } else if (!memcmp(type, "PLTE", 4)) {
+            palette.assign(data, data + len);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            break;
+        }
+        at += 12 + (size_t)len;
+    }
+    const int channels = colour == 0 ? 1 : colour == 2 ? 3 : colour == 3 ? 1 : colour == 4 ? 2 : colour == 6 ? 4 : 0;
+    if (!channels || w == 0 || h == 0 || w > 16384 || h > 16384 || (colour == 3 && palette.size() < 3)) return nullptr;
+    const size_t stride = (size_t)w * channels;
+    std::vector<unsigned char> raw((stride + 1) * h);
+    uLongf rawLen = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size()) return nullptr;
+    std::vector<unsigned char> img(stride * h);
+    for (uint32_t y = 0; y < h; y++) { /* undo the per-row filters (PNG spec §9) */
+        const unsigned char* src = &raw[(stride + 1) * y];
+        unsigned char* row = &img[stride * y];
+        const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
+        const int filter = src[0];
+        if (filter > 4) return nullptr;
+        for (size_t x = 0; x < stride; x++) {
+            const int a = x >= (size_t)channels ? row[x - channels] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)channels) ? up[x - channels] : 0;
+            const int pred = filter == 0 ? 0 : filter == 1 ? a : filter == 2 ? b : filter == 3 ? (a + b) / 2 : paeth(a, b, c);
+            row[x] = (unsigned char)(src[1 + x] + pred);
+        }
+    }
+    std::vector<uint8_t> rgba((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        const unsigned char* p = &img[i * channels];
+        uint8_t r, g, b, a = 255;
+        if (colour == 0) { r = g = b = p[0]; }
+        else if (colour == 4) { r = g = b = p[0]; a = p[1]; }
+        else if (colour == 3) {
+            const size_t k = (size_t)p[0] * 3;
+            if (k + 2 >= palette.size()) return nullptr;
+            r = palette[k]; g = palette[k + 1]; b = palette[k + 2];
+        } else { r = p[0]; g = p[1]; b = p[2]; if (colour == 6) a = p[3]; }
+        rgba[i * 4] = r; rgba[i * 4 + 1] = g; rgba[i * 4 + 2] = b; rgba[i * 4 + 3] = a;
+    }
+    return std::make_shared<VTexture2D>((size_t)w, (size_t)h, std::move(rgba));
+}
+
+VObjectPtr<VTexture2D> VTexture2D::LoadFromFile(const std::string& path) {
+    if (VObjectPtr<VTexture2D> t = LoadPNG(path)) return t;
+    return LoadPPM(path);
 }
 
 namespace Renderer {
@@ -146,8 +229,8 @@ int VHipRenderer::ResolveTexture(const std::string& path) {
     auto it = Textures.find(path);
     if (it == Textures.end()) {
         TextureEntry e;
-        e.Texture = VTexture2D::LoadPPM(path);
-        if (!e.Texture) fprintf(stderr, "[VHipRenderer][warning] material texture '%s' is neither registered nor a binary PPM; left unbound\n", path.c_str());
+        e.Texture = VTexture2D::LoadFromFile(path);
+        if (!e.Texture) fprintf(stderr, "[VHipRenderer][warning] material texture '%s' is neither registered nor a readable PNG / binary PPM; left unbound\n", path.c_str());
         it = Textures.emplace(path, e).first;
     }
     if (!it->second.Texture) return -1;

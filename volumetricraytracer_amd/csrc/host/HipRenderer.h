@@ -36,7 +36,7 @@ public:
 
     /* Material textures are looked up by the path a VMaterial names (the reference's path-keyed table,
        RDXScene.cpp:771-800, 905-925).  An application that decodes its own images registers them here; paths
-       nobody registered are tried once as binary PPM files and otherwise stay unbound (logged). */
+       nobody registered are tried once as PNG / binary PPM files and otherwise stay unbound (logged). */
     void RegisterTexture(const std::string& path, VObjectPtr<VTexture2D> texture);
 
     /* backend-specific */

@@ -102,4 +102,24 @@ int vrh_vox_rewrite(const char* in_path, const char* out_path) {
     }
 }
 
+/* Decode a material texture file (PNG or binary PPM) the way VHipRenderer resolves VMaterial texture paths.
+   Writes width/height; copies width*height*4 RGBA8 bytes when out is non-null and cap suffices.  0 / -1. */
+int vrh_texture_load(const char* path, int* width, int* height, uint8_t* out, size_t cap) {
+    VObjectPtr<VTexture2D> t = VTexture2D::LoadFromFile(path ? path : "");
+    if (!t) {
+        g_error = std::string("cannot decode ") + (path ? path : "(null)");
+        return -1;
+    }
+    if (width) *width = (int)t->GetWidth();
+    if (height) *height = (int)t->GetHeight();
+    if (out) {
+        if (cap < t->GetPixels().size()) {
+            g_error = "buffer too small";
+            return -1;
+        }
+        memcpy(out, t->GetPixels().data(), t->GetPixels().size());
+    }
+    return 0;
+}
+
 }  // extern "C"

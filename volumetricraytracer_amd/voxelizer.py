@@ -195,3 +195,18 @@ def gltf_to_glb(gltf_path: str, glb_path: str) -> None:
         f.write(struct.pack("<4sII", b"glTF", 2, total))
         f.write(struct.pack("<II", len(js), 0x4E4F534A) + js)
         f.write(struct.pack("<II", len(blob), 0x004E4942) + blob)
+
+
+def load_texture(path: str) -> np.ndarray:
+    """Decodes a material texture file (PNG or binary PPM) with the C++ host loader VHipRenderer uses for
+    VMaterial texture paths; returns uint8 [H, W, 4]."""
+    lib = load_host()
+    lib.vrh_texture_load.restype = C.c_int
+    lib.vrh_texture_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+    w, h = C.c_int(), C.c_int()
+    if lib.vrh_texture_load(path.encode(), C.byref(w), C.byref(h), None, 0) != 0:
+        raise RuntimeError("vrh_texture_load: " + lib.vrh_last_error().decode())
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    if lib.vrh_texture_load(path.encode(), None, None, out.ctypes.data, out.nbytes) != 0:
+        raise RuntimeError("vrh_texture_load: " + lib.vrh_last_error().decode())
+    return out
