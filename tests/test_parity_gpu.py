@@ -471,6 +471,39 @@ def test_bench_two_rank_rehearsal(oracle_lib):
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
 
 
+def test_render_rows_can_be_captured_into_a_graph(renderer, oracle_lib):
+    """vrt_render_rows makes no host synchronisation and (after the first launch of a size) no allocation, so a frame
+    can be captured into a HIP graph and replayed (include/vrt.h): same pixels as the direct launch; a captured launch
+    is not event-timed (0 ms) but its counters are read back."""
+    import torch
+
+    sc = scenes.config3_torus(6, 16)
+    p = v.default_params(200, 120, scenes.min_cell(sc), 255, shadow=True)
+    renderer.SetSceneToRender(sc)
+    renderer.SyncWithScene()
+    ref, st = OracleScene(sc).render(p, threads=8)
+    direct = torch.zeros((120, 200, 4), dtype=torch.float32, device="cuda:0")
+    for _ in range(4):  # every counter slot has seen this launch size: nothing left to allocate
+        renderer.render_rows(p, 0, 120, direct.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = torch.zeros_like(direct)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        renderer.render_rows(p, 0, 120, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert float(out.abs().max()) == 0.0  # capture does not execute
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, direct)
+    assert np.abs(out.cpu().numpy() - ref).max() <= TOL
+    t = renderer.last_timing()
+    assert t["kernel_ms"] == 0.0 and t["primary_steps"] == st["primary_steps"] and t["hits"] == st["hits"]
+    renderer.render_rows(p, 0, 120, direct.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert renderer.last_timing()["kernel_ms"] > 0.0
+
+
 def test_multi_tile_context_on_one_gpu(oracle_lib):
     """A context with two logical devices (the same ordinal twice) exercises the row-tile split
     and the gather into device 0's frame that an 8-GPU context uses."""
@@ -483,6 +516,11 @@ def test_multi_tile_context_on_one_gpu(oracle_lib):
         ref, st = OracleScene(sc).render(p, threads=8)
         assert np.abs(img - ref).max() <= TOL
         assert t["primary_rays"] == 160 * 90 and t["hits"] == st["hits"]
+        q = _abi.vrt_params.from_buffer_copy(p)
+        q.flags |= _abi.FLAG_OUTPUT_RGBA8  # the 4-byte tiles take the same split + peer gather
+        img8, _ = gpu_render(r2, sc, q)
+        from test_tiles_gloo import quantize_rgba8
+        assert img8.dtype == np.uint8 and np.array_equal(img8, quantize_rgba8(img))
     finally:
         r2.Stop()
 

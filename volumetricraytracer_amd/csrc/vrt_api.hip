@@ -83,6 +83,7 @@ struct DeviceState {
     hipEvent_t ev0[kRing];
     hipEvent_t ev1[kRing];
     bool events_ok = false;
+    bool timed[kRing] = {}; /* launch in this ring slot recorded its event pair (false: captured into a graph) */
 };
 
 }  // namespace
@@ -633,10 +634,15 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
         if (!D.d_diag) HIP_TRY(hipMalloc(&D.d_diag, sizeof(unsigned) * kDiagRecord * 4 * (size_t)kMaxBlocks));
         F.diag_buf = D.d_diag;
     }
-    HIP_TRY(hipEventRecord(D.ev0[ring], stream));
+    /* a launch that is being captured into a hipGraph is not timed: the event pair would become graph nodes and
+       never hold a time stamp of its own (vrt_last_timing / vrt_timing_history report 0 ms for it) */
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream != nullptr && hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    D.timed[ring] = cap == hipStreamCaptureStatusNone;
+    if (D.timed[ring]) HIP_TRY(hipEventRecord(D.ev0[ring], stream));
     const bool single = ctx->scene.n_instances == 1;
     HIP_TRY(launch_march(F, resolve_path(p->path, single, p->mode), single, stream));
-    HIP_TRY(hipEventRecord(D.ev1[ring], stream));
+    if (D.timed[ring]) HIP_TRY(hipEventRecord(D.ev1[ring], stream));
     return VRT_OK;
 }
 
@@ -1024,9 +1030,13 @@ int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out) {
     for (int g = 0; g < ctx->last_devices; g++) {
         DeviceState& D = ctx->dev[(size_t)g];
         HIP_TRY(hipSetDevice(D.ordinal));
-        HIP_TRY(hipEventSynchronize(D.ev1[ring]));
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, D.ev0[ring], D.ev1[ring]));
+        if (D.timed[ring]) {
+            HIP_TRY(hipEventSynchronize(D.ev1[ring]));
+            HIP_TRY(hipEventElapsedTime(&ms, D.ev0[ring], D.ev1[ring]));
+        } else {
+            HIP_TRY(hipDeviceSynchronize()); /* captured launch: wait for whatever replay is in flight before reading the counters */
+        }
         kernel_ms = std::max(kernel_ms, ms);
         std::vector<unsigned> rec((size_t)D.last_blocks * 4 * kStatRecord);
         if (D.last_blocks > 0)
@@ -1057,9 +1067,11 @@ int vrt_timing_history(vrt_ctx* ctx, int n, float* kernel_ms_out) {
     for (int i = 0; i < m; i++) {
         const uint64_t launch = ctx->launches - (uint64_t)m + (uint64_t)i;
         const int ring = (int)(launch % kRing);
-        HIP_TRY(hipEventSynchronize(D.ev1[ring]));
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, D.ev0[ring], D.ev1[ring]));
+        if (D.timed[ring]) {
+            HIP_TRY(hipEventSynchronize(D.ev1[ring]));
+            HIP_TRY(hipEventElapsedTime(&ms, D.ev0[ring], D.ev1[ring]));
+        }
         kernel_ms_out[i] = ms;
     }
     return m;
