@@ -141,3 +141,72 @@ def textured_scene(resolution: int = 6, env: int = 32) -> v.VScene:
     m = vols[2].Material
     m.NormalTexture, m.RMTexture, m.TextureScale = nrm, rm, (61.0, 44.0)
     return sc
+
+
+def random_scene(seed: int):
+    """A seeded random scene + march parameters for the fuzz parity test: 1-6 instances of 1-3 volumes (sphere / torus /
+    CSG / voxelized shell at resolutions 3-6) with arbitrary rotation, anisotropic (also mirrored) scale and material,
+    a camera somewhere around (sometimes inside a volume), optional point / spot lights, textures, sky, any render
+    mode, shadow on/off, 0-2 bounces, small or large step budgets, cone termination on/off."""
+    rng = np.random.default_rng(1000 + seed)
+
+    def material():
+        m = v.VMaterial(tuple(rng.uniform(0.05, 1.0, 3)) + (1.0,), float(rng.uniform(0.02, 1.0)), float(rng.uniform(0.0, 1.0)))
+        if rng.random() < 0.35:
+            alb, nrm, rm = procedural_textures(int(rng.integers(0, 1000)))
+            if rng.random() < 0.7:
+                m.AlbedoTexture = alb
+            if rng.random() < 0.5:
+                m.NormalTexture = nrm
+            if rng.random() < 0.5:
+                m.RMTexture = rm
+            m.TextureScale = (float(rng.uniform(5, 120)), float(rng.uniform(5, 120)))
+        return m
+
+    vols = []
+    for _ in range(int(rng.integers(1, 4))):
+        kind, res = int(rng.integers(0, 4)), int(rng.integers(3, 7))
+        if kind == 0:
+            vol = v.sphere_volume(res, 100.0, float(rng.uniform(25, 80)), material())
+        elif kind == 1:
+            vol = v.torus_volume(res, 100.0, float(rng.uniform(35, 60)), float(rng.uniform(12, 30)), material())
+        elif kind == 2:
+            vol = v.csg_volume(res, 100.0, material())
+        else:
+            vol = voxelized_torus(min(res, 5), material())
+        vols.append(vol)
+    objs = []
+    for _ in range(int(rng.integers(1, 7))):
+        axis = rng.normal(size=3)
+        q = v.quat_from_axis_angle(tuple(axis / np.linalg.norm(axis)), float(rng.uniform(0, 2 * math.pi)))
+        sc = rng.uniform(0.4, 1.8, 3) * (rng.choice([1.0, 1.0, 1.0, -1.0], 3))
+        objs.append(v.VVoxelObject(Position=tuple(rng.uniform(-160, 160, 3)), Rotation=tuple(q), Scale=tuple(float(x) for x in sc),
+                                   Volume=vols[int(rng.integers(0, len(vols)))]))
+    used = {id(o.Volume) for o in objs}
+    cam_pos = rng.uniform(-1, 1, 3)
+    cam_pos = cam_pos / np.linalg.norm(cam_pos) * rng.uniform(60, 650)
+    yaw = math.atan2(-cam_pos[1], -cam_pos[0])
+    pitch = math.atan2(cam_pos[2], math.hypot(cam_pos[0], cam_pos[1]))  # looks at the origin (pitch about +Y tilts +X towards -Z... up)
+    cam_q = v.quat_mul(v.quat_from_axis_angle(v.UP, yaw), v.quat_from_axis_angle(v.RIGHT, pitch))
+    cam = v.VCamera(Position=tuple(float(x) for x in cam_pos), Rotation=tuple(cam_q), FOVAngle=float(rng.uniform(30, 95)))
+    light_axis = rng.normal(size=3)
+    light = v.VLight(Rotation=tuple(v.quat_from_axis_angle(tuple(light_axis / np.linalg.norm(light_axis)), float(rng.uniform(0, 6.28)))),
+                     IlluminationStrength=float(rng.uniform(0, 8)))
+    points = [v.VPointLight(Position=tuple(rng.uniform(-300, 300, 3)), IlluminationStrength=float(rng.uniform(50, 900)),
+                            Color=tuple(rng.uniform(0.2, 1, 3)) + (1.0,), AttenuationLinear=float(rng.uniform(0.005, 0.1)),
+                            AttenuationExp=float(rng.uniform(0.0002, 0.01))) for _ in range(int(rng.integers(0, 3)))]
+    spots = []
+    for _ in range(int(rng.integers(0, 3))):
+        a = rng.normal(size=3)
+        spots.append(v.VSpotLight(Position=tuple(rng.uniform(-300, 300, 3)),
+                                  Rotation=tuple(v.quat_from_axis_angle(tuple(a / np.linalg.norm(a)), float(rng.uniform(0, 6.28)))),
+                                  IlluminationStrength=float(rng.uniform(100, 1500)), Color=tuple(rng.uniform(0.2, 1, 3)) + (1.0,),
+                                  AttenuationLinear=float(rng.uniform(0.005, 0.05)), AttenuationExp=float(rng.uniform(0.0002, 0.005)),
+                                  FalloffAngle=float(rng.uniform(10, 40)), Angle=float(rng.uniform(45, 120))))
+    env = v.procedural_skybox(int(rng.choice([4, 16, 33]))) if rng.random() < 0.8 else None
+    scene = v.VScene(Camera=cam, DirectionalLight=light, Objects=objs, PointLights=points, SpotLights=spots, EnvironmentMap=env)
+    w, h = int(rng.integers(40, 130)), int(rng.integers(30, 80))
+    p = v.default_params(w, h, min(vol.GetCellSize() for vol in vols if id(vol) in used), int(rng.choice([3, 40, 255])),
+                         shadow=bool(rng.random() < 0.7), mode=int(rng.integers(0, 8)), cone=bool(rng.random() < 0.7))
+    p.max_bounces = int(rng.integers(0, 3))
+    return scene, p
