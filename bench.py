@@ -72,6 +72,7 @@ def main() -> None:
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3, 4],
                     help="frames launched before the first one must have finished, each on its own HIP stream and tile buffer "
                          "(the reference keeps 3 in flight, DXConstants.cpp:23)")
+    ap.add_argument("--tile-map", default="supertile", choices=["supertile", "band", "linear"], help="blockIdx -> tile map (speed only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
@@ -115,6 +116,7 @@ def main() -> None:
     p = v.default_params(W, H, scenes.min_cell(sc), max_steps, shadow=shadow, path=path)
     if rgba8:
         p.flags |= _abi.FLAG_OUTPUT_RGBA8
+    p.flags |= {"supertile": 0, "band": 1, "linear": 2}[args.tile_map]
 
     r = v.VHipRenderer(devices=(local_rank,))
     if not r.Start():

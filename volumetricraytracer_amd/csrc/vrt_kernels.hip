@@ -818,10 +818,14 @@ __device__ __forceinline__ unsigned unorm8(float c) {
 
 __device__ __forceinline__ void store_pixel(const DFrame& F, int px, int pyl, F3 color) {
     const float r = tonemap(color.x), g = tonemap(color.y), b = tonemap(color.z);
+    /* streaming stores: a frame writes as many bytes as an XCD's whole L2 holds; they must not push the bricks out */
     if (F.rgba8) {
-        reinterpret_cast<unsigned*>(F.out)[(size_t)pyl * F.width + px] = unorm8(r) | unorm8(g) << 8 | unorm8(b) << 16 | 0xff000000u;
+        __builtin_nontemporal_store(unorm8(r) | unorm8(g) << 8 | unorm8(b) << 16 | 0xff000000u,
+                                    reinterpret_cast<unsigned*>(F.out) + ((size_t)pyl * F.width + px));
     } else {
-        reinterpret_cast<float4*>(F.out)[(size_t)pyl * F.width + px] = make_float4(r, g, b, 1.0f);
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v = {r, g, b, 1.0f};
+        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(F.out) + ((size_t)pyl * F.width + px));
     }
 }
 
