@@ -526,17 +526,19 @@ def test_random_scenes_parity(oracle_lib, seed):
 
 
 def test_multi_tile_context_on_one_gpu(oracle_lib):
-    """A context with two logical devices (the same ordinal twice) exercises the row-tile split
-    and the gather into device 0's frame that an 8-GPU context uses."""
+    """A context with three logical devices (the same ordinal three times) exercises the interleaved-strip split and the
+    peer gather into device 0's frame that an 8-GPU context uses: one strip per device with a ragged last one (90 rows),
+    and several strips per device with an empty strip slot on the last device (230 rows = 8 strips over 3 devices)."""
     sc = scenes.config5_instances(5, 16)
-    p = v.default_params(160, 90, scenes.min_cell(sc), 255, shadow=True)
     r2 = v.VHipRenderer(devices=(0, 0, 0))
     assert r2.Start()
     try:
-        img, t = gpu_render(r2, sc, p)
-        ref, st = OracleScene(sc).render(p, threads=8)
-        assert np.abs(img - ref).max() <= TOL
-        assert t["primary_rays"] == 160 * 90 and t["hits"] == st["hits"]
+        for w, h in ((96, 230), (160, 90)):
+            p = v.default_params(w, h, scenes.min_cell(sc), 255, shadow=True)
+            img, t = gpu_render(r2, sc, p)
+            ref, st = OracleScene(sc).render(p, threads=8)
+            assert np.abs(img - ref).max() <= TOL
+            assert t["primary_rays"] == w * h and t["hits"] == st["hits"]
         q = _abi.vrt_params.from_buffer_copy(p)
         q.flags |= _abi.FLAG_OUTPUT_RGBA8  # the 4-byte tiles take the same split + peer gather
         img8, _ = gpu_render(r2, sc, q)

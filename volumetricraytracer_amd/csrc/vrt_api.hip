@@ -938,14 +938,16 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
     const size_t row_bytes = (size_t)W * ((params->flags & VRT_FLAG_OUTPUT_RGBA8) ? 4 : 4 * sizeof(float));
     auto t0 = std::chrono::steady_clock::now();
 
-    /* contiguous row tiles, GPU g renders rows [g*H/n, (g+1)*H/n)   */
-    std::vector<int> r0((size_t)n + 1);
-    for (int g = 0; g <= n; g++) r0[(size_t)g] = (int)(((long long)g * H) / n);
+    /* One device: the whole frame.  Several: 32-row strips dealt round-robin (device g renders strips g, g+n, ... into
+       a compact tile) — contiguous tiles would put every object row on the middle devices */
+    constexpr int kStripRows = 32;
+    const int total_strips = (H + kStripRows - 1) / kStripRows;
+    const int strips_per = n > 1 ? (total_strips + n - 1) / n : 0;
+    const int tile_rows = n > 1 ? strips_per * kStripRows : H;
 
     for (int g = 0; g < n; g++) {
         DeviceState& D = ctx->dev[(size_t)g];
-        const int rows = r0[(size_t)g + 1] - r0[(size_t)g];
-        const size_t need = std::max<size_t>((size_t)rows * row_bytes, 16);
+        const size_t need = std::max<size_t>((size_t)tile_rows * row_bytes, 16);
         HIP_TRY(hipSetDevice(D.ordinal));
         if (D.fb_bytes < need) {
             if (D.fb) HIP_TRY(hipFree(D.fb));
@@ -972,8 +974,14 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
         DeviceState& D = ctx->dev[(size_t)g];
         HIP_TRY(hipSetDevice(D.ordinal));
         RowSet rs;
-        rs.row0 = r0[(size_t)g];
-        rs.rows = r0[(size_t)g + 1] - r0[(size_t)g];
+        if (n > 1) {
+            rs.rows = tile_rows;
+            rs.strip_rows = kStripRows;
+            rs.strip_first = g;
+            rs.strip_stride = n;
+        } else {
+            rs.rows = H;
+        }
         rc = enqueue_rows(ctx, D, params, rs, D.fb, D.stream, ring);
         if (rc != VRT_OK) return rc;
     }
@@ -984,8 +992,8 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
 
     float gather_ms = 0.f;
     if (n > 1) {
-        /* wait for the kernels, then gather every tile into device 0's full frame over the
-           peer links (one point-to-point copy per source GPU, all concurrent) */
+        /* wait for the kernels, then gather every strip into device 0's frame over the peer links (the copies of
+           one source device go in its own stream, all devices concurrently) */
         for (int g = 0; g < n; g++) {
             HIP_TRY(hipSetDevice(ctx->dev[(size_t)g].ordinal));
             HIP_TRY(hipStreamSynchronize(ctx->dev[(size_t)g].stream));
@@ -993,11 +1001,15 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
         auto g0 = std::chrono::steady_clock::now();
         for (int g = 0; g < n; g++) {
             DeviceState& D = ctx->dev[(size_t)g];
-            const size_t bytes = (size_t)(r0[(size_t)g + 1] - r0[(size_t)g]) * row_bytes;
-            if (bytes == 0) continue;
             HIP_TRY(hipSetDevice(D.ordinal));
-            char* dst = reinterpret_cast<char*>(ctx->gather) + (size_t)r0[(size_t)g] * row_bytes;
-            HIP_TRY(hipMemcpyPeerAsync(dst, ctx->dev[0].ordinal, D.fb, D.ordinal, bytes, D.stream));
+            for (int k = 0; k < strips_per; k++) {
+                const int frame_row = (k * n + g) * kStripRows;
+                const int rows = std::min(kStripRows, H - frame_row);
+                if (rows <= 0) break;
+                char* dst = reinterpret_cast<char*>(ctx->gather) + (size_t)frame_row * row_bytes;
+                const char* src = reinterpret_cast<const char*>(D.fb) + (size_t)k * kStripRows * row_bytes;
+                HIP_TRY(hipMemcpyPeerAsync(dst, ctx->dev[0].ordinal, src, D.ordinal, (size_t)rows * row_bytes, D.stream));
+            }
         }
         for (int g = 0; g < n; g++) {
             HIP_TRY(hipSetDevice(ctx->dev[(size_t)g].ordinal));
