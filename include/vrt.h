@@ -46,6 +46,7 @@ extern "C" {
 #define VRT_MAX_DEVICES      8
 #define VRT_MAX_RESOLUTION   9    /* N = 513: the kernels address a volume with 32-bit byte offsets (brick pool 1.07 GB);
                                      the reference's own tools stop at 8 (VolumeConverter.cpp:44-49) */
+#define VRT_FRAMES_IN_FLIGHT 3    /* frame slots of vrt_render_begin / vrt_render_end: FrameCount, DXConstants.cpp:23 */
 #define VRT_MAX_TEXTURES     64   /* 2D material textures resident at once (3 per volume slot + spare) */
 #define VRT_FLAG_DIAG_TIMELINE 4 /* run the diagnostic kernel build that stamps per-wave timeline records */
 #define VRT_FLAG_OUTPUT_RGBA8 8  /* store R8G8B8A8_UNORM pixels (4 B, R in the low byte, A = 255) instead of float4:
@@ -255,6 +256,17 @@ int vrt_render_rows(vrt_ctx* ctx, const vrt_params* params, int row0, int rows,
  * DXRenderer.cpp:827-867 — the reference is single-adapter, NodeMask 0.) */
 int vrt_render_strips(vrt_ctx* ctx, const vrt_params* params, int strip_rows, int first_strip,
                       int strip_stride, int n_strips, void* device_rgba, void* hip_stream);
+
+/* Pipelined rendering — the reference keeps FrameCount = 3 frames in flight and paces them with fences
+ * (DXConstants.cpp:23, DXRenderer.cpp:974-989); a frame's last third is a few latency-bound waves, which the next frame's
+ * march hides.  vrt_render_begin snapshots the scene as it is NOW (instances, BVH, lights, material / metric / texture
+ * tables), enqueues the march of the whole frame and its copy into an internal pinned host frame on the slot's own
+ * stream, and returns at once; the application may go on to vrt_scene_set the next frame.  vrt_render_end waits for that
+ * slot and hands out the pinned frame (width*height float4, or uint32 with VRT_FLAG_OUTPUT_RGBA8), valid until the slot
+ * is begun again.  slot in [0, VRT_FRAMES_IN_FLIGHT); single-device contexts only; volume / texture / sky uploads still
+ * drain every frame in flight first. */
+int vrt_render_begin(vrt_ctx* ctx, const vrt_params* params, int slot);
+int vrt_render_end(vrt_ctx* ctx, int slot, const void** host_pixels);
 
 int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out);
 /* Kernel durations (ms) of the last n vrt_render_rows/vrt_render launches, oldest first;

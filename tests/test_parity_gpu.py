@@ -471,6 +471,69 @@ def test_bench_two_rank_rehearsal(oracle_lib):
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
 
 
+def test_frames_in_flight_keep_their_own_scene(oracle_lib):
+    """vrt_render_begin / vrt_render_end (the reference's three frames in flight, DXConstants.cpp:23): frame i is begun,
+    then the objects, the camera, a light and a material are already changed for frame i+1 (vrt_scene_set,
+    vrt_volume_set_material) before frame i is collected.  Every collected frame must be the frame of ITS scene."""
+    import copy
+
+    def scene_at(k):
+        sc = scenes.config5_instances(5, 16)
+        ang = 0.35 * k
+        for j, o in enumerate(sc.Objects):
+            o.Position = (o.Position[0] + 25.0 * math.sin(ang + j), o.Position[1] - 18.0 * k, o.Position[2] + 9.0 * k)
+            o.Rotation = tuple(v.quat_from_axis_angle(v.UP, ang * (j + 1)))
+        sc.Camera = v.look_minus_x_camera(900.0 - 40.0 * k, 20.0 * k)
+        sc.PointLights = [v.VPointLight(Position=(300.0 - 60.0 * k, 50.0, 200.0), IlluminationStrength=1500.0 + 300.0 * k,
+                                        AttenuationLinear=0.01, AttenuationExp=0.0005)]
+        sc.volumes()[0].Material = v.VMaterial((0.2 + 0.1 * k, 0.8 - 0.1 * k, 0.5, 1.0), 0.8, 0.1 * k)
+        return sc
+
+    import math
+
+    base = scenes.config5_instances(5, 16)
+    vol = base.volumes()[0]
+    frames = []
+    for k in range(7):
+        sc = scene_at(k)
+        for o in sc.Objects:  # same volume object throughout: it is uploaded once, only the scene around it moves
+            o.Volume = vol
+        vol.Material = sc_mat = v.VMaterial((0.2 + 0.1 * k, 0.8 - 0.1 * k, 0.5, 1.0), 0.8, 0.1 * k)
+        frames.append((sc, copy.copy(sc_mat)))
+    r = v.VHipRenderer()
+    assert r.Start()
+    try:
+        K = _abi.VRT_FRAMES_IN_FLIGHT
+        r.ResizeRenderOutput(160, 90)
+        r.Shadows, r.MaxSteps = True, 255
+        pending, got = {}, []
+        for k, (sc, mat) in enumerate(frames):
+            slot = k % K
+            if slot in pending:
+                got.append(r.render_end(slot, pending.pop(slot)))
+            # the application edits the scene for frame k while frames k-1 and k-2 are still in flight
+            vol.Material = mat
+            r.SetSceneToRender(sc)
+            r.SyncWithScene()  # uploads the volume once (frame 0); afterwards only vrt_scene_set
+            mm = mat.to_abi()
+            _abi.check(r._lib.vrt_volume_set_material(r._ctx, 0, C.byref(mm)), "vrt_volume_set_material")
+            pending[slot] = r.render_begin(slot)
+        for k in range(len(frames) - len(pending), len(frames)):
+            got.append(r.render_end(k % K, pending.pop(k % K)))
+        with pytest.raises(_abi.VrtError):
+            r.render_end(0, r.make_params())  # nothing in flight on that slot any more
+    finally:
+        r.Stop()
+    assert len(got) == len(frames)
+    for k, (sc, mat) in enumerate(frames):
+        vol.Material = mat
+        p = v.default_params(160, 90, scenes.min_cell(sc), 255, shadow=True)
+        p.max_bounces = 2
+        ref, _ = OracleScene(sc).render(p, threads=8)
+        assert np.abs(got[k] - ref).max() <= TOL, f"frame {k}"
+    assert np.abs(got[0] - got[3]).max() > 0.05  # the frames really differ
+
+
 def test_render_rows_can_be_captured_into_a_graph(renderer, oracle_lib):
     """vrt_render_rows makes no host synchronisation and (after the first launch of a size) no allocation, so a frame
     can be captured into a HIP graph and replayed (include/vrt.h): same pixels as the direct launch; a captured launch

@@ -11,6 +11,7 @@ import os
 
 VRT_MAX_VOLUMES = 20
 VRT_MAX_TEXTURES = 64
+VRT_FRAMES_IN_FLIGHT = 3
 VRT_MAX_RESOLUTION = 9
 VRT_MAX_POINT_LIGHTS = 5
 VRT_MAX_SPOT_LIGHTS = 5
@@ -158,6 +159,8 @@ SYMBOLS = {
     "vrt_render": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_void_p]),
     "vrt_render_rows": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vrt_render_strips": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vrt_render_begin": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int]),
+    "vrt_render_end": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "vrt_last_timing": (C.c_int, [C.c_void_p, C.POINTER(vrt_timing)]),
     "vrt_timing_history": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "vrt_debug_wave_records": (C.c_longlong, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]),

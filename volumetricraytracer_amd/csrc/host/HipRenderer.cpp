@@ -168,6 +168,9 @@ void VHipRenderer::Stop() {
     Ctx = nullptr;
     Uploaded.clear();
     UploadedEnv = nullptr;
+    for (bool& b : SlotBusy) b = false;
+    FramePixels = nullptr;
+    FramePixelCount = 0;
     TextureIds.clear();
     for (auto& kv : Textures) kv.second.Id = -1;
 }
@@ -360,7 +363,42 @@ void VHipRenderer::Render() {
     const VObjectPtr<Scene::VCamera> cam = scene->GetActiveCamera();
     p.cone_eps = std::tan(cam->FOVAngle * (3.14159265358979323846f / 180.0f) * 0.5f) / (float)Height;
     Frame.resize((size_t)Width * Height * 4);
-    ok(vrt_render(Ctx, &p, Frame.data()), "vrt_render");
+    if (FramesInFlight <= 1 || Devices.size() != 1) {
+        if (ok(vrt_render(Ctx, &p, Frame.data()), "vrt_render")) {
+            FramePixels = Frame.data();
+            FramePixelCount = Frame.size();
+        }
+        return;
+    }
+    /* pipelined: like the reference's swap chain, Render() returns once the frame is enqueued; GetFrame() holds the
+       newest frame that has been collected (the one begun FramesInFlight calls ago) until Flush() */
+    const int k = FramesInFlight > VRT_FRAMES_IN_FLIGHT ? VRT_FRAMES_IN_FLIGHT : FramesInFlight;
+    const int slot = (int)(FrameIndex % (unsigned long long)k);
+    if (SlotBusy[slot]) Collect(slot);
+    if (ok(vrt_render_begin(Ctx, &p, slot), "vrt_render_begin")) {
+        SlotBusy[slot] = true;
+        SlotPixels[slot] = (size_t)Width * Height * 4;
+        FrameIndex++;
+    }
+}
+
+void VHipRenderer::Collect(int slot) {
+    const void* px = nullptr;
+    if (ok(vrt_render_end(Ctx, slot, &px), "vrt_render_end") && px) {
+        /* no copy: the pinned frame of the slot stays valid until the slot is begun again, FramesInFlight - 1 frames on */
+        FramePixels = static_cast<const float*>(px);
+        FramePixelCount = SlotPixels[slot];
+    }
+    SlotBusy[slot] = false;
+}
+
+void VHipRenderer::Flush() {
+    if (!Ctx) return;
+    const int k = FramesInFlight > VRT_FRAMES_IN_FLIGHT ? VRT_FRAMES_IN_FLIGHT : FramesInFlight;
+    for (int i = 0; i < k; i++) { /* oldest first, so that GetFrame() ends up with the newest frame */
+        const int slot = (int)((FrameIndex + (unsigned long long)i) % (unsigned long long)(k > 0 ? k : 1));
+        if (slot < VRT_FRAMES_IN_FLIGHT && SlotBusy[slot]) Collect(slot);
+    }
 }
 
 bool VHipRenderer::GetLastTiming(vrt_timing& out) const { return Ctx && vrt_last_timing(Ctx, &out) == VRT_OK; }

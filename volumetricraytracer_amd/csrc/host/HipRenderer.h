@@ -41,7 +41,11 @@ public:
 
     /* backend-specific */
     void SetDevices(const std::vector<int>& hipOrdinals) { Devices = hipOrdinals; } /* before Start(); default {0} */
-    const std::vector<float>& GetFrame() const { return Frame; }                     /* Width*Height RGBA */
+    /* The newest finished frame: Width*Height float RGBA (null before the first one).  With frames in flight it points
+       into the slot's pinned buffer and stays valid for FramesInFlight - 1 further Render() calls. */
+    const float* GetFramePixels() const { return FramePixels; }
+    size_t GetFramePixelCount() const { return FramePixelCount; }
+    const std::vector<float>& GetFrame() const { return Frame; }                     /* FramesInFlight == 1 only */
     unsigned GetWidth() const { return Width; }
     unsigned GetHeight() const { return Height; }
     bool GetLastTiming(vrt_timing& out) const;
@@ -50,6 +54,11 @@ public:
     bool Shadows = true;      /* the reference always casts the directional shadow ray */
     int MaxBounces = 2;       /* MAX_RAY_RECURSION_DEPTH 3 = primary + 2 mirror bounces (RaytracingHlsl.h:32) */
     int DataPath = VRT_PATH_AUTO;
+    /* 1: Render() returns with the finished frame (vrt_render).  2..3: frames in flight like the reference's swap chain
+       (FrameCount 3, DXConstants.cpp:23): Render() enqueues (vrt_render_begin) and GetFrame() lags by FramesInFlight - 1
+       frames until Flush() collects what is still in flight.  Single-device only. */
+    int FramesInFlight = 1;
+    void Flush();
 
 private:
     bool SyncWithScene(Scene::VScene& scene);
@@ -57,6 +66,8 @@ private:
     std::vector<int> Devices{0};
     unsigned Width = 1024, Height = 576; /* Win32Window.cpp:218-219 */
     std::vector<float> Frame;
+    const float* FramePixels = nullptr;
+    size_t FramePixelCount = 0;
     std::vector<const Voxel::VVoxelVolume*> Uploaded; /* per slot */
     const VTextureCube* UploadedEnv = nullptr;
     struct TextureEntry {
@@ -67,6 +78,10 @@ private:
     std::map<const VTexture2D*, int> TextureIds;
     int ResolveTexture(const std::string& path);
     float MinCell = 1.f;
+    void Collect(int slot);
+    unsigned long long FrameIndex = 0;
+    bool SlotBusy[VRT_FRAMES_IN_FLIGHT] = {};
+    size_t SlotPixels[VRT_FRAMES_IN_FLIGHT] = {};
 };
 
 }  // namespace Hip

@@ -7,7 +7,7 @@
  * exactly like VEngine::EngineLoop does (Engine/Private/Engine.cpp:201-232):
  * tick → Renderer->Render() → post-render.  Writes the last frame as a PPM.
  *
- *   vrt_demo [--frames N] [--size WxH] [--scene file.vox] [--out frame.ppm] [--mode 0..7 (EVRenderMode)]
+ *   vrt_demo [--frames N] [--size WxH] [--scene file.vox] [--out frame.ppm] [--mode 0..7 (EVRenderMode)] [--in-flight 1..3]
  */
 #include <chrono>
 #include <cmath>
@@ -59,13 +59,14 @@ int main(int argc, char** argv) {
     int frames = 60;
     unsigned W = 1024, H = 576;
     std::string scenePath, outPath = "vrt_demo.ppm";
-    int mode = 0;
+    int mode = 0, inFlight = 1;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--size") && i + 1 < argc) sscanf(argv[++i], "%ux%u", &W, &H);
         else if (!strcmp(argv[i], "--scene") && i + 1 < argc) scenePath = argv[++i];
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) outPath = argv[++i];
         else if (!strcmp(argv[i], "--mode") && i + 1 < argc) mode = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--in-flight") && i + 1 < argc) inFlight = atoi(argv[++i]);
     }
 
     std::shared_ptr<Renderer::VRenderer> renderer = Renderer::VRendererFactory::NewRenderer();
@@ -106,6 +107,7 @@ int main(int argc, char** argv) {
     renderer->SetSceneToRender(scene);
 
     auto* hip = dynamic_cast<Renderer::Hip::VHipRenderer*>(renderer.get());
+    if (hip && inFlight >= 1 && inFlight <= 3) hip->FramesInFlight = inFlight;
     double kernel_ms = 0.0;
     const auto t0 = std::chrono::steady_clock::now();
     for (int f = 0; f < frames; f++) {
@@ -118,15 +120,16 @@ int main(int argc, char** argv) {
         vrt_timing tm;
         if (hip && hip->GetLastTiming(tm)) kernel_ms += tm.kernel_ms;
     }
+    if (hip) hip->Flush(); /* collect the frames still in flight: GetFrame() is the last frame again */
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("%d frames %ux%u: %.2f ms/frame wall (%.1f FPS), march kernel %.3f ms/frame\n", frames, W, H, wall / frames * 1e3, frames / wall,
            kernel_ms / frames);
 
-    if (hip && !hip->GetFrame().empty()) {
+    if (hip && hip->GetFramePixels()) {
         FILE* fp = fopen(outPath.c_str(), "wb");
         if (fp) {
             fprintf(fp, "P6 %u %u 255\n", W, H);
-            const auto& fr = hip->GetFrame();
+            const float* fr = hip->GetFramePixels();
             for (size_t i = 0; i < (size_t)W * H; i++) {
                 unsigned char rgb[3];
                 for (int c = 0; c < 3; c++) rgb[c] = (unsigned char)(std::fmin(std::fmax(fr[i * 4 + c], 0.f), 1.f) * 255.f + 0.5f);

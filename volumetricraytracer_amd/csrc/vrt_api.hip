@@ -58,6 +58,30 @@ struct DeviceVolume {
     uint8_t* cube_skip = nullptr; /* 2 x nb^3 bytes: the Cube modes' distance-to-solid table and its build scratch */
 };
 
+/* The small read-only arrays a launch dereferences, in ONE device allocation so that a frame in flight can keep its
+   own snapshot while the application already edits the scene for the next frame. */
+struct SceneArrays {
+    DVolume vols[VRT_MAX_VOLUMES];
+    DInstance inst[VRT_MAX_INSTANCES];
+    DBvhNode nodes[kMaxBvhNodes];
+    DPointLight point[VRT_MAX_POINT_LIGHTS];
+    DSpotLight spot[VRT_MAX_SPOT_LIGHTS];
+};
+
+/* One frame in flight (vrt_render_begin / vrt_render_end): stream, completion event, scene snapshot, device frame and
+   a pinned host frame. */
+struct FrameSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    SceneArrays* d_scene = nullptr;
+    SceneArrays* h_scene = nullptr; /* pinned */
+    void* d_fb = nullptr;
+    void* h_fb = nullptr; /* pinned */
+    size_t fb_bytes = 0;
+    bool busy = false;
+    int ring = 0;       /* event-ring slot of the launch (timing) */
+};
+
 struct DeviceState {
     int ordinal = 0;
     hipStream_t stream = nullptr;
@@ -82,6 +106,7 @@ struct DeviceState {
     bool last_diag = false;
     hipEvent_t ev0[kRing];
     hipEvent_t ev1[kRing];
+    FrameSlot slot[VRT_FRAMES_IN_FLIGHT];
     bool events_ok = false;
     bool timed[kRing] = {}; /* launch in this ring slot recorded its event pair (false: captured into a graph) */
 };
@@ -374,6 +399,14 @@ void destroy_device(DeviceState& D) {
     if (D.d_env) (void)hipFree(D.d_env);
     for (int i = 0; i < VRT_MAX_TEXTURES; i++)
         if (D.tex[i]) (void)hipFree(D.tex[i]);
+    for (auto& S : D.slot) {
+        if (S.stream) (void)hipStreamDestroy(S.stream);
+        if (S.done) (void)hipEventDestroy(S.done);
+        if (S.d_scene) (void)hipFree(S.d_scene);
+        if (S.h_scene) (void)hipHostFree(S.h_scene);
+        if (S.d_fb) (void)hipFree(S.d_fb);
+        if (S.h_fb) (void)hipHostFree(S.h_fb);
+    }
     if (D.fb) (void)hipFree(D.fb);
     for (int i = 0; i < kStatSlots; i++)
         if (D.d_stats[i]) (void)hipFree(D.d_stats[i]);
@@ -547,7 +580,7 @@ struct RowSet {
 };
 
 void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, const RowSet& rs, float* out,
-                 unsigned* stats, DFrame& F) {
+                 unsigned* stats, DFrame& F, const SceneArrays* snapshot = nullptr) {
     const int row0 = rs.row0, rows = rs.rows;
     memset(&F, 0, sizeof F);
     pack_camera(ctx->scene, p->width, p->height, F);
@@ -601,11 +634,11 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.n_nodes = ctx->n_nodes;
     F.n_point = std::min(ctx->scene.n_point_lights, VRT_MAX_POINT_LIGHTS);
     F.n_spot = std::min(ctx->scene.n_spot_lights, VRT_MAX_SPOT_LIGHTS);
-    F.vols = D.d_vols;
-    F.inst = D.d_inst;
-    F.nodes = D.d_nodes;
-    F.point = D.d_point;
-    F.spot = D.d_spot;
+    F.vols = snapshot ? snapshot->vols : D.d_vols;
+    F.inst = snapshot ? snapshot->inst : D.d_inst;
+    F.nodes = snapshot ? snapshot->nodes : D.d_nodes;
+    F.point = snapshot ? snapshot->point : D.d_point;
+    F.spot = snapshot ? snapshot->spot : D.d_spot;
     F.env = ctx->env_size > 0 ? D.d_env : nullptr;
     F.env_size = ctx->env_size;
     F.out = out;
@@ -614,9 +647,9 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
 
 /* Enqueue one tile on one device.  No allocation, no host sync. */
 int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet& rs, float* out, hipStream_t stream,
-                 int ring) {
+                 int ring, const SceneArrays* snapshot = nullptr) {
     DFrame F;
-    build_frame(ctx, D, p, rs, out, nullptr, F);
+    build_frame(ctx, D, p, rs, out, nullptr, F, snapshot);
     if ((long long)F.tiles_x * F.tiles_y > kMaxBlocks / 2) return VRT_ERR_INVALID;
     D.last_blocks = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     const int slot = (int)(ctx->launches % kStatSlots);
@@ -759,6 +792,7 @@ int vrt_volume_download(vrt_ctx* ctx, int slot, vrt_voxel* out) {
 int vrt_volume_set_material(vrt_ctx* ctx, int slot, const vrt_material* material) {
     if (!ctx || !material) return VRT_ERR_INVALID;
     if (!valid_slot(slot) || !ctx->vol[slot].used) return VRT_ERR_SLOT;
+    if (memcmp(&ctx->vol[slot].mat, material, sizeof *material) == 0) return VRT_OK; /* adaptors re-send it every frame */
     ctx->vol[slot].mat = *material;
     return sync_volume_table(ctx);
 }
@@ -818,6 +852,11 @@ int vrt_volume_set_textures(vrt_ctx* ctx, int slot, int albedo_id, int normal_id
     for (int i = 0; i < 3; i++) {
         if (ids[i] < -1 || ids[i] >= VRT_MAX_TEXTURES) return VRT_ERR_INVALID;
         if (ids[i] >= 0 && !ctx->tex[ids[i]].used) return VRT_ERR_SLOT;
+    }
+    {
+        const HostVolume& cur = ctx->vol[slot];
+        if (cur.tex[0] == ids[0] && cur.tex[1] == ids[1] && cur.tex[2] == ids[2] && cur.tex_scale[0] == scale_u && cur.tex_scale[1] == scale_v)
+            return VRT_OK; /* unchanged: nothing to drain, nothing to send */
     }
     for (auto& D : ctx->dev) {
         HIP_TRY(hipSetDevice(D.ordinal));
@@ -1029,6 +1068,68 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
     }
     ctx->last_gather_ms = gather_ms;
     ctx->last_total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return VRT_OK;
+}
+
+int vrt_render_begin(vrt_ctx* ctx, const vrt_params* params, int slot) {
+    int rc = check_params(ctx, params);
+    if (rc != VRT_OK) return rc;
+    if (slot < 0 || slot >= VRT_FRAMES_IN_FLIGHT || ctx->dev.size() != 1) return VRT_ERR_INVALID;
+    DeviceState& D = ctx->dev[0];
+    FrameSlot& S = D.slot[slot];
+    if (S.busy) return VRT_ERR_NOT_READY; /* vrt_render_end(slot) first */
+    HIP_TRY(hipSetDevice(D.ordinal));
+    const size_t need = (size_t)params->width * params->height * ((params->flags & VRT_FLAG_OUTPUT_RGBA8) ? 4 : 16);
+    if (!S.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+        HIP_TRY(hipMalloc(&S.d_scene, sizeof(SceneArrays)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S.h_scene), sizeof(SceneArrays), hipHostMallocDefault));
+    }
+    if (S.fb_bytes < need) {
+        if (S.d_fb) HIP_TRY(hipFree(S.d_fb));
+        if (S.h_fb) HIP_TRY(hipHostFree(S.h_fb));
+        S.d_fb = S.h_fb = nullptr;
+        S.fb_bytes = 0;
+        HIP_TRY(hipMalloc(&S.d_fb, need));
+        HIP_TRY(hipHostMalloc(&S.h_fb, need, hipHostMallocDefault));
+        S.fb_bytes = need;
+    }
+    /* snapshot of everything the kernel dereferences besides the volumes themselves: later vrt_scene_set /
+       vrt_volume_set_* calls do not reach a frame that is already in flight */
+    for (int i = 0; i < VRT_MAX_VOLUMES; i++) fill_dvolume(ctx, D, ctx->vol[i], D.vol[i], S.h_scene->vols[i]);
+    memcpy(S.h_scene->inst, ctx->inst, sizeof S.h_scene->inst);
+    memcpy(S.h_scene->nodes, ctx->nodes, sizeof S.h_scene->nodes);
+    memcpy(S.h_scene->point, ctx->point, sizeof S.h_scene->point);
+    memcpy(S.h_scene->spot, ctx->spot, sizeof S.h_scene->spot);
+    HIP_TRY(hipMemcpyAsync(S.d_scene, S.h_scene, sizeof(SceneArrays), hipMemcpyHostToDevice, S.stream));
+    const int ring = (int)(ctx->launches % kRing);
+    RowSet rs;
+    rs.rows = params->height;
+    rc = enqueue_rows(ctx, D, params, rs, static_cast<float*>(S.d_fb), S.stream, ring, S.d_scene);
+    if (rc != VRT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(S.h_fb, S.d_fb, need, hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipEventRecord(S.done, S.stream));
+    S.busy = true;
+    S.ring = ring;
+    ctx->launches++;
+    ctx->last_devices = 1;
+    ctx->last_w = (uint32_t)params->width;
+    ctx->last_h = (uint32_t)params->height;
+    ctx->last_gather_ms = 0.f;
+    ctx->last_total_ms = 0.f;
+    return VRT_OK;
+}
+
+int vrt_render_end(vrt_ctx* ctx, int slot, const void** host_pixels) {
+    if (!ctx || slot < 0 || slot >= VRT_FRAMES_IN_FLIGHT || ctx->dev.size() != 1) return VRT_ERR_INVALID;
+    DeviceState& D = ctx->dev[0];
+    FrameSlot& S = D.slot[slot];
+    if (!S.busy) return VRT_ERR_NOT_READY;
+    HIP_TRY(hipSetDevice(D.ordinal));
+    HIP_TRY(hipEventSynchronize(S.done));
+    S.busy = false;
+    if (host_pixels) *host_pixels = S.h_fb;
     return VRT_OK;
 }
 

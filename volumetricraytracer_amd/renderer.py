@@ -195,6 +195,26 @@ class VHipRenderer:
         _abi.check(self._lib.vrt_render_strips(self._ctx, C.byref(params), strip_rows, first_strip, strip_stride, n_strips,
                                                C.c_void_p(device_ptr), C.c_void_p(stream)), "vrt_render_strips")
 
+    def render_begin(self, slot: int, params: Optional[_abi.vrt_params] = None) -> _abi.vrt_params:
+        """vrt_render_begin: sync the scene, snapshot it and enqueue the whole frame on frame slot `slot`
+        (0..VRT_FRAMES_IN_FLIGHT-1); returns at once.  Collect with render_end(slot, params)."""
+        self._require()
+        self.SyncWithScene()
+        p = params if params is not None else self.make_params()
+        _abi.check(self._lib.vrt_render_begin(self._ctx, C.byref(p), slot), "vrt_render_begin")
+        return p
+
+    def render_end(self, slot: int, params: _abi.vrt_params) -> np.ndarray:
+        """vrt_render_end: wait for the frame begun on `slot` and return a copy of its pixels."""
+        self._require()
+        ptr = C.c_void_p()
+        _abi.check(self._lib.vrt_render_end(self._ctx, slot, C.byref(ptr)), "vrt_render_end")
+        if params.flags & _abi.FLAG_OUTPUT_RGBA8:
+            buf = (C.c_uint8 * (params.width * params.height * 4)).from_address(ptr.value)
+            return np.frombuffer(buf, dtype=np.uint8).reshape(params.height, params.width, 4).copy()
+        buf = (C.c_float * (params.width * params.height * 4)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.float32).reshape(params.height, params.width, 4).copy()
+
     def last_timing(self) -> dict:
         self._require()
         t = _abi.vrt_timing()
