@@ -210,7 +210,20 @@ void pack_instance(const vrt_instance& in, DInstance& out) {
     out.pos[1] = in.position[1];
     out.pos[2] = in.position[2];
     out.slot = in.volume_slot;
-    out.pad_[0] = out.pad_[1] = 0.f;
+    out.pad_ = 0.f;
+}
+
+/* Constants of the directional light's shadow ray in an instance's object space — the very expressions of the
+   kernel's setup_ray / slab (mul33, dot3, 1/sqrt, inf-safe reciprocals), evaluated once here. */
+void pack_shadow_ray(const float light_dir[3], DInstance& I) {
+    const float* m = I.w2o;
+    const float lx = light_dir[0], ly = light_dir[1], lz = light_dir[2];
+    I.sh_od[0] = (m[0] * lx + m[1] * ly) + m[2] * lz;
+    I.sh_od[1] = (m[3] * lx + m[4] * ly) + m[5] * lz;
+    I.sh_od[2] = (m[6] * lx + m[7] * ly) + m[8] * lz;
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int a = 0; a < 3; a++) I.sh_inv[a] = I.sh_od[a] != 0.0f ? 1.0f / I.sh_od[a] : (I.sh_od[a] > 0.0f ? inf : -inf);
+    I.sh_inv_len = 1.0f / sqrtf((I.sh_od[0] * I.sh_od[0] + I.sh_od[1] * I.sh_od[1]) + I.sh_od[2] * I.sh_od[2]);
 }
 
 struct Box {
@@ -312,6 +325,7 @@ void fill_dvolume(const vrt_ctx* ctx, const DeviceState& D, const HostVolume& h,
     out.extent = h.extent;
     float cell = (h.extent * 2.0f) / (float)(h.N - 1); /* RDXVoxelVolume.cpp:386 */
     out.inv_cell = 1.0f / cell;
+    out.cell = cell;
     out.density_scale = h.density_scale;
     out.step_max = h.step_max > 0.0f ? h.step_max : std::numeric_limits<float>::infinity();
     out.tint[0] = h.mat.tint[0];
@@ -505,6 +519,7 @@ int pack_scene(vrt_ctx* ctx) {
     std::vector<Box> boxes((size_t)s.n_instances);
     for (int i = 0; i < s.n_instances; i++) {
         pack_instance(s.instances[i], ctx->inst[i]);
+        pack_shadow_ray(s.light_dir, ctx->inst[i]);
         boxes[(size_t)i] = instance_box(ctx->inst[i], ctx->vol[s.instances[i].volume_slot].extent);
     }
     ctx->n_nodes = 0;

@@ -67,7 +67,7 @@ struct VolRef {
     gbyte_p cube; /* Cube modes: distance-to-solid table */
     int N;
     int nb;
-    float extent, inv_cell, dscale, step_max;
+    float extent, inv_cell, cell, dscale, step_max;
 };
 
 template <int PATH>
@@ -80,6 +80,7 @@ __device__ __forceinline__ VolRef load_vol(const DVolume* __restrict__ v) {
     r.nb = v->nb;
     r.extent = v->extent;
     r.inv_cell = v->inv_cell;
+    r.cell = v->cell;
     r.dscale = v->density_scale;
     r.step_max = v->step_max;
     return r;
@@ -183,6 +184,17 @@ __device__ __forceinline__ bool slab(F3 o, F3 d, float e, float t_cur, float& t_
     return t_exit > t_enter && t_exit >= 0.0f && t_enter <= t_cur;
 }
 
+/* The same test with the reciprocals given (they only depend on the direction). */
+__device__ __forceinline__ bool slab_inv(F3 o, F3 d, F3 inv, float e, float t_cur, float& t_enter, float& t_exit) {
+    const bool px = d.x > 0.0f, py = d.y > 0.0f, pz = d.z > 0.0f;
+    const float tminx = ((px ? -e : e) - o.x) * inv.x, tmaxx = ((px ? e : -e) - o.x) * inv.x;
+    const float tminy = ((py ? -e : e) - o.y) * inv.y, tmaxy = ((py ? e : -e) - o.y) * inv.y;
+    const float tminz = ((pz ? -e : e) - o.z) * inv.z, tmaxz = ((pz ? e : -e) - o.z) * inv.z;
+    t_enter = maxf_(maxf_(tminx, tminy), tminz);
+    t_exit = minf_(minf_(tmaxx, tmaxy), tmaxz);
+    return t_exit > t_enter && t_exit >= 0.0f && t_enter <= t_cur;
+}
+
 /* General box slab for the BVH (world space). */
 __device__ __forceinline__ bool slab_box(F3 o, F3 d, const DBvhNode& n, float t_cur) {
     const float inf = __builtin_inff();
@@ -243,7 +255,30 @@ __device__ __forceinline__ bool setup_ray(const DFrame& F, const DInstance* __re
     R.t_end = minf_(t_exit, t_cur);
     /* smallest step: one pixel-footprint radius at the total path length t_base + t */
     R.base_min = __builtin_fmaf(t_base, F.cone_eps, F.step_min);
-    R.leap_unit = (4.0f * (1.0f / V.inv_cell)) * inv_len;
+    R.leap_unit = (4.0f * V.cell) * inv_len;
+    return true;
+}
+
+/* setup_ray for the directional light's shadow ray: direction-only terms come precomputed with the instance
+ * (DInstance::sh_*, same arithmetic on the host), so only the origin is transformed here.  Bit-identical to
+ * setup_ray(F, I, V, o, light_dir, ...). */
+__device__ __forceinline__ bool setup_shadow_ray(const DFrame& F, const DInstance* __restrict__ I, const VolRef& V, F3 o, float t_cur,
+                                                 float t_base, RaySeg& R) {
+    F3 rel = f3(o.x - I->pos[0], o.y - I->pos[1], o.z - I->pos[2]);
+    R.oo = mul33(I->w2o, rel);
+    R.od = f3(I->sh_od[0], I->sh_od[1], I->sh_od[2]);
+    float t_exit;
+    if (!slab_inv(R.oo, R.od, f3(I->sh_inv[0], I->sh_inv[1], I->sh_inv[2]), V.extent, t_cur, R.t_enter, t_exit)) return false;
+    const float inv_len = I->sh_inv_len;
+    R.ds = V.dscale * inv_len;
+    R.smax = V.step_max * inv_len;
+    R.uo = f3((R.oo.x + V.extent) * V.inv_cell, (R.oo.y + V.extent) * V.inv_cell, (R.oo.z + V.extent) * V.inv_cell);
+    R.ud = R.od * V.inv_cell;
+    R.cmax = (float)(V.N - 2);
+    R.t0 = (R.t_enter > 0.0f ? R.t_enter : 0.0f) + F.eps_in;
+    R.t_end = minf_(t_exit, t_cur);
+    R.base_min = __builtin_fmaf(t_base, F.cone_eps, F.step_min);
+    R.leap_unit = (4.0f * V.cell) * inv_len;
     return true;
 }
 
@@ -460,7 +495,7 @@ __device__ __forceinline__ bool march_cube(const DFrame& F, const DInstance* __r
  * true on hit and the ray parameter (shared by world and object space — the object-space direction
  * is not re-normalised, DXR semantics).  NORMAL: also produce the world-space normal.
  */
-template <int PATH, int NORMAL /* 0 none, 1 fast length, 2 exact length */, bool DIAG = false>
+template <int PATH, int NORMAL /* 0 none, 1 fast length, 2 exact length */, bool DIAG = false, bool DIR_SHADOW = false>
 __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance* __restrict__ I,
                                                const DVolume* __restrict__ Vd, F3 o, F3 d, float t_cur, float t_base,
                                                float& t_hit, F3& n_world, unsigned& steps, DiagAcc* dg = nullptr) {
@@ -469,7 +504,11 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     } else {
     const VolRef V = load_vol<PATH>(Vd);
     RaySeg R;
-    if (!setup_ray(F, I, V, o, d, t_cur, t_base, R)) return false;
+    if constexpr (DIR_SHADOW) { /* d is the scene's directional light: its per-instance constants come precomputed */
+        if (!setup_shadow_ray(F, I, V, o, t_cur, t_base, R)) return false;
+    } else {
+        if (!setup_ray(F, I, V, o, d, t_cur, t_base, R)) return false;
+    }
     float t = R.t0;
     const int max_steps = F.max_steps;
     bool hit = false;
@@ -577,13 +616,13 @@ __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float
     }
 }
 
-template <int PATH, bool SINGLE, bool DIAG = false>
+template <int PATH, bool SINGLE, bool DIAG = false, bool DIR_SHADOW = false>
 __device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_max, float t_base, unsigned& steps,
                                           DiagAcc* dg = nullptr) {
     float t;
     F3 n;
     if constexpr (SINGLE) {
-        return march_instance<PATH, 0, DIAG>(F, F.inst, F.vols + F.inst->slot, o, d, t_max, t_base, t, n, steps, dg);
+        return march_instance<PATH, 0, DIAG, DIR_SHADOW>(F, F.inst, F.vols + F.inst->slot, o, d, t_max, t_base, t, n, steps, dg);
     } else {
         int stack[16];
         int sp = 0;
@@ -593,7 +632,7 @@ __device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_m
             if (!slab_box(o, d, nd, t_max)) continue;
             if (nd.left < 0) {
                 const DInstance* I = F.inst + (-nd.left - 1);
-                if (march_instance<PATH, 0, DIAG>(F, I, F.vols + I->slot, o, d, t_max, t_base, t, n, steps, dg)) return true;
+                if (march_instance<PATH, 0, DIAG, DIR_SHADOW>(F, I, F.vols + I->slot, o, d, t_max, t_base, t, n, steps, dg)) return true;
             } else {
                 stack[sp++] = nd.right;
                 stack[sp++] = nd.left;
@@ -869,7 +908,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
             if (F.shadow && !F.unlit) {
                 k.n_shadow = 1;
                 F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
-                shadowed = trace_any<PATH, SINGLE, DIAG>(F, shadow_origin(F, o, d, t_hit), ld, 5000.0f, t_hit, k.s_shadow, &dg);
+                shadowed = trace_any<PATH, SINGLE, DIAG, true>(F, shadow_origin(F, o, d, t_hit), ld, 5000.0f, t_hit, k.s_shadow, &dg);
             }
             color = shade_hit(F, F.vols + F.inst[inst].slot, d, n, shadowed);
         } else {
@@ -1032,7 +1071,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_full(const DFrame 
                 bool sh = false;
                 if (shadows) {
                     k.n_shadow++;
-                    sh = trace_any<PATH, SINGLE>(F, so, ld, 5000.0f, tb, k.s_shadow);
+                    sh = trace_any<PATH, SINGLE, false, true>(F, so, ld, 5000.0f, tb, k.s_shadow);
                 }
                 if (!sh) sum = sum + radiance(f3(F.light_strength, F.light_strength, F.light_strength), ld, wo, n, albedo, rough, metal, kk);
             }
@@ -1324,8 +1363,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame 
         bool act_s = false;
         if (want_shadow) {
             k.n_shadow = 1;
-            F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
-            act_s = setup_ray(F, I, V, shadow_origin(F, o, d, t_hit), ld, 5000.0f, t_hit, Rs);
+            act_s = setup_shadow_ray(F, I, V, shadow_origin(F, o, d, t_hit), 5000.0f, t_hit, Rs);
         }
         float ts = 0.0f;
         Cell cs = {0, 0, 0, 0.0f, 0.0f, 0.0f};
