@@ -151,6 +151,17 @@ class VVoxelVolume:
         idx = np.arange(self.N, dtype=np.float32)
         return idx * np.float32(self.CellSize) + np.float32(-self.VolumeExtends)
 
+    def quantize_like_reference_texels(self) -> "VVoxelVolume":
+        """Rounds the densities the way the reference's GPU texture does: sign bit + 15-bit trunc(|d| * 100)
+        (VDXVoxelVolume::EncodeVoxel, Renderer/DX/Private/RDXVoxelVolume.cpp:399-421; DecodeDensity,
+        Shaders/Include/Voxel.hlsli:254-266).  This build keeps fp32 on the device; apply this before the
+        upload to march exactly the field the DXR backend sees (0.01 quantum, magnitudes wrap at 327.68)."""
+        d = np.asarray(self.density, dtype=np.float32)
+        q = ((np.abs(d) * np.float32(100.0)).astype(np.int64) & 0xFFFF & 0x7FFF).astype(np.float32) * np.float32(0.01)
+        self.density = np.where(d < 0, -q, q).astype(np.float32)
+        self.dirty = True
+        return self
+
     def fill(self, fn: Callable[[np.ndarray, np.ndarray, np.ndarray], np.ndarray]) -> "VVoxelVolume":
         """density[x,z,y] = fn(X, Y, Z); material = (density <= 0) like InitSphere
         (RendererEngineInstance.cpp:286-308)."""
