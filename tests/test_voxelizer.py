@@ -333,3 +333,45 @@ def test_general_mesh_densities_match_brute_force_distance():
     assert np.abs(vol.density[near] - (best[near] / thr - 0.5)).max() < 5e-5
     assert (vol.density[~near] >= 0.5 - 1e-5).all()
     assert np.array_equal(vol.material_id == 1, vol.density <= 0)
+
+
+def test_skybox_from_face_images(tmp_path):
+    """Six face PNGs named like the reference's Resources/Skybox folder -> one cube map in D3D face order; the miss shader
+    then reads the right face (oracle env lookup, dir.xzy)."""
+    from oracle.binding import env_lookup
+
+    S = 8
+    cols = {"XP": (250, 10, 10), "XM": (10, 250, 10), "YP": (10, 10, 250), "YM": (250, 250, 10), "ZP": (250, 10, 250), "ZM": (10, 250, 250)}
+    for name, c in cols.items():
+        img = np.zeros((S, S, 4), np.uint8)
+        img[..., :3] = c
+        img[..., 3] = 255
+        img[0, 0, :3] = (1, 2, 3)  # a marker texel: orientation is kept as stored
+        _write_png(str(tmp_path / f"{name}.png"), img, 6)
+    cube = vx.load_skybox_faces(str(tmp_path))
+    assert cube.shape == (6, S, S, 4)
+    for f, name in enumerate(("XP", "XM", "YP", "YM", "ZP", "ZM")):
+        assert tuple(cube[f, 3, 3, :3]) == cols[name] and tuple(cube[f, 0, 0, :3]) == (1, 2, 3)
+    # world +X looks at face +X; world +Z (up) is cube +Y after the .xzy swizzle of the miss shader
+    assert np.allclose(env_lookup(cube, (1.0, 0.05, 0.02)) * 255.0, cols["XP"], atol=0.51)
+    assert np.allclose(env_lookup(cube, (0.02, 0.05, 1.0)) * 255.0, cols["YP"], atol=0.51)
+    assert np.allclose(env_lookup(cube, (0.02, -1.0, 0.05)) * 255.0, cols["ZM"], atol=0.51)
+    os.remove(str(tmp_path / "ZM.png"))
+    with pytest.raises(RuntimeError):
+        vx.load_skybox_faces(str(tmp_path))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/VolumetricRaytracer/VolumetricRaytracer/Resources/Skybox"),
+                    reason="the reference checkout (with its Resources/Skybox PNGs) is only present on the build machine")
+def test_reference_skybox_pngs_decode():
+    """The reference's own six sky box faces (data files, Resources/Skybox/*.png) through this build's PNG reader: 1024^2
+    RGBA each, identical to what PIL decodes."""
+    d = "/root/reference/VolumetricRaytracer/VolumetricRaytracer/Resources/Skybox"
+    cube = vx.load_skybox_faces(d)
+    assert cube.shape == (6, 1024, 1024, 4)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    for f, name in enumerate(("XP", "XM", "YP", "YM", "ZP", "ZM")):
+        assert np.array_equal(cube[f], np.array(Image.open(os.path.join(d, name + ".png")).convert("RGBA")))

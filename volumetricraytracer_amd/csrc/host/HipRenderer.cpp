@@ -131,6 +131,20 @@ VObjectPtr<VTexture2D> VTexture2D::LoadPNG(const std::string& path) {
     return std::make_shared<VTexture2D>((size_t)w, (size_t)h, std::move(rgba));
 }
 
+VObjectPtr<VTextureCube> VTextureCube::LoadFromFaceDirectory(const std::string& dir) {
+    static const char* names[6] = {"XP", "XM", "YP", "YM", "ZP", "ZM"};
+    std::vector<uint8_t> all;
+    size_t size = 0;
+    for (int f = 0; f < 6; f++) {
+        const std::string path = dir + (dir.empty() || dir.back() == '/' ? "" : "/") + names[f] + ".png";
+        const VObjectPtr<VTexture2D> face = VTexture2D::LoadFromFile(path);
+        if (!face || face->GetWidth() != face->GetHeight() || (f > 0 && face->GetWidth() != size)) return nullptr;
+        size = face->GetWidth();
+        all.insert(all.end(), face->GetPixels().begin(), face->GetPixels().end());
+    }
+    return std::make_shared<VTextureCube>(size, std::move(all));
+}
+
 VObjectPtr<VTexture2D> VTexture2D::LoadFromFile(const std::string& path) {
     if (VObjectPtr<VTexture2D> t = LoadPNG(path)) return t;
     return LoadPPM(path);

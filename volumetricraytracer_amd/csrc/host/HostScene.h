@@ -30,6 +30,10 @@ public:
     size_t GetHeight() const { return Height; }
     size_t GetArraySize() const { return 6; }
     const std::vector<uint8_t>& GetPixels() const { return Pixels; }
+    /* Six square faces of equal size from <dir>/XP.png, XM.png, YP.png, YM.png, ZP.png, ZM.png (the layout of the
+       reference's Resources/Skybox/ folder, the source of its Skybox.dds) in D3D cube-face order +X,-X,+Y,-Y,+Z,-Z;
+       nullptr when a face is missing, undecodable, not square or of another size. */
+    static std::shared_ptr<VTextureCube> LoadFromFaceDirectory(const std::string& dir);
 
 private:
     size_t Width, Height;

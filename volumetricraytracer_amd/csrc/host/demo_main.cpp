@@ -7,7 +7,7 @@
  * exactly like VEngine::EngineLoop does (Engine/Private/Engine.cpp:201-232):
  * tick → Renderer->Render() → post-render.  Writes the last frame as a PPM.
  *
- *   vrt_demo [--frames N] [--size WxH] [--scene file.vox] [--out frame.ppm] [--mode 0..7 (EVRenderMode)] [--in-flight 1..3]
+ *   vrt_demo [--frames N] [--size WxH] [--scene file.vox] [--out frame.ppm] [--mode 0..7 (EVRenderMode)] [--in-flight 1..3] [--skybox dir-with-XP..ZM.png]
  */
 #include <chrono>
 #include <cmath>
@@ -58,7 +58,7 @@ static VObjectPtr<VTextureCube> ProceduralSky(size_t S) {
 int main(int argc, char** argv) {
     int frames = 60;
     unsigned W = 1024, H = 576;
-    std::string scenePath, outPath = "vrt_demo.ppm";
+    std::string scenePath, skyboxDir, outPath = "vrt_demo.ppm";
     int mode = 0, inFlight = 1;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
@@ -67,6 +67,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) outPath = argv[++i];
         else if (!strcmp(argv[i], "--mode") && i + 1 < argc) mode = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--in-flight") && i + 1 < argc) inFlight = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--skybox") && i + 1 < argc) skyboxDir = argv[++i];
     }
 
     std::shared_ptr<Renderer::VRenderer> renderer = Renderer::VRendererFactory::NewRenderer();
@@ -94,7 +95,9 @@ int main(int argc, char** argv) {
         light->IlluminationStrength = 6.f;
         scene->SetActiveDirectionalLight(light);
     }
-    scene->SetEnvironmentTexture(ProceduralSky(256));
+    VObjectPtr<VTextureCube> sky = skyboxDir.empty() ? nullptr : VTextureCube::LoadFromFaceDirectory(skyboxDir);
+    if (!skyboxDir.empty() && !sky) fprintf(stderr, "cannot load a sky box from %s; using the procedural one\n", skyboxDir.c_str());
+    scene->SetEnvironmentTexture(sky ? sky : ProceduralSky(256));
     scene->SetActiveSceneCamera(camera);
     VMaterial material;
     material.AlbedoColor = VColor::RED;

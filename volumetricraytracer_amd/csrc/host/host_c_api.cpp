@@ -122,4 +122,23 @@ int vrh_texture_load(const char* path, int* width, int* height, uint8_t* out, si
     return 0;
 }
 
+/* Sky box from a folder of six face images (XP/XM/YP/YM/ZP/ZM.png).  Writes the face size; copies 6*size*size*4
+   RGBA8 bytes (+X,-X,+Y,-Y,+Z,-Z) when out is non-null and cap suffices.  0 / -1. */
+int vrh_cubemap_load(const char* dir, int* face_size, uint8_t* out, size_t cap) {
+    VObjectPtr<VTextureCube> t = VTextureCube::LoadFromFaceDirectory(dir ? dir : "");
+    if (!t) {
+        g_error = std::string("cannot load six equal square faces from ") + (dir ? dir : "(null)");
+        return -1;
+    }
+    if (face_size) *face_size = (int)t->GetWidth();
+    if (out) {
+        if (cap < t->GetPixels().size()) {
+            g_error = "buffer too small";
+            return -1;
+        }
+        memcpy(out, t->GetPixels().data(), t->GetPixels().size());
+    }
+    return 0;
+}
+
 }  // extern "C"

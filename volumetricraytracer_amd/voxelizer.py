@@ -210,3 +210,18 @@ def load_texture(path: str) -> np.ndarray:
     if lib.vrh_texture_load(path.encode(), None, None, out.ctypes.data, out.nbytes) != 0:
         raise RuntimeError("vrh_texture_load: " + lib.vrh_last_error().decode())
     return out
+
+
+def load_skybox_faces(directory: str) -> np.ndarray:
+    """Sky box from <directory>/XP.png ... ZM.png (the reference's Resources/Skybox layout) through the C++ host loader;
+    returns uint8 [6, S, S, 4] in the order vrt_env_upload / VScene.EnvironmentMap expect (+X,-X,+Y,-Y,+Z,-Z)."""
+    lib = load_host()
+    lib.vrh_cubemap_load.restype = C.c_int
+    lib.vrh_cubemap_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+    size = C.c_int()
+    if lib.vrh_cubemap_load(directory.encode(), C.byref(size), None, 0) != 0:
+        raise RuntimeError("vrh_cubemap_load: " + lib.vrh_last_error().decode())
+    out = np.zeros((6, size.value, size.value, 4), np.uint8)
+    if lib.vrh_cubemap_load(directory.encode(), None, out.ctypes.data, out.nbytes) != 0:
+        raise RuntimeError("vrh_cubemap_load: " + lib.vrh_last_error().decode())
+    return out
