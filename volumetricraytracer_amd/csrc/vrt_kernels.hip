@@ -295,15 +295,17 @@ struct MarchState {
     Cell c;
 };
 __device__ __forceinline__ Cell cell_at(const RaySeg& R, float t) {
-    const float ux = __builtin_fmaf(R.ud.x, t, R.uo.x);
-    const float uy = __builtin_fmaf(R.ud.y, t, R.uo.y);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 uxy = __builtin_elementwise_fma((f2){R.ud.x, R.ud.y}, (f2){t, t}, (f2){R.uo.x, R.uo.y}); /* one v_pk_fma_f32 */
+    const float ux = uxy.x, uy = uxy.y;
     const float uz = __builtin_fmaf(R.ud.z, t, R.uo.z);
     const float cxf = __builtin_amdgcn_fmed3f(floorf(ux), 0.0f, R.cmax);
     const float cyf = __builtin_amdgcn_fmed3f(floorf(uy), 0.0f, R.cmax);
     const float czf = __builtin_amdgcn_fmed3f(floorf(uz), 0.0f, R.cmax);
     Cell c;
-    c.fx = ux - cxf;
-    c.fy = uy - cyf;
+    const f2 fxy = uxy - (f2){cxf, cyf}; /* one v_pk_add_f32 */
+    c.fx = fxy.x;
+    c.fy = fxy.y;
     c.fz = uz - czf;
     c.cx = (int)cxf;
     c.cy = (int)cyf;
