@@ -6,6 +6,7 @@
 // hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o gather gather.hip && ./gather
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 __device__ __forceinline__ float lerp1(float a, float b, float w) { return __builtin_fmaf(w, b - a, a); }
@@ -61,7 +62,32 @@ __global__ __launch_bounds__(256) void gather_cells_kernel(const float4* __restr
     out[gid] = acc;
 }
 
-int main() {
+// Calibration of the FETCH_SIZE counter for THIS access pattern: every cell of every brick is sampled exactly once (lane
+// = cell, 4 x dwordx2 at +0/+20/+100/+120 B), so the unique bytes are known: nbricks * 512.  `./gather calibrate` runs
+// only this kernel (under `rocprofv3 --pmc FETCH_SIZE`), over a pool larger than the 256-MiB Infinity Cache.
+__global__ __launch_bounds__(256) void sweep_kernel(const float* __restrict__ bricks, size_t ncells, float* __restrict__ out) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= ncells) return;
+    const size_t b = gid >> 6;
+    const unsigned l = (unsigned)gid & 63u, lx = l >> 4, lz = (l >> 2) & 3u, ly = l & 3u;
+    const float* p = bricks + (b << 7) + (lx * 25u + lz * 5u + ly);
+    out[gid & 0xfffff] = ((p[0] + p[1]) + (p[5] + p[6])) + ((p[25] + p[26]) + (p[30] + p[31]));
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "calibrate")) {
+        const size_t nbricks = (size_t)1 << 20;  // 512 MiB pool
+        float *bricks, *out;
+        hipMalloc(&bricks, nbricks * 512);
+        hipMemset(bricks, 0, nbricks * 512);
+        hipMalloc(&out, sizeof(float) << 20);
+        const size_t ncells = nbricks * 64;
+        for (int rep = 0; rep < 3; rep++)
+            hipLaunchKernelGGL(sweep_kernel, dim3((unsigned)(ncells / 256)), dim3(256), 0, 0, bricks, ncells, out);
+        hipDeviceSynchronize();
+        printf("sweep_kernel: %zu bricks, %zu unique bytes read per launch\n", nbricks, nbricks * 512);
+        return 0;
+    }
     const int blocks = 256 * 8 * 4, threads = 256, iters = 256;  // 8192 workgroups: every CU at its occupancy limit
     float* out;
     hipMalloc(&out, sizeof(float) * blocks * threads);
