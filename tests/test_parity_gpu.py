@@ -251,6 +251,29 @@ def test_voxelizer_cli_on_the_device_writes_the_same_file(tmp_path):
     assert len(a) > 2_000_000 and a == b
 
 
+@pytest.mark.parametrize("kind", ["nan", "inf", "-inf", "mix"])
+def test_non_finite_densities_do_not_break_parity(oracle_lib, kind):
+    """Volumes with NaN / +-Inf / 1e30 voxels (a corrupt file, an overflowing generator): no NaN pixel, no hang, and the
+    kernel still takes exactly the oracle's decisions — same pixels, same sample and hit counters — in the interpolated
+    and in the Cube modes."""
+    rng = np.random.default_rng(3)
+    sc = scenes.config2_sphere(5, 16)
+    vol = sc.volumes()[0]
+    vol.density = np.array(vol.density, dtype=np.float32, copy=True)
+    vals = {"nan": [np.nan], "inf": [np.inf], "-inf": [-np.inf], "mix": [np.nan, np.inf, -np.inf, 1e30, -1e30]}[kind]
+    for j, (a, b, c) in enumerate(rng.integers(0, vol.N, size=(400, 3))):
+        vol.density[a, b, c] = vals[j % len(vals)]
+    r = v.VHipRenderer()
+    assert r.Start()
+    try:
+        for mode in (_abi.MODE_INTERP_NOTEX, _abi.MODE_CUBE_NOTEX):
+            p = v.default_params(160, 90, vol.GetCellSize(), 255, shadow=True, mode=mode)
+            img, t = assert_parity(r, sc, p)
+            assert t["hits"] > 100
+    finally:
+        r.Stop()
+
+
 def test_largest_volume_parity(oracle_lib):
     """Resolution 9 (N = 513, 135 M voxels: 540 MB dense, 1.07 GB of bricks), the largest the 32-bit addressing
     takes (VRT_MAX_RESOLUTION): every path against the oracle; resolution 10 is refused."""
