@@ -73,6 +73,9 @@ def main() -> None:
                     help="frames launched before the first one must have finished, each on its own HIP stream and tile buffer "
                          "(the reference keeps 3 in flight, DXConstants.cpp:23)")
     ap.add_argument("--tile-map", default="supertile", choices=["supertile", "band", "linear"], help="blockIdx -> tile map (speed only)")
+    ap.add_argument("--skip-empty", action="store_true",
+                    help="VRT_FLAG_SKIP_EMPTY: no samples in bricks the leap table declares empty (same pixels, fewer samples "
+                         "and therefore fewer algorithmic bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
@@ -117,6 +120,8 @@ def main() -> None:
     if rgba8:
         p.flags |= _abi.FLAG_OUTPUT_RGBA8
     p.flags |= {"supertile": 0, "band": 1, "linear": 2}[args.tile_map]
+    if args.skip_empty:
+        p.flags |= _abi.FLAG_SKIP_EMPTY
 
     r = v.VHipRenderer(devices=(local_rank,))
     if not r.Start():
@@ -241,7 +246,7 @@ def main() -> None:
             "config": {"workload": label, "width": W, "height": H, "volume": f"{sc.volumes()[0].N - 1}^3 cells",
                        "max_steps": max_steps, "shadow": bool(shadow), "data_path": args.path,
                        "output": "rgba8 (R8G8B8A8_UNORM tiles; march and shading in f32)" if rgba8 else "f32 (float4)",
-                       "frames_in_flight": K,
+                       "frames_in_flight": K, "skip_empty": bool(args.skip_empty),
                        "parallelism": ("1 GPU" if world == 1 else
                                        (f"{strip_rows}-row interleaved strips" if strip_rows else "contiguous row tiles") +
                                        f" x{world} + " + ("gloo gather, REHEARSAL on one GPU" if rehearsal else "RCCL gather to rank 0")),

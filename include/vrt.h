@@ -49,6 +49,10 @@ extern "C" {
 #define VRT_FRAMES_IN_FLIGHT 3    /* frame slots of vrt_render_begin / vrt_render_end: FrameCount, DXConstants.cpp:23 */
 #define VRT_MAX_TEXTURES     64   /* 2D material textures resident at once (3 per volume slot + spare) */
 #define VRT_FLAG_DIAG_TIMELINE 4 /* run the diagnostic kernel build that stamps per-wave timeline records */
+#define VRT_FLAG_SKIP_EMPTY 32   /* do not sample where the empty-space table already decides the step: in a brick that
+                                   is two or more bricks away from any brick that can hold surface, every sample is at least the
+                                   step clamp, so the ray can only leap and cannot hit.  Same ray positions, same pixels, fewer
+                                   samples (and fewer algorithmic bytes) than without the flag */
 #define VRT_FLAG_OUTPUT_RGBA8 8  /* store R8G8B8A8_UNORM pixels (4 B, R in the low byte, A = 255) instead of float4:
                                    the reference's back-buffer precision (B8G8R8A8_UNORM, DXConstants.cpp:21);
                                    value = (uint)(min(c,1)*255 + 0.5) of the float channel the float4 path stores */
@@ -158,7 +162,7 @@ typedef struct vrt_params {
     int32_t max_bounces;  /* mirror-reflection depth, 0..2 (MAX_RAY_RECURSION_DEPTH 3 = primary + 2) */
     int32_t flags;        /* bits 0-1: blockIdx→tile map, 0 supertile (default) / 1 XCD band / 2 linear
                              (speed only, never results); bit 2: VRT_FLAG_DIAG_TIMELINE; bit 3:
-                             VRT_FLAG_OUTPUT_RGBA8.  Others 0 */
+                             VRT_FLAG_OUTPUT_RGBA8; bit 5: VRT_FLAG_SKIP_EMPTY.  Others 0 */
     float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
     float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
     float step_min;       /* lower bound of one march step (ray-parameter units) */

@@ -485,6 +485,20 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
         float czf = minf(maxf(floorf(uz), 0.0f), cmax);
         float fx = ux - cxf, fy = uy - cyf, fz = uz - czf;
         int cx = (int)cxf, cy = (int)cyf, cz = (int)czf;
+        if ((P.prm.flags & VRT_FLAG_SKIP_EMPTY) && !V.skip.empty()) {
+            /* A brick with D >= 2 holds no sample below the step clamp (nor do its neighbours), so a sample here is
+               >= smax: it cannot be a hit while the threshold is below smax (factor 2: rounding margin), and
+               max(min(s*k, smax), footprint, leap) = max(footprint, leap) once leap >= smax.  Advance without sampling. */
+            const int dd = V.skip[((size_t)(cx >> 2) * V.nb + (size_t)(cz >> 2)) * V.nb + (size_t)(cy >> 2)];
+            const float leap0 = (float)(dd > 1 ? dd - 1 : 0) * leap_unit;
+            const float thr = fmaf(t, P.prm.cone_eps, P.prm.eps_hit);
+            if (dd > 1 && leap0 >= smax && thr + thr <= smax) {
+                t_prev = t;
+                s_prev = smax;
+                t = t + fmaxf(fmaf(t, P.prm.cone_eps, base_min), leap0);
+                continue;
+            }
+        }
         float s = trilinear(V, cx, cy, cz, fx, fy, fz) * ds;
         steps++;
         if (s < fmaf(t, P.prm.cone_eps, P.prm.eps_hit)) {

@@ -251,6 +251,30 @@ def test_voxelizer_cli_on_the_device_writes_the_same_file(tmp_path):
     assert len(a) > 2_000_000 and a == b
 
 
+@pytest.mark.parametrize("path", [_abi.PATH_BRICK, _abi.PATH_DENSE, _abi.PATH_BRICK_LDS])
+def test_skip_empty_option_parity(renderer, oracle_lib, path):
+    """VRT_FLAG_SKIP_EMPTY on the shell volume (single instance), the instanced scene and the full closest hit: pixels and
+    counters equal the oracle's with the same flag, and the frame is bit-identical to the frame without the flag."""
+    for sc, w, h, single in ((scenes.config3_voxelized(6, 16), 320, 180, True), (scenes.full_closest_hit_scene(), 240, 136, False)):
+        p = v.default_params(w, h, scenes.min_cell(sc), 255, shadow=True, path=path)
+        p.max_bounces = 2
+        plain, t0 = gpu_render(renderer, sc, p)
+        p.flags |= _abi.FLAG_SKIP_EMPTY
+        img, t = assert_parity(renderer, sc, p, check_stats=single)
+        assert np.array_equal(img, plain)
+        if single:
+            assert t["primary_steps"] < 0.8 * t0["primary_steps"]
+    shell_instances = scenes.config5_instances(5, 16)
+    vol = scenes.voxelized_torus(5)
+    for o in shell_instances.Objects:
+        o.Volume = vol
+    p = v.default_params(240, 136, vol.GetCellSize(), 255, shadow=True, path=path)
+    plain, _ = gpu_render(renderer, shell_instances, p)
+    p.flags |= _abi.FLAG_SKIP_EMPTY
+    img, _ = assert_parity(renderer, shell_instances, p, check_stats=False)
+    assert np.array_equal(img, plain)
+
+
 @pytest.mark.parametrize("kind", ["nan", "inf", "-inf", "mix"])
 def test_non_finite_densities_do_not_break_parity(oracle_lib, kind):
     """Volumes with NaN / +-Inf / 1e30 voxels (a corrupt file, an overflowing generator): no NaN pixel, no hang, and the

@@ -39,6 +39,7 @@ MODE_CUBE_NOTEX_UNLIT = 7
 
 FLAG_DIAG_TIMELINE = 4
 FLAG_OUTPUT_RGBA8 = 8
+FLAG_SKIP_EMPTY = 32
 
 PATH_AUTO = 0
 PATH_DENSE = 1

@@ -574,15 +574,17 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
         return VRT_ERR_INVALID;
     if (p->mode < VRT_MODE_INTERP || p->mode > VRT_MODE_CUBE_NOTEX_UNLIT) return VRT_ERR_INVALID;
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_BRICK_LDS) return VRT_ERR_INVALID;
-    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8)) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
+    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_SKIP_EMPTY)) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
     if (!ctx->have_scene) return VRT_ERR_NOT_READY;
     return VRT_OK;
 }
 
 /* AUTO picks the fastest measured path; the LDS brick cache is wave-cooperative and currently
  * covers single-instance scenes — multi-instance scenes fall back to bricks in global memory. */
-int resolve_path(int path, bool single, int mode) {
+int resolve_path(int path, bool single, int mode, int flags = 0) {
     if (mode >= VRT_MODE_CUBE) return kPathCube; /* exact grid traversal over the bricks, whatever path was asked for */
+    if (flags & VRT_FLAG_SKIP_EMPTY) /* its own instantiations of the per-lane kernels; the LDS kernel always samples */
+        return path == VRT_PATH_DENSE ? kPathDenseSkip : kPathBrickSkip;
     if (path == VRT_PATH_AUTO) return VRT_PATH_BRICK;
     if (path == VRT_PATH_BRICK_LDS && !single) return VRT_PATH_BRICK;
     return path;
@@ -689,7 +691,7 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
     D.timed[ring] = cap == hipStreamCaptureStatusNone;
     if (D.timed[ring]) HIP_TRY(hipEventRecord(D.ev0[ring], stream));
     const bool single = ctx->scene.n_instances == 1;
-    HIP_TRY(launch_march(F, resolve_path(p->path, single, p->mode), single, stream));
+    HIP_TRY(launch_march(F, resolve_path(p->path, single, p->mode, p->flags), single, stream));
     if (D.timed[ring]) HIP_TRY(hipEventRecord(D.ev1[ring], stream));
     return VRT_OK;
 }

@@ -12,6 +12,9 @@ namespace vrt {
 constexpr int kBrickCells = 4;                 /* cells per brick edge */
 constexpr int kBrickSamples = 5;               /* samples per brick edge (cells + 1 apron) */
 constexpr int kBrickFloats = 128;              /* 125 samples padded to 512 B = 4 x 128-B lines */
+constexpr int kPathBrickSkip = 5;              /* VRT_PATH_BRICK with VRT_FLAG_SKIP_EMPTY compiled in (a run-time test in the march loop
+                                                  cost the default path 6 %) */
+constexpr int kPathDenseSkip = 6;              /* VRT_PATH_DENSE likewise */
 constexpr int kPathCube = 4;                   /* internal data path of the Cube render modes (bricks + cube_skip, exact grid traversal) */
 constexpr int kTile = 8;                       /* one wave = 8x8 pixels */
 constexpr int kBlockThreads = 256;             /* 4 waves = 16x16 pixels */

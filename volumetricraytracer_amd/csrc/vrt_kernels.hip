@@ -504,7 +504,9 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     if constexpr (PATH == kPathCube) {
         return march_cube<NORMAL>(F, I, Vd, o, d, t_cur, t_hit, n_world, steps);
     } else {
-    const VolRef V = load_vol<PATH>(Vd);
+    constexpr bool SKIP = PATH == kPathBrickSkip || PATH == kPathDenseSkip; /* VRT_FLAG_SKIP_EMPTY */
+    constexpr int DP = PATH == kPathDenseSkip ? VRT_PATH_DENSE : (PATH == kPathBrickSkip ? VRT_PATH_BRICK : PATH); /* where the taps come from */
+    const VolRef V = load_vol<DP>(Vd);
     RaySeg R;
     if constexpr (DIR_SHADOW) { /* d is the scene's directional light: its per-instance constants come precomputed */
         if (!setup_shadow_ray(F, I, V, o, t_cur, t_base, R)) return false;
@@ -531,11 +533,24 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
         }
         Taps taps;
         float leap = 0.0f;
-        if constexpr (PATH == VRT_PATH_DENSE) {
-            taps = fetch8<PATH>(V, c.cx, c.cy, c.cz);
-            if (V.skip != nullptr) leap = leap_at(V, R, brick_index(V, c.cx, c.cy, c.cz));
+        const unsigned brick = brick_index(V, c.cx, c.cy, c.cz);
+        if (SKIP && V.skip != nullptr) { /* the table byte decides before the taps are asked for */
+            leap = leap_at(V, R, brick);
+            const float thr = __builtin_fmaf(t, F.cone_eps, F.eps_hit);
+            if (leap > 0.0f && leap >= R.smax && thr + thr <= R.smax) {
+                /* nothing below the step clamp in this brick or around it: the sample could neither hit nor shorten the
+                   step (oracle: same condition, same advance) */
+                t_prev = t;
+                s_prev = R.smax;
+                t = t + __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
+                continue;
+            }
+            if constexpr (DP == VRT_PATH_DENSE) taps = fetch8<DP>(V, c.cx, c.cy, c.cz);
+            else taps = fetch8_brick(V, brick, c.cx, c.cy, c.cz);
+        } else if constexpr (DP == VRT_PATH_DENSE) {
+            taps = fetch8<DP>(V, c.cx, c.cy, c.cz);
+            if (V.skip != nullptr) leap = leap_at(V, R, brick);
         } else {
-            const unsigned brick = brick_index(V, c.cx, c.cy, c.cz);
             taps = fetch8_brick(V, brick, c.cx, c.cy, c.cz);
             if (V.skip != nullptr) leap = leap_at(V, R, brick);
         }
@@ -564,10 +579,10 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
         t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
     }
     if (!hit) return false;
-    if (s_hit < 0.0f && i > 0) t = refine_hit<PATH>(V, R, t_prev, s_prev, t, s_hit, c, steps);
+    if (s_hit < 0.0f && i > 0) t = refine_hit<DP>(V, R, t_prev, s_prev, t, s_hit, c, steps);
     t_hit = t;
-    if constexpr (NORMAL == 1) n_world = hit_normal<PATH, false>(I, V, R, c, i);
-    if constexpr (NORMAL == 2) n_world = hit_normal<PATH, true>(I, V, R, c, i);
+    if constexpr (NORMAL == 1) n_world = hit_normal<DP, false>(I, V, R, c, i);
+    if constexpr (NORMAL == 2) n_world = hit_normal<DP, true>(I, V, R, c, i);
     return true;
     }
 }
@@ -1528,13 +1543,17 @@ static hipError_t launch_t(const DFrame& F, hipStream_t stream) {
     return hipGetLastError();
 }
 
-/* Cube modes: no diagnostic instantiation. */
-template <bool SINGLE>
-static hipError_t launch_cube_t(const DFrame& F, hipStream_t stream) {
+/* Paths without a diagnostic instantiation. */
+template <int PATH, bool SINGLE>
+static hipError_t launch_nodiag_t(const DFrame& F, hipStream_t stream) {
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL((march_kernel<kPathCube, SINGLE, false>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
+    hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
     return hipGetLastError();
+}
+template <bool SINGLE>
+static hipError_t launch_cube_t(const DFrame& F, hipStream_t stream) {
+    return launch_nodiag_t<kPathCube, SINGLE>(F, stream);
 }
 
 static hipError_t launch_coop(const DFrame& F, hipStream_t stream) {
@@ -1559,6 +1578,15 @@ hipError_t launch_march(const DFrame& F, int path, bool single, hipStream_t stre
     if (path == kPathCube) {
         if (F.full) return single ? launch_full_t<kPathCube, true>(F, stream) : launch_full_t<kPathCube, false>(F, stream);
         return single ? launch_cube_t<true>(F, stream) : launch_cube_t<false>(F, stream);
+    }
+    if (path == kPathBrickSkip || path == kPathDenseSkip) { /* VRT_FLAG_SKIP_EMPTY: no diagnostic instantiation */
+        const bool dense = path == kPathDenseSkip;
+        if (F.full) {
+            if (dense) return single ? launch_full_t<kPathDenseSkip, true>(F, stream) : launch_full_t<kPathDenseSkip, false>(F, stream);
+            return single ? launch_full_t<kPathBrickSkip, true>(F, stream) : launch_full_t<kPathBrickSkip, false>(F, stream);
+        }
+        if (dense) return single ? launch_nodiag_t<kPathDenseSkip, true>(F, stream) : launch_nodiag_t<kPathDenseSkip, false>(F, stream);
+        return single ? launch_nodiag_t<kPathBrickSkip, true>(F, stream) : launch_nodiag_t<kPathBrickSkip, false>(F, stream);
     }
     if (F.full) {
         /* full closest hit: per-lane kernels on the dense grid or the bricks */
