@@ -164,3 +164,24 @@ def test_tile_rows_partition():
     assert tile_rows(2160, 8, 7) == (270, 1890, 270)  # config 4: 4K -> 270 rows each
     with pytest.raises(ValueError):
         tile_rows(10, 2, 2)
+
+
+@pytest.mark.parametrize("world,height,strip_rows", [(8, 3055, 32), (8, 1080, 32), (4, 2160, 32), (5, 77, 8)])
+def test_unshuffle_puts_every_strip_where_it_belongs(world, height, strip_rows):
+    """Rank 0's un-shuffle at the bench's real shapes (8 ranks, 3055 rows, ...) without processes: the gathered buffer is
+    filled the way the ranks' compact tiles arrive (rank-major, strip after strip), every row tagged with its frame row."""
+    import torch
+
+    from volumetricraytracer_amd.tiles import FrameGather, strip_frame_rows
+
+    width = 3
+    fg = FrameGather(height, width, world, 0, torch.device("cpu"), dtype=torch.float32, buffers=1, strip_rows=strip_rows)
+    fg.frames[0].fill_(-1.0)
+    for rank in range(world):
+        tile = fg.frames[0][rank * fg.rows_per:(rank + 1) * fg.rows_per]
+        for local0, frame0, rows in strip_frame_rows(height, world, rank, strip_rows):
+            tile[local0:local0 + rows] = torch.arange(frame0, frame0 + rows, dtype=torch.float32)[:, None, None]
+    fg.unshuffle(0)
+    got = fg.frame(0)
+    assert got.shape == (height, width, 4)
+    assert torch.equal(got[:, 0, 0], torch.arange(height, dtype=torch.float32))
