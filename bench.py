@@ -145,13 +145,18 @@ def main() -> None:
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(K - 1)]
     stream = streams[0]
 
+    # Rank 0 un-shuffles the gathered strips on a stream of its own, so that the copy does not sit between two frames of
+    # a march stream: it only has to be finished before the NEXT gather into the same frame buffer starts.
+    unshuffle = world > 1 and rank == 0 and strip_rows > 0
+    copy_stream = torch.cuda.Stream(device=dev) if unshuffle else None
+    unshuffled = [None] * K  # event: frames[b] has been copied out and may be overwritten
+
     def step(i: int) -> None:
         b = i % K
         with torch.cuda.stream(streams[b]):
             if pending[b] is not None:
                 pending[b].wait()  # tile buffer b is free again (its gather finished); stream b waits, not the host
                 pending[b] = None
-                fg.unshuffle(b)  # rank 0, strips: gathered order -> frame order (one strided device copy)
             if strip_rows > 0:
                 r.render_strips(p, strip_rows, rank, world, fg.strips_per, march_tiles[b].data_ptr(), streams[b].cuda_stream)
             else:
@@ -159,7 +164,15 @@ def main() -> None:
             if rehearsal:
                 fg.tiles[b].copy_(march_tiles[b])
             if world > 1:
+                if unshuffled[b] is not None:
+                    streams[b].wait_event(unshuffled[b])
                 pending[b] = fg.gather(b, async_op=True)  # RCCL gather over xGMI, overlaps the following frames' march
+        if unshuffle:
+            with torch.cuda.stream(copy_stream):
+                pending[b].wait()  # the copy stream (not the host) waits for this gather (gloo rehearsal: the host does)
+                fg.unshuffle(b)    # gathered [rank, strip] order -> frame order, one strided device copy
+                unshuffled[b] = torch.cuda.Event()
+                unshuffled[b].record(copy_stream)
 
     def drain() -> None:
         for b in range(K):
@@ -167,7 +180,6 @@ def main() -> None:
                 if pending[b] is not None:
                     pending[b].wait()
                     pending[b] = None
-                    fg.unshuffle(b)
         torch.cuda.synchronize()
 
     def barrier() -> None:
