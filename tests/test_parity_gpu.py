@@ -569,6 +569,14 @@ def test_frames_in_flight_keep_their_own_scene(oracle_lib):
             got.append(r.render_end(k % K, pending.pop(k % K)))
         with pytest.raises(_abi.VrtError):
             r.render_end(0, r.make_params())  # nothing in flight on that slot any more
+        # the RGBA8 frame format through the same slots: the quantised version of the float frame of the last scene
+        q = r.make_params()
+        q.flags |= _abi.FLAG_OUTPUT_RGBA8
+        r.render_begin(1, q)
+        with pytest.raises(_abi.VrtError):
+            r.render_begin(1, q)  # the slot is busy until it is collected
+        from test_tiles_gloo import quantize_rgba8
+        assert np.array_equal(r.render_end(1, q), quantize_rgba8(got[-1]))
     finally:
         r.Stop()
     assert len(got) == len(frames)
