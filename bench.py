@@ -2,97 +2,284 @@
 """Benchmark of the ray-march hot path (BASELINE.json metric: Mrays/s + ms/frame at 1080p over a
 256^3 SDF volume, 1/2/4/8 MI355X).
 
-A "step" is one full frame.  With N ranks (one process per GPU, launched by torch.distributed.run)
-the frame is cut into 32-row strips dealt round-robin to the ranks (interleaved row tiles: contiguous
-tiles would put every object row on the middle GPUs); every rank marches its strips into a compact
-device tile with ONE launch and the tiles are gathered onto rank 0 with one RCCL gather
-(torch.distributed backend "nccl") that overlaps with the next frame's march (two tile buffers);
-rank 0 un-shuffles the gathered strips into frame order.  The exchange format is R8G8B8A8_UNORM, the
-reference's own back-buffer precision (DXConstants.cpp:21): at 16 B/pixel rank 0's seven inbound
-xGMI links, not the march, would set the frame time.
+A "step" is one full frame of the workload (default: BASELINE config 3 — 1920x1080, 256^3 voxelized mesh,
+shadow ray on).  With N ranks (one process per GPU) the SAME frame is split N ways — strong scaling, as the
+metric and config 4 define it: the frame is cut into 32-row strips dealt round-robin to the ranks
+(contiguous tiles would put every object row on the middle GPUs); every rank marches its strips into a
+compact device tile with ONE launch and the tiles are gathered onto rank 0 with one RCCL gather
+(torch.distributed backend "nccl") that overlaps with the following frames' march; rank 0 un-shuffles the
+gathered strips into frame order.  The exchange format is R8G8B8A8_UNORM, the reference's own back-buffer
+precision (DXConstants.cpp:21).  `--scaling weak` (frame grows with N, fixed rays per GPU) is kept as an
+option; it is never the default.
 
-Scaling is WEAK by default: the per-GPU ray count is fixed at the 1080p frame of the metric and the
-frame grows with N at constant 16:9 aspect (N=1 1920x1080, N=2 2715x1527, N=4 3840x2160 = config 4's
-frame, N=8 5431x3055), same camera, same scene.  A 1080p frame is ~0.19 ms of GPU work, most of it
-the latency-bound tail of a few hundred grazing rays, so splitting THAT frame 8 ways
-cannot scale; `--scaling strong --workload c4` gives the fixed-4K-frame split of config 4.
+Launching: `python bench.py --gpus N` starts the N ranks itself (a child `python -m torch.distributed.run`,
+spawned BEFORE this process touches the GPU); under `torch.distributed.run` (WORLD_SIZE set) it is a rank.
+A rank whose WORLD_SIZE differs from --gpus exits non-zero.
 
-Prints ONE JSON line on rank 0 (see the driver contract), extended with "roofline" and
-"cpu_baseline".
+Prints ONE JSON line on rank 0 (driver contract) extended with:
+  roofline        contract fields (algorithmic bytes / event-timed kernel duration / 8 TB/s) PLUS the physical
+                  ones: measured HBM bytes per launch (PMC, from profiles/traffic_latest.json when it was taken
+                  with this very kernel source and these settings), their rate and fraction of peak, samples/s
+                  next to the measured gather ceilings, and what actually limits the kernel
+  cpu_baseline    the scalar oracle on this host's cores (a reported baseline)
+  latency         one frame in flight: ms per frame as an application waiting for each frame sees it
+  end_to_end      vrt_render_begin/_end: march + copy of the frame to pinned host memory, pipelined
+  config4         the same scene at 3840x2160 split the same N ways (BASELINE config 4)
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-
-import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
+# tools/microbench/gather.hip on MI355X (profiles/r01_gather_microbench.txt): trilinear samples/s the chip sustains for
+# 4 x dwordx2 taps per lane at random cells, by where the bricks live
+GATHER_CEILING_GSAMPLES = {"l1": 264.0, "l2": 209.0, "mall_hbm": 126.0}
 
 
-def build_workload(name: str):
-    """Returns (scene, width, height, max_steps, shadow, label)."""
-    import scenes
-
-    if name == "c3":
-        sc = scenes.bench_config3()
-        return sc, 1920, 1080, 255, True, "config3: 256^3 voxelized glTF-style mesh (torus, 16384 triangles), 1920x1080, shadow ray on"
-    if name == "c3sdf":
-        sc = scenes.config3_torus(8, 256, distance=190.0)
-        return sc, 1920, 1080, 255, True, "config3 (analytic SDF variant): 256^3 torus SDF, 1920x1080, shadow ray on"
-    if name == "c2":
-        sc = scenes.config2_sphere(6, 256)
-        return sc, 1280, 720, 128, False, "config2: 64^3 SDF sphere, 1280x720, 128 max steps"
-    if name == "c4":
-        sc = scenes.bench_config3()
-        return sc, 3840, 2160, 255, True, "config4: 256^3 voxelized mesh, 3840x2160, row tiles + RCCL gather"
-    if name == "c5":
-        sc = scenes.config5_instances(7, 256)
-        return sc, 1920, 1080, 255, True, "config5: 8 instanced 128^3 volumes + skybox, 1920x1080, AABB BVH"
-    raise SystemExit(f"unknown workload {name}")
-
-
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3sdf", "c4", "c5"])
     ap.add_argument("--path", default="auto", choices=["auto", "dense", "brick", "lds"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N>1: weak = frame grows with N (fixed rays per GPU); strong = the workload's own frame split N ways")
+    ap.add_argument("--format", default="auto", choices=["auto", "f32", "texel16"],
+                    help="device volume format: f32 bricks, or the reference's 16-bit texel (sign + 15-bit |d|*100)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N>1: strong = the workload's own frame split N ways (the metric); weak = frame grows with N")
     ap.add_argument("--output", default="auto", choices=["auto", "f32", "rgba8"],
                     help="tile pixel format; auto = float4 on one GPU, RGBA8 (the exchange format) on several")
     ap.add_argument("--strip-rows", type=int, default=32, help="N>1: rows per interleaved strip; 0 = contiguous row tiles")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3, 4],
-                    help="frames launched before the first one must have finished, each on its own HIP stream and tile buffer "
-                         "(the reference keeps 3 in flight, DXConstants.cpp:23)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="frames launched before the first one must have finished, each on its own HIP stream and tile "
+                         "buffer (the reference keeps 3 in flight, DXConstants.cpp:23); 0 = 2 on one GPU, 3 on several")
     ap.add_argument("--tile-map", default="supertile", choices=["supertile", "band", "linear"], help="blockIdx -> tile map (speed only)")
-    ap.add_argument("--skip-empty", action="store_true",
-                    help="VRT_FLAG_SKIP_EMPTY: no samples in bricks the leap table declares empty (same pixels, fewer samples "
-                         "and therefore fewer algorithmic bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the latency / end_to_end / config4 legs")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of the baseline sample")
-    args = ap.parse_args()
+    ap.add_argument("--launch-check", action="store_true",
+                    help="CPU-only check of the N-rank launch path: ranks rendezvous over gloo, gather synthetic tiles "
+                         "through FrameGather and report; no march, no GPU (never a measurement)")
+    return ap.parse_args(argv)
 
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int, argv) -> int:
+    """Start the n ranks as a child `python -m torch.distributed.run` and return its exit code.  Called before
+    this process has made any GPU call (a process that initialised the GPU must never be replaced or forked)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def build_workload(name: str):
+    """Returns (scene, width, height, max_steps, shadow, label)."""
+    from volumetricraytracer_amd import workloads
+
+    if name == "c3":
+        sc = workloads.bench_config3()
+        return sc, 1920, 1080, 255, True, "config3: 256^3 voxelized glTF-style mesh (torus, 16384 triangles), 1920x1080, shadow ray on"
+    if name == "c3sdf":
+        sc = workloads.config3_torus(8, 256, distance=190.0)
+        return sc, 1920, 1080, 255, True, "config3 (analytic SDF variant): 256^3 torus SDF, 1920x1080, shadow ray on"
+    if name == "c2":
+        sc = workloads.config2_sphere(6, 256)
+        return sc, 1280, 720, 128, False, "config2: 64^3 SDF sphere, 1280x720, 128 max steps"
+    if name == "c4":
+        sc = workloads.bench_config3()
+        return sc, 3840, 2160, 255, True, "config4: 256^3 voxelized mesh, 3840x2160, row tiles + RCCL gather"
+    if name == "c5":
+        sc = workloads.config5_instances(7, 256)
+        return sc, 1920, 1080, 255, True, "config5: 8 instanced 128^3 volumes + skybox, 1920x1080, AABB BVH"
+    raise SystemExit(f"unknown workload {name}")
+
+
+def kernel_source_hash() -> str:
+    """sha256 of the kernel + device-struct sources: ties a PMC traffic figure to the code it was measured on."""
+    h = hashlib.sha256()
+    for rel in ("volumetricraytracer_amd/csrc/vrt_kernels.hip", "volumetricraytracer_amd/csrc/vrt_device.h"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def traffic_key(args, world: int, K: int, rgba8: bool) -> dict:
+    return {"workload": args.workload, "n_gpus": world, "path": args.path, "format": args.format, "tile_map": args.tile_map,
+            "frames_in_flight": K, "rgba8": bool(rgba8), "kernel_source_sha": kernel_source_hash()}
+
+
+def measured_traffic(key: dict):
+    """HBM bytes per march launch from the PMC passes of tools/profile_bench.sh, or None when the committed figure
+    was not taken on this kernel source with these settings."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        tj = json.load(open(tpath))
+    except Exception:
+        return None
+    if all(tj.get("key", {}).get(k) == v for k, v in key.items()):
+        return tj.get("hbm_bytes_per_launch")
+    return None
+
+
+class Pipeline:
+    """K frames in flight: K tile buffers, K HIP streams; the gather of frame i overlaps the march of i+1.."""
+
+    def __init__(self, r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal):
+        import torch
+
+        from volumetricraytracer_amd.tiles import FrameGather
+
+        self.torch, self.r, self.p, self.world, self.rank, self.K = torch, r, p, world, rank, K
+        self.strip_rows, self.rehearsal = strip_rows, rehearsal
+        pix = torch.uint8 if rgba8 else torch.float32
+        self.fg = FrameGather(H, W, world, rank, torch.device("cpu") if rehearsal else dev, dtype=pix, buffers=K, strip_rows=strip_rows)
+        self.march_tiles = [torch.zeros_like(x, device=dev) for x in self.fg.tiles] if rehearsal else self.fg.tiles
+        self.pending = [None] * K
+        self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(K - 1)]
+        # Rank 0 un-shuffles the gathered strips on a stream of its own: the copy only has to finish before the NEXT
+        # gather into the same frame buffer starts, not between two frames of a march stream.
+        self.unshuffle = world > 1 and rank == 0 and strip_rows > 0
+        self.copy_stream = torch.cuda.Stream(device=dev) if self.unshuffle else None
+        self.unshuffled = [None] * K
+
+    def step(self, i: int) -> None:
+        torch, fg, b = self.torch, self.fg, i % self.K
+        with torch.cuda.stream(self.streams[b]):
+            if self.pending[b] is not None:
+                self.pending[b].wait()  # tile buffer b is free again (its gather finished); stream b waits, not the host
+                self.pending[b] = None
+            if self.strip_rows > 0:
+                self.r.render_strips(self.p, self.strip_rows, self.rank, self.world, fg.strips_per, self.march_tiles[b].data_ptr(),
+                                     self.streams[b].cuda_stream)
+            else:
+                self.r.render_rows(self.p, fg.row0, fg.rows, self.march_tiles[b].data_ptr(), self.streams[b].cuda_stream)
+            if self.rehearsal:
+                fg.tiles[b].copy_(self.march_tiles[b])
+            if self.world > 1:
+                if self.unshuffled[b] is not None:
+                    self.streams[b].wait_event(self.unshuffled[b])
+                self.pending[b] = fg.gather(b, async_op=True)  # RCCL gather over xGMI, overlaps the following frames' march
+        if self.unshuffle:
+            with torch.cuda.stream(self.copy_stream):
+                self.pending[b].wait()  # the copy stream (not the host) waits for this gather (gloo rehearsal: the host does)
+                fg.unshuffle(b)         # gathered [rank, strip] order -> frame order, one strided device copy
+                self.unshuffled[b] = torch.cuda.Event()
+                self.unshuffled[b].record(self.copy_stream)
+
+    def drain(self) -> None:
+        torch = self.torch
+        for b in range(self.K):
+            with torch.cuda.stream(self.streams[b]):
+                if self.pending[b] is not None:
+                    self.pending[b].wait()
+                    self.pending[b] = None
+        torch.cuda.synchronize()
+
+
+def timed_run(pipe: Pipeline, steps: int, warmup: int, world: int, cdev) -> float:
+    """W untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; MAX over ranks (seconds)."""
     import torch
     import torch.distributed as dist
 
-    import scenes
-    import volumetricraytracer_amd as v
-    from volumetricraytracer_amd import _abi
+    def barrier() -> None:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
+    for i in range(warmup):
+        pipe.step(i)
+    pipe.drain()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        pipe.step(i)
+    pipe.drain()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    return elapsed
+
+
+def launch_check(args) -> None:
+    """The N-rank plumbing without a march (CPU, gloo): rendezvous, strip layout, gather, un-shuffle, max-over-ranks."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from volumetricraytracer_amd.tiles import FrameGather, strip_frame_rows
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W, sr = 77, 16, 8
+    fg = FrameGather(H, W, world, rank, torch.device("cpu"), dtype=torch.uint8, buffers=1, strip_rows=sr if world > 1 else 0)
+    t0 = time.perf_counter()
+    for _ in range(max(args.steps, 1)):
+        if world == 1:
+            fg.tiles[0][:H] = (torch.arange(H, dtype=torch.int32) % 251).to(torch.uint8)[:, None, None]
+            continue
+        for local0, frame0, rows in strip_frame_rows(H, world, rank, sr):
+            fg.tiles[0][local0:local0 + rows] = (torch.arange(frame0, frame0 + rows, dtype=torch.int32) % 251).to(torch.uint8)[:, None, None]
+        fg.gather(0, async_op=True).wait()
+        fg.unshuffle(0)
+    te = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        ok = bool(np.array_equal(fg.frame(0)[:, 0, 0].numpy(), (np.arange(H) % 251).astype(np.uint8)))
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_joined": world, "gathered_frame_ok": ok,
+                          "elapsed_s": round(float(te.item()), 4)}), flush=True)
+        if not ok:
+            raise SystemExit(3)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main() -> None:
+    args = parse_args()
+    n = max(args.gpus, 1)
+    if "WORLD_SIZE" not in os.environ and n > 1:
+        # not under a launcher: start the ranks ourselves, before anything here touches the GPU
+        raise SystemExit(self_launch(n, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1):
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus={args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if world != n:
+        print(f"[bench] rank {rank}: WORLD_SIZE={world} but --gpus={n}: refusing to measure a different job", file=sys.stderr)
+        raise SystemExit(2)
+    if args.launch_check:
+        launch_check(args)
+        return
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import volumetricraytracer_amd as v
+    from volumetricraytracer_amd import _abi, workloads
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # VRT_BENCH_BACKEND=gloo: rehearsal of the N>1 code path on a ONE-GPU box (every rank marches on cuda:0,
@@ -102,27 +289,40 @@ def main() -> None:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearsal else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        joined = torch.ones(1, dtype=torch.int32, device=cdev)
+        dist.all_reduce(joined)
+        if int(joined.item()) != n:
+            raise SystemExit(f"[bench] only {int(joined.item())} of {n} ranks joined")
 
     sc, W, H, max_steps, shadow, label = build_workload(args.workload)
     if world > 1 and args.scaling == "weak":
         W, H = int(round(W * world ** 0.5)), int(round(H * world ** 0.5))
         label += f" -- weak-scaled to {W}x{H} for {world} GPUs"
+    elif world > 1:
+        label += f" -- the same {W}x{H} frame split over {world} GPUs (strong scaling)"
     rgba8 = args.output == "rgba8" or (args.output == "auto" and world > 1)
     strip_rows = args.strip_rows if world > 1 else 0
+    K = args.frames_in_flight or (2 if world == 1 else 3)
     path = {"auto": _abi.PATH_AUTO, "dense": _abi.PATH_DENSE, "brick": _abi.PATH_BRICK, "lds": _abi.PATH_BRICK_LDS}[args.path]
-    p = v.default_params(W, H, scenes.min_cell(sc), max_steps, shadow=shadow, path=path)
-    if rgba8:
-        p.flags |= _abi.FLAG_OUTPUT_RGBA8
-    p.flags |= {"supertile": 0, "band": 1, "linear": 2}[args.tile_map]
-    if args.skip_empty:
-        p.flags |= _abi.FLAG_SKIP_EMPTY
+    fmt = {"auto": workloads.BENCH_VOLUME_FORMAT, "f32": _abi.FORMAT_F32, "texel16": _abi.FORMAT_TEXEL16}[args.format]
+    for vol in sc.volumes():
+        vol.set_device_format(fmt)
 
+    def params(w, h):
+        q = v.default_params(w, h, workloads.min_cell(sc), max_steps, shadow=shadow, path=path)
+        if rgba8:
+            q.flags |= _abi.FLAG_OUTPUT_RGBA8
+        q.flags |= {"supertile": 0, "band": 1, "linear": 2}[args.tile_map]
+        return q
+
+    p = params(W, H)
     r = v.VHipRenderer(devices=(local_rank,))
     if not r.Start():
         raise SystemExit("VHipRenderer.Start() failed")
@@ -130,122 +330,83 @@ def main() -> None:
     r.ResizeRenderOutput(W, H)
     r.SyncWithScene()
 
-    from volumetricraytracer_amd.tiles import FrameGather
-
-    # tile of this rank + (rank 0) the gathered frames
-    pix = torch.uint8 if rgba8 else torch.float32
-    # Frames in flight: K tile buffers, K HIP streams.  A frame's last ~90 us are a few hundred latency-bound waves
-    # on an otherwise idle chip; the next frame's march fills it.  Within a buffer, frame i+K follows
-    # frame i in stream order, so a tile is never overwritten before it has been consumed.
-    K = args.frames_in_flight
-    fg = FrameGather(H, W, world, rank, torch.device("cpu") if rehearsal else dev, dtype=pix, buffers=K, strip_rows=strip_rows)
-    row0, rows = fg.row0, fg.rows
-    march_tiles = [torch.zeros_like(x, device=dev) for x in fg.tiles] if rehearsal else fg.tiles
-    pending = [None] * K
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(K - 1)]
-    stream = streams[0]
-
-    # Rank 0 un-shuffles the gathered strips on a stream of its own, so that the copy does not sit between two frames of
-    # a march stream: it only has to be finished before the NEXT gather into the same frame buffer starts.
-    unshuffle = world > 1 and rank == 0 and strip_rows > 0
-    copy_stream = torch.cuda.Stream(device=dev) if unshuffle else None
-    unshuffled = [None] * K  # event: frames[b] has been copied out and may be overwritten
-
-    def step(i: int) -> None:
-        b = i % K
-        with torch.cuda.stream(streams[b]):
-            if pending[b] is not None:
-                pending[b].wait()  # tile buffer b is free again (its gather finished); stream b waits, not the host
-                pending[b] = None
-            if strip_rows > 0:
-                r.render_strips(p, strip_rows, rank, world, fg.strips_per, march_tiles[b].data_ptr(), streams[b].cuda_stream)
-            else:
-                r.render_rows(p, row0, rows, march_tiles[b].data_ptr(), streams[b].cuda_stream)
-            if rehearsal:
-                fg.tiles[b].copy_(march_tiles[b])
-            if world > 1:
-                if unshuffled[b] is not None:
-                    streams[b].wait_event(unshuffled[b])
-                pending[b] = fg.gather(b, async_op=True)  # RCCL gather over xGMI, overlaps the following frames' march
-        if unshuffle:
-            with torch.cuda.stream(copy_stream):
-                pending[b].wait()  # the copy stream (not the host) waits for this gather (gloo rehearsal: the host does)
-                fg.unshuffle(b)    # gathered [rank, strip] order -> frame order, one strided device copy
-                unshuffled[b] = torch.cuda.Event()
-                unshuffled[b].record(copy_stream)
-
-    def drain() -> None:
-        for b in range(K):
-            with torch.cuda.stream(streams[b]):
-                if pending[b] is not None:
-                    pending[b].wait()
-                    pending[b] = None
-        torch.cuda.synchronize()
-
-    def barrier() -> None:
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        cdev = torch.device("cpu") if rehearsal else dev
-        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    pipe = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal)
+    elapsed = timed_run(pipe, args.steps, args.warmup, world, cdev)
 
     t = r.last_timing()  # this rank's tile, last frame (every frame is identical)
     kms = r.timing_history(min(args.steps, 200))
     verified = None
     if os.environ.get("VRT_BENCH_VERIFY") and rank == 0 and args.steps > 0:
         # the gathered (and un-shuffled) frame must be the frame one GPU renders alone, bit for bit
-        whole = torch.empty((H, W, 4), dtype=pix, device=dev)
-        r.render_rows(p, 0, H, whole.data_ptr(), stream.cuda_stream)
+        whole = torch.empty((H, W, 4), dtype=torch.uint8 if rgba8 else torch.float32, device=dev)
+        r.render_rows(p, 0, H, whole.data_ptr(), pipe.streams[0].cuda_stream)
         torch.cuda.synchronize()
-        got = fg.frame((args.steps - 1) % K)
+        got = pipe.fg.frame((args.steps - 1) % K)
         verified = bool(torch.equal(got.cpu(), whole.cpu()))
         if not verified:
             raise SystemExit("[bench] gathered frame differs from the single-GPU frame")
         t = dict(t)  # keep the tile's counters (the verification launch overwrote last_timing)
-    counts = torch.tensor([t["primary_rays"], t["shadow_rays"], t["primary_steps"], t["shadow_steps"], t["hits"]],
-                          dtype=torch.float64, device=torch.device("cpu") if rehearsal else dev)
-    if world > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    primary, shadow_rays, psteps, ssteps, hits = [float(x) for x in counts.tolist()]
+
+    def job_counts(tt):
+        c = torch.tensor([tt["primary_rays"], tt["shadow_rays"], tt["primary_steps"], tt["shadow_steps"], tt["hits"]],
+                         dtype=torch.float64, device=cdev)
+        if world > 1:
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        return [float(x) for x in c.tolist()]
+
+    primary, shadow_rays, psteps, ssteps, hits = job_counts(t)
     rays_per_frame = primary + shadow_rays
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
     value = rays_per_frame * args.steps / elapsed / 1e6 if args.steps > 0 else 0.0
 
+    # ---- extra legs (outside the timed region) ------------------------------------------------------------------
+    latency = end_to_end = config4 = None
+    if not args.no_extra_legs and args.steps > 0:
+        lsteps = max(min(args.steps, 50), 5)
+        # one frame in flight: what an application that waits for every frame sees
+        p1 = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, 1, rehearsal)
+        e1 = timed_run(p1, lsteps, 3, world, cdev)
+        k1 = r.timing_history(lsteps)
+        latency = {"frames_in_flight": 1, "ms_per_frame": round(e1 / lsteps * 1e3, 4), "value": round(rays_per_frame * lsteps / e1 / 1e6, 2),
+                   "unit": "Mrays/s", "kernel_ms": round(float(np.mean(k1)), 4) if k1 else None}
+        del p1
+        if world == 1:
+            end_to_end = end_to_end_leg(r, p, rays_per_frame, lsteps)
+        if args.workload in ("c3", "c4") and args.scaling == "strong":
+            W4, H4 = 3840, 2160
+            p4 = params(W4, H4)
+            r.ResizeRenderOutput(W4, H4)
+            pipe4 = Pipeline(r, p4, W4, H4, world, rank, dev, rgba8, strip_rows, K, rehearsal)
+            s4 = max(lsteps // 2, 5)
+            e4 = timed_run(pipe4, s4, 3, world, cdev)
+            c4 = job_counts(r.last_timing())
+            config4 = {"workload": f"config4: 256^3 voxelized mesh, 3840x2160 split over {world} GPU(s)" +
+                                   (", 32-row interleaved strips + RCCL gather to rank 0" if world > 1 else ""),
+                       "ms_per_frame": round(e4 / s4 * 1e3, 4), "value": round((c4[0] + c4[1]) * s4 / e4 / 1e6, 2), "unit": "Mrays/s",
+                       "steps": s4, "frames_in_flight": K}
+            del pipe4
+            r.ResizeRenderOutput(W, H)
+
     if rank == 0:
-        # roofline of the march kernel on THIS rank's tile: algorithmic bytes / mean
-        # kernel time from the hipEvent pairs recorded on the launch stream around every launch
         alg_bytes = v.algorithmic_bytes(t, 4 if rgba8 else 16)
         k_ms = float(np.mean(kms)) if kms else float("nan")
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if kms else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload and tj.get("n_gpus") == world:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        samples = int(t["primary_steps"] + t["shadow_steps"])
+        traffic = measured_traffic(traffic_key(args, world, K, rgba8))
         roofline = {
+            # contract fields: ALGORITHMIC bytes (32 B per trilinear sample + 192 B per hit + the pixel store)
+            # of one launch / its mean event-timed duration / the HBM peak
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernel": "march_kernel", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-            "samples_per_launch": int(t["primary_steps"] + t["shadow_steps"]),
+            "samples_per_launch": samples,
+            # physical picture: what really crosses the HBM interface, and what the kernel really waits for
+            "hbm_measured_GBps": round(traffic / (k_ms * 1e-3) / 1e9, 2) if traffic and kms else None,
+            "hbm_measured_frac": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and kms else None,
+            "hbm_measured_frac_of_ms_per_step": round(traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and world == 1 else None,
+            "limiter": "latency of dependent sample chains (tail) / texture-addresser gather rate (busy phase); not HBM bandwidth",
+            "gsamples_per_s": round(samples / (k_ms * 1e-3) / 1e9, 2) if kms else None,
+            "gather_ceiling_gsamples_per_s": GATHER_CEILING_GSAMPLES,
         }
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -256,14 +417,17 @@ def main() -> None:
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": W, "height": H, "volume": f"{sc.volumes()[0].N - 1}^3 cells",
+                       "volume_format": {_abi.FORMAT_F32: "f32 bricks (512 B per 4^3 cells)",
+                                         _abi.FORMAT_TEXEL16: "reference texel: sign + 15-bit |d|*100, 16-bit bricks (256 B per 4^3 cells)"}[fmt],
                        "max_steps": max_steps, "shadow": bool(shadow), "data_path": args.path,
                        "output": "rgba8 (R8G8B8A8_UNORM tiles; march and shading in f32)" if rgba8 else "f32 (float4)",
-                       "frames_in_flight": K, "skip_empty": bool(args.skip_empty),
+                       "frames_in_flight": K,
                        "parallelism": ("1 GPU" if world == 1 else
                                        (f"{strip_rows}-row interleaved strips" if strip_rows else "contiguous row tiles") +
                                        f" x{world} + " + ("gloo gather, REHEARSAL on one GPU" if rehearsal else "RCCL gather to rank 0")),
                        "rays_per_frame": int(rays_per_frame), "samples_per_ray": round((psteps + ssteps) / max(rays_per_frame, 1), 2)},
             "roofline": roofline, "cpu_baseline": cpu,
+            "latency": latency, "end_to_end": end_to_end, "config4": config4,
         }
         if verified is not None:
             out["gathered_frame_equals_single_gpu_frame"] = verified
@@ -272,6 +436,25 @@ def main() -> None:
     r.Stop()
     if world > 1:
         dist.destroy_process_group()
+
+
+def end_to_end_leg(r, p, rays_per_frame: float, steps: int):
+    """The frame as a host application gets it: vrt_render_begin / vrt_render_end with two frame slots — march,
+    then the copy of the frame into pinned host memory, the next frame's march overlapping the copy."""
+    for i in range(2):
+        r.render_begin(i % 2, p)
+        r.render_end(i % 2, p, copy=False)
+    t0 = time.perf_counter()
+    r.render_begin(0, p)
+    for i in range(1, steps):
+        r.render_begin(i % 2, p)
+        r.render_end((i - 1) % 2, p, copy=False)
+    r.render_end((steps - 1) % 2, p, copy=False)
+    dt = time.perf_counter() - t0
+    bpp = 4 if p.flags & 8 else 16
+    return {"value": round(rays_per_frame * steps / dt / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(dt / steps * 1e3, 4),
+            "includes": f"march + D2H of the {p.width}x{p.height} frame ({bpp} B/pixel) into pinned host memory, "
+                        "vrt_render_begin/_end with 2 frame slots (scene re-synchronised every frame)"}
 
 
 def cpu_baseline(sc, p, target_seconds: float):

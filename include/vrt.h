@@ -12,6 +12,8 @@
  *                                   Renderer/DX/Private/DXRenderer.cpp:204-316, 68-100
  *   vrt_volume_upload*              VDXVoxelVolume::UpdateFromVoxelVolume / UpdateVolumeTexture
  *                                   Renderer/DX/Private/RDXVoxelVolume.cpp:33-60, 294-327
+ *   vrt_set_volume_format,          VDXVoxelVolume::EncodeVoxel  RDXVoxelVolume.cpp:399-421 (the 4-byte volume texel,
+ *   vrt_volume_upload_texels        DecodeDensity Shaders/Include/Voxel.hlsli:254-266)
  *   vrt_volume_set_material         VDXVoxelVolume::UpdateGeometryConstantBuffer  :368-397
  *   vrt_volume_free                 VRDXScene::RemoveVoxelVolume  Renderer/DX/Private/RDXScene.cpp:663-701
  *   vrt_env_upload                  VRDXScene::InitEnvironmentMap RDXScene.cpp:181-199
@@ -49,10 +51,6 @@ extern "C" {
 #define VRT_FRAMES_IN_FLIGHT 3    /* frame slots of vrt_render_begin / vrt_render_end: FrameCount, DXConstants.cpp:23 */
 #define VRT_MAX_TEXTURES     64   /* 2D material textures resident at once (3 per volume slot + spare) */
 #define VRT_FLAG_DIAG_TIMELINE 4 /* run the diagnostic kernel build that stamps per-wave timeline records */
-#define VRT_FLAG_SKIP_EMPTY 32   /* do not sample where the empty-space table already decides the step: in a brick that
-                                   is two or more bricks away from any brick that can hold surface, every sample is at least the
-                                   step clamp, so the ray can only leap and cannot hit.  Same ray positions, same pixels, fewer
-                                   samples (and fewer algorithmic bytes) than without the flag */
 #define VRT_FLAG_OUTPUT_RGBA8 8  /* store R8G8B8A8_UNORM pixels (4 B, R in the low byte, A = 255) instead of float4:
                                    the reference's back-buffer precision (B8G8R8A8_UNORM, DXConstants.cpp:21);
                                    value = (uint)(min(c,1)*255 + 0.5) of the float channel the float4 path stores */
@@ -86,6 +84,16 @@ enum vrt_data_path {
     VRT_PATH_DENSE = 1,       /* taps from the dense N^3 grid in global memory */
     VRT_PATH_BRICK = 2,       /* taps from 4^3-cell (5^3-sample) bricks in global memory */
     VRT_PATH_BRICK_LDS = 3    /* bricks staged through a per-wave LDS brick cache */
+};
+
+/* How a volume's densities are kept on the device (per upload, vrt_set_volume_format). */
+enum vrt_volume_format {
+    VRT_FORMAT_F32 = 0,      /* fp32 samples: 512-B bricks of 5^3 floats (round 1's layout) */
+    VRT_FORMAT_TEXEL16 = 1   /* the reference's own volume texel: sign + 15-bit trunc(|d| * 100)
+                                (VDXVoxelVolume::EncodeVoxel, Renderer/DX/Private/RDXVoxelVolume.cpp:399-421; DecodeDensity,
+                                Shaders/Include/Voxel.hlsli:254-266), held as int16 in 256-B bricks.  The march sees exactly the
+                                field the DXR backend sees, 0.01 * (+-q): the kernels interpolate the integers and fold the 0.01
+                                into the volume's density scale */
 };
 
 /* Host/disk layout of one voxel: VVoxel, Voxel/Public/Voxel.h:23-30 (8 bytes). */
@@ -162,7 +170,7 @@ typedef struct vrt_params {
     int32_t max_bounces;  /* mirror-reflection depth, 0..2 (MAX_RAY_RECURSION_DEPTH 3 = primary + 2) */
     int32_t flags;        /* bits 0-1: blockIdx→tile map, 0 supertile (default) / 1 XCD band / 2 linear
                              (speed only, never results); bit 2: VRT_FLAG_DIAG_TIMELINE; bit 3:
-                             VRT_FLAG_OUTPUT_RGBA8; bit 5: VRT_FLAG_SKIP_EMPTY.  Others 0 */
+                             VRT_FLAG_OUTPUT_RGBA8.  Others 0 */
     float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
     float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
     float step_min;       /* lower bound of one march step (ray-parameter units) */
@@ -183,6 +191,9 @@ typedef struct vrt_timing {
     uint64_t primary_steps;  /* trilinear samples taken by primary + bounce rays */
     uint64_t shadow_steps;   /* trilinear samples taken by shadow rays */
     uint64_t hits;           /* radiance hits (each costs 6 extra trilinear samples for the normal) */
+    uint64_t exhausted_rays; /* marches (ray x instance) that visited max_steps positions while still inside the volume:
+                                treated as misses (the reference paints them red, Raytracing.hlsl:325-334); non-zero
+                                means max_steps is too small for the scene */
 } vrt_timing;
 
 typedef struct vrt_ctx vrt_ctx;
@@ -199,6 +210,14 @@ int vrt_volume_upload(vrt_ctx* ctx, int slot, uint8_t resolution, float extent,
 /* Same, straight from VVoxelVolume's storage (std::vector<VVoxel>, 8 B records). */
 int vrt_volume_upload_voxels(vrt_ctx* ctx, int slot, uint8_t resolution, float extent,
                              const vrt_voxel* voxels);
+/* Device format of the volumes uploaded FROM NOW ON (vrt_volume_upload, _upload_voxels, vrt_voxelize_mesh); default
+ * VRT_FORMAT_F32.  With VRT_FORMAT_TEXEL16 the upload quantises every density on the device the way
+ * VDXVoxelVolume::UpdateVolumeTexture does on the host (RDXVoxelVolume.cpp:294-327).  Volumes already resident keep theirs. */
+int vrt_set_volume_format(vrt_ctx* ctx, int format);
+/* The reference's volume texture itself: N^3 R8G8B8A8_UINT texels, texel (x,y,z) at byte 4*(z*N*N + y*N + x)
+ * (UpdateVolumeTexture, RDXVoxelVolume.cpp:294-327 with Core/Private/MathHelpers (2).cpp:26-46): R = sign<<7 | q>>8,
+ * G = q & 0xff, B = A = material.  Always VRT_FORMAT_TEXEL16. */
+int vrt_volume_upload_texels(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, const uint8_t* rgba8_texels);
 int vrt_volume_set_material(vrt_ctx* ctx, int slot, const vrt_material* material);
 /* density_scale: object-space length of one density unit (1 for metric SDFs; the Voxelizer's
  * extraction threshold for its shell volumes).  step_max: largest object-space step that is
@@ -244,9 +263,15 @@ int vrt_scene_set(vrt_ctx* ctx, const vrt_scene* scene);
 int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null);
 /* Render rows [row0, row0+rows) of the frame on the context's first device into a caller-owned
  * *device* buffer of rows*width float4 (uint32 R8G8B8A8 with VRT_FLAG_OUTPUT_RGBA8), asynchronously on `hip_stream` (a hipStream_t, may be
- * NULL).  No host synchronisation and — after the first launch of a given size — no allocation: safe to capture
- * into a hipGraph.  Up to 4 launches may be in flight at once on different streams (the reference keeps 3 frames
- * in flight, DXConstants.cpp:23): each uses its own counter buffer and event pair. */
+ * NULL).  No host synchronisation.  The only allocation on this path is the launch's per-wave counter buffer, which
+ * belongs to the STREAM: the first launch on a stream, and any launch with more 16x16-pixel tiles than every earlier
+ * one on that stream, allocates; all others do not.  So one un-captured launch of the same (or a larger) size on
+ * the stream you are going to capture on makes the launch safe to capture into a hipGraph.  Counter buffers are
+ * never freed before vrt_destroy, so a captured launch stays replayable after later, larger launches; it must be
+ * re-captured after vrt_volume_upload* / vrt_volume_free / vrt_texture_* / a vrt_env_upload of another size /
+ * vrt_scene_set (they replace device buffers or arrays the launch dereferences).  Up to 4 streams may have
+ * launches in flight at once (the reference keeps 3 frames in flight, DXConstants.cpp:23): each stream has its
+ * own counter buffer, each launch its own event pair. */
 int vrt_render_rows(vrt_ctx* ctx, const vrt_params* params, int row0, int rows,
                     void* device_rgba, void* hip_stream);
 
@@ -279,7 +304,7 @@ int vrt_timing_history(vrt_ctx* ctx, int n, float* kernel_ms_out);
 
 /* Diagnostics: per-wave records of the last launch on the first device, 8 words each, record
  * index = blockIdx*4 + wave.  which = 0: counters {primary_rays, shadow_rays, bounce_rays,
- * primary_steps, shadow_steps, hits, 0, 0}.  which = 1 (only after a VRT_FLAG_DIAG_TIMELINE launch):
+ * primary_steps, shadow_steps, hits, exhausted_rays, 0}.  which = 1 (only after a VRT_FLAG_DIAG_TIMELINE launch):
  * {start, end (100 MHz ticks), iterations whose taps were back within 450 cycles, XCC_ID | HW_ID<<4, longest
  * per-lane sample chain, tap-fetch cycles, march-loop cycles, march-loop iterations} of the lane with the longest
  * chain.  Returns the number of words available and copies min(max_words, that). */

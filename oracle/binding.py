@@ -36,12 +36,13 @@ class vrto_volume(C.Structure):
         ("normal_tex", vrto_texture),
         ("rm_tex", vrto_texture),
         ("tex_scale", C.c_float * 2),
+        ("format", C.c_int32),
     ]
 
 
 class vrto_stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("primary_rays", "shadow_rays", "bounce_rays", "primary_steps", "shadow_steps", "hits")]
+                ("primary_rays", "shadow_rays", "bounce_rays", "primary_steps", "shadow_steps", "hits", "exhausted_rays")]
 
 
 _lib = None
@@ -73,6 +74,8 @@ def load() -> C.CDLL:
         lib.vrto_ref_hit_t.restype = C.c_int
         lib.vrto_ref_hit_t.argtypes = [C.POINTER(vrto_volume), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                        C.POINTER(C.c_double)]
+        lib.vrto_debug_tables.restype = C.c_int
+        lib.vrto_debug_tables.argtypes = [C.POINTER(vrto_volume), C.c_void_p, C.c_void_p, C.c_void_p]
         lib.vrto_env_lookup.restype = None
         lib.vrto_env_lookup.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _lib = lib
@@ -100,6 +103,7 @@ class OracleScene:
             o.extent = v.VolumeExtends
             o.density_scale = v.density_scale
             o.step_max = v.step_max
+            o.format = int(v.device_format)
             o.material = v.Material.to_abi()
             for name, img in zip(("albedo_tex", "normal_tex", "rm_tex"), v.Material.textures()):
                 if img is not None:
@@ -144,6 +148,19 @@ class OracleScene:
         o, d = (C.c_float * 3)(), (C.c_float * 3)()
         lib.vrto_camera_ray(C.byref(self.abi), width, height, px, py, o, d)
         return np.array(list(o), dtype=np.float32), np.array(list(d), dtype=np.float32)
+
+    def tables(self, slot: int):
+        """(skip [nb,nb,nb] uint8 Chebyshev brick distances, nib [nb,nb,nb] uint32 sub-block nibbles, field [N,N,N]) of a
+        bounded-step volume, indexed [x, z, y] like the grid."""
+        vol = self.scene.volumes()[slot]
+        nb = (vol.N - 1 + 3) // 4
+        skip = np.zeros((nb, nb, nb), np.uint8)
+        nib = np.zeros((nb, nb, nb), np.uint32)
+        field = np.zeros((vol.N,) * 3, np.float32)
+        rc = load().vrto_debug_tables(C.byref(self.vols[slot]), skip.ctypes.data, nib.ctypes.data, field.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"vrto_debug_tables failed: {rc}")
+        return skip, nib, field
 
     def sample(self, slot: int, p) -> float:
         return float(load().vrto_sample(C.byref(self.vols[slot]), _f3(p)))

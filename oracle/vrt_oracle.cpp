@@ -28,6 +28,8 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include <cstdint>
@@ -123,14 +125,32 @@ struct Volume {
     vrto_texture tex[3];               /* albedo, normal, rm */
     float tex_scale[2];
     bool textured;                     /* any of the three bound */
-    /* empty-space table of volumes with a bounded step (step_max finite): per 4^3-cell brick the
-       Chebyshev distance, in bricks, to the nearest brick that holds a sample closer than step_max
-       to the surface (capped at 255).  Empty: no leaping. */
+    /* Two-level empty-space table of volumes with a bounded step (step_max finite); see build_skip_table /
+       build_nibble_table.  skip: per 4^3-cell brick the Chebyshev distance D, in bricks, to the nearest brick that
+       holds an ACTIVE cell (a cell with a corner closer than step_max to the surface), capped at 255.  nib: per
+       brick eight 4-bit fields, one per 2^3-cell sub-block (bit offset 4*((lx>>1)*4 + (lz>>1)*2 + (ly>>1))): the
+       floor of the Euclidean distance, in cells, from the sub-block's cells to the nearest active cell, capped at
+       15; only consulted where D <= 1.  Null: no leaping. */
     int nb = 0;
-    std::vector<uint8_t> skip;
+    const uint8_t* skip = nullptr;
+    const uint32_t* nib = nullptr;
     /* Cube modes: per brick the Chebyshev distance, in bricks, to the nearest brick that holds a solid
        voxel (density <= 0 at one of its 4^3 cell-origin voxels); 0 = this brick holds one.  Built on demand. */
+    const uint8_t* cube_skip = nullptr;
+    std::shared_ptr<const struct Derived> derived; /* owner of the three tables and of the quantised field */
+};
+
+/* Everything derived from a volume's samples and metric, cached across vrto_* calls (keyed by a hash of the
+   samples, never by their address): building the tables of a 256^3 volume takes seconds on one core. */
+struct Derived {
+    uint64_t key_hash = 0;
+    int N = 0, format = 0;
+    float density_scale = 0.f, step_max = 0.f;
+    std::vector<float> field;      /* VRT_FORMAT_TEXEL16: the integer-valued field the march sees */
+    std::vector<uint8_t> skip;
+    std::vector<uint32_t> nib;
     std::vector<uint8_t> cube_skip;
+    bool has_cube = false;
 };
 
 struct Instance {
@@ -201,41 +221,158 @@ void chebyshev_dilate(std::vector<uint8_t>& cur, int nb) {
     }
 }
 
+int table_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    return (int)(n < 1 ? 1 : (n > 32 ? 32 : n));
+}
+
+/* Runs fn(x0, x1) over [0, n) split into contiguous chunks on table_threads() threads. */
+template <class F>
+void parallel_slabs(int n, F fn) {
+    const int T = std::min(table_threads(), n < 1 ? 1 : n);
+    if (T <= 1) {
+        fn(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int k = 0; k < T; k++) th.emplace_back([=]() { fn((int)((long long)n * k / T), (int)((long long)n * (k + 1) / T)); });
+    for (auto& t : th) t.join();
+}
+
 /*
- * Empty-space table (restates, for the sphere-trace, what the reference's collapsed octree did for
- * its DDA: Voxel/Private/Octree.cpp:70-107,181-262 merges cells without surface).  A brick is
- * "near" when any of its 5^3 samples satisfies density*density_scale < step_max, i.e. holds a
- * trustworthy distance below the clamp.  D[b] = Chebyshev distance in bricks from b to the nearest
- * near brick.  From any point of a brick with D >= 2 the ray may advance (D-1) brick edges: that
- * cannot reach a near brick, and the interpolant is below the clamp only inside near bricks.
+ * Empty-space table, level 1 (restates, for the sphere-trace, what the reference's collapsed octree did for
+ * its DDA: Voxel/Private/Octree.cpp:70-107,181-262 merges cells without surface).  A cell is ACTIVE when one of
+ * its 8 corners satisfies density*density_scale < step_max, i.e. holds a trustworthy distance below the clamp;
+ * the interpolant is below the clamp only inside active cells.  A brick is "near" when it holds an active cell
+ * (equivalently: when any of its 5^3 samples is below the clamp).  D[b] = Chebyshev distance in bricks from b
+ * to the nearest near brick.  From any point of a brick with D >= 2 the ray may advance (D-1) brick edges: that
+ * cannot reach a near brick.
  */
-void build_skip_table(Volume& v) {
-    const int nb = v.nb, N = v.N;
+void build_skip_table(const float* den, int N, int nb, float density_scale, float step_max, std::vector<uint8_t>& out) {
     std::vector<uint8_t> cur((size_t)nb * nb * nb, 255);
-    for (int bx = 0; bx < nb; bx++)
-        for (int bz = 0; bz < nb; bz++)
-            for (int by = 0; by < nb; by++) {
-                bool near = false;
-                for (int lx = 0; lx < 5 && !near; lx++)
-                    for (int lz = 0; lz < 5 && !near; lz++)
-                        for (int ly = 0; ly < 5 && !near; ly++) {
-                            int x = bx * 4 + lx, y = by * 4 + ly, z = bz * 4 + lz;
-                            x = x > N - 1 ? N - 1 : x;
-                            y = y > N - 1 ? N - 1 : y;
-                            z = z > N - 1 ? N - 1 : z;
-                            near = v.den[((size_t)x * N + z) * N + y] * v.density_scale < v.step_max;
-                        }
-                if (near) cur[((size_t)bx * nb + bz) * nb + by] = 0;
-            }
+    parallel_slabs(nb, [&](int b0, int b1) {
+        for (int bx = b0; bx < b1; bx++)
+            for (int bz = 0; bz < nb; bz++)
+                for (int by = 0; by < nb; by++) {
+                    bool near = false;
+                    for (int lx = 0; lx < 5 && !near; lx++)
+                        for (int lz = 0; lz < 5 && !near; lz++)
+                            for (int ly = 0; ly < 5 && !near; ly++) {
+                                int x = bx * 4 + lx, y = by * 4 + ly, z = bz * 4 + lz;
+                                x = x > N - 1 ? N - 1 : x;
+                                y = y > N - 1 ? N - 1 : y;
+                                z = z > N - 1 ? N - 1 : z;
+                                near = den[((size_t)x * N + z) * N + y] * density_scale < step_max;
+                            }
+                    if (near) cur[((size_t)bx * nb + bz) * nb + by] = 0;
+                }
+    });
     chebyshev_dilate(cur, nb);
-    v.skip.swap(cur);
+    out.swap(cur);
+}
+
+/*
+ * Empty-space table, level 2: inside and next to near bricks (D <= 1) the brick table says nothing, yet most
+ * of their cells are empty too.  For every cell the squared Euclidean distance, in cells, to the nearest active
+ * cell is computed exactly within a window of kNibWindow cells (cube-to-cube distance: per axis max(|d|-1, 0)),
+ * as three separable min-plus passes (y, z, x).  A 2^3-cell sub-block keeps min over its cells of
+ * floor(sqrt(d2)), capped at 15: from any point of the sub-block the ray may advance that many cell edges
+ * without entering an active cell.
+ */
+const int kNibWindow = 16;
+void build_nibble_table(const float* den, int N, int nb, float density_scale, float step_max, std::vector<uint32_t>& out) {
+    const int C = N - 1; /* cells per axis */
+    const uint16_t INF = 0xffff;
+    std::vector<uint8_t> act((size_t)C * C * C);
+    parallel_slabs(C, [&](int x0, int x1) {
+        for (int x = x0; x < x1; x++)
+            for (int z = 0; z < C; z++)
+                for (int y = 0; y < C; y++) {
+                    bool a = false;
+                    for (int k = 0; k < 8 && !a; k++) {
+                        const int xx = x + (k >> 2), zz = z + ((k >> 1) & 1), yy = y + (k & 1);
+                        a = den[((size_t)xx * N + zz) * N + yy] * density_scale < step_max;
+                    }
+                    act[((size_t)x * C + z) * C + y] = a ? 1 : 0;
+                }
+    });
+    auto gap2 = [](int d) {
+        d = d < 0 ? -d : d;
+        d = d > 0 ? d - 1 : 0;
+        return d * d;
+    };
+    std::vector<uint16_t> g((size_t)C * C * C), h((size_t)C * C * C);
+    parallel_slabs(C, [&](int x0, int x1) { /* pass y */
+        for (int x = x0; x < x1; x++)
+            for (int z = 0; z < C; z++)
+                for (int y = 0; y < C; y++) {
+                    int best = INF;
+                    for (int d = -kNibWindow; d <= kNibWindow; d++) {
+                        const int yy = y + d;
+                        if (yy < 0 || yy >= C || !act[((size_t)x * C + z) * C + yy]) continue;
+                        const int q = gap2(d);
+                        best = q < best ? q : best;
+                    }
+                    g[((size_t)x * C + z) * C + y] = (uint16_t)best;
+                }
+    });
+    parallel_slabs(C, [&](int x0, int x1) { /* pass z */
+        for (int x = x0; x < x1; x++)
+            for (int z = 0; z < C; z++)
+                for (int y = 0; y < C; y++) {
+                    int best = INF;
+                    for (int d = -kNibWindow; d <= kNibWindow; d++) {
+                        const int zz = z + d;
+                        if (zz < 0 || zz >= C) continue;
+                        const int q = gap2(d) + (int)g[((size_t)x * C + zz) * C + y];
+                        best = q < best ? q : best;
+                    }
+                    h[((size_t)x * C + z) * C + y] = (uint16_t)best;
+                }
+    });
+    parallel_slabs(C, [&](int x0, int x1) { /* pass x */
+        for (int x = x0; x < x1; x++)
+            for (int z = 0; z < C; z++)
+                for (int y = 0; y < C; y++) {
+                    int best = INF;
+                    for (int d = -kNibWindow; d <= kNibWindow; d++) {
+                        const int xx = x + d;
+                        if (xx < 0 || xx >= C) continue;
+                        const int q = gap2(d) + (int)h[((size_t)xx * C + z) * C + y];
+                        best = q < best ? q : best;
+                    }
+                    g[((size_t)x * C + z) * C + y] = (uint16_t)best;
+                }
+    });
+    out.assign((size_t)nb * nb * nb, 0u);
+    parallel_slabs(nb, [&](int b0, int b1) {
+        for (int bx = b0; bx < b1; bx++)
+            for (int bz = 0; bz < nb; bz++)
+                for (int by = 0; by < nb; by++) {
+                    int e[8];
+                    for (int k = 0; k < 8; k++) e[k] = 15;
+                    for (int lx = 0; lx < 4; lx++)
+                        for (int lz = 0; lz < 4; lz++)
+                            for (int ly = 0; ly < 4; ly++) {
+                                const int x = bx * 4 + lx, y = by * 4 + ly, z = bz * 4 + lz;
+                                if (x >= C || y >= C || z >= C) continue;
+                                const int d2 = g[((size_t)x * C + z) * C + y];
+                                int r = 0;
+                                while (r < 15 && (r + 1) * (r + 1) <= d2) r++;
+                                const int k = (lx >> 1) * 4 + (lz >> 1) * 2 + (ly >> 1);
+                                e[k] = r < e[k] ? r : e[k];
+                            }
+                    uint32_t w = 0;
+                    for (int k = 0; k < 8; k++) w |= (uint32_t)e[k] << (4 * k);
+                    out[((size_t)bx * nb + bz) * nb + by] = w;
+                }
+    });
 }
 
 /* Cube modes (SH/Raytracing_Cube*.hlsl): voxel (x,y,z) is the cube [x,x+1)x[y,y+1)x[z,z+1) cells, solid when
    its density is <= 0 (GetVoxelDensity(currentVoxelPos) <= 0, Raytracing_Cube.hlsl:242).  The table plays the
    role of the reference's collapsed octree (big empty nodes are crossed in one step). */
-void build_cube_table(Volume& v) {
-    const int nb = v.nb, N = v.N;
+void build_cube_table(const float* den, int N, int nb, std::vector<uint8_t>& out) {
     std::vector<uint8_t> cur((size_t)nb * nb * nb, 255);
     for (int bx = 0; bx < nb; bx++)
         for (int bz = 0; bz < nb; bz++)
@@ -246,12 +383,83 @@ void build_cube_table(Volume& v) {
                         for (int ly = 0; ly < 4 && !solid; ly++) {
                             const int x = bx * 4 + lx, y = by * 4 + ly, z = bz * 4 + lz;
                             if (x > N - 2 || y > N - 2 || z > N - 2) continue;
-                            solid = v.den[((size_t)x * N + z) * N + y] <= 0.0f;
+                            solid = den[((size_t)x * N + z) * N + y] <= 0.0f;
                         }
                 if (solid) cur[((size_t)bx * nb + bz) * nb + by] = 0;
             }
     chebyshev_dilate(cur, nb);
-    v.cube_skip.swap(cur);
+    out.swap(cur);
+}
+
+/* VRT_FORMAT_TEXEL16 (R6): the reference keeps a voxel as sign + 15-bit trunc(|d| * 100) (VDXVoxelVolume::EncodeVoxel,
+   Renderer/DX/Private/RDXVoxelVolume.cpp:399-421) and decodes (float)q * 0.01 (DecodeDensity, SH/Include/Voxel.hlsli:254-266).
+   The march works on the integer field i = +-q (held as floats; int16 on the device) with the density unit 0.01
+   folded into the volume's density scale: the same field, 0.01 * i, with one rounding less per tap. */
+inline float texel16_value(float d) {
+    const float a = fabsf(d) * 100.0f;
+    uint32_t q = 0;
+    if (a >= 4294967040.0f) q = 0xffffffffu;
+    else if (a >= 0.0f) q = (uint32_t)a; /* NaN -> 0 */
+    q &= 0x7fffu;
+    const float v = (float)q;
+    return d < 0.0f ? -v : v;
+}
+
+uint64_t hash_floats(const float* p, size_t n) {
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)n;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+    for (size_t i = 0; i < n; i++) {
+        h ^= w[i];
+        h *= 0x100000001b3ull;
+        h = (h << 29) | (h >> 35);
+    }
+    return h;
+}
+
+std::mutex g_cache_mutex;
+std::vector<std::shared_ptr<Derived>> g_cache; /* most recently used last */
+
+/* The derived data of one volume for one metric; `want_cube` adds the Cube modes' table. */
+std::shared_ptr<const Derived> derive(const vrto_volume& s, int N, int nb, bool want_cube) {
+    const size_t count = (size_t)N * N * N;
+    const uint64_t hsh = hash_floats(s.density, count);
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    std::shared_ptr<Derived> d;
+    for (size_t i = 0; i < g_cache.size(); i++) {
+        Derived& c = *g_cache[i];
+        if (c.key_hash == hsh && c.N == N && c.format == s.format && c.density_scale == s.density_scale && c.step_max == s.step_max) {
+            d = g_cache[i];
+            g_cache.erase(g_cache.begin() + (long)i);
+            break;
+        }
+    }
+    if (!d) {
+        d = std::make_shared<Derived>();
+        d->key_hash = hsh;
+        d->N = N;
+        d->format = s.format;
+        d->density_scale = s.density_scale;
+        d->step_max = s.step_max;
+        const float* field = s.density;
+        float scale = s.density_scale;
+        if (s.format == VRT_FORMAT_TEXEL16) {
+            d->field.resize(count);
+            for (size_t i = 0; i < count; i++) d->field[i] = texel16_value(s.density[i]);
+            field = d->field.data();
+            scale = s.density_scale * 0.01f;
+        }
+        if (s.step_max > 0.0f) {
+            build_skip_table(field, N, nb, scale, s.step_max, d->skip);
+            build_nibble_table(field, N, nb, scale, s.step_max, d->nib);
+        }
+    }
+    if (want_cube && !d->has_cube) {
+        build_cube_table(s.format == VRT_FORMAT_TEXEL16 ? d->field.data() : s.density, N, nb, d->cube_skip);
+        d->has_cube = true;
+    }
+    g_cache.push_back(d);
+    while (g_cache.size() > 6) g_cache.erase(g_cache.begin());
+    return d;
 }
 
 bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env, int env_size,
@@ -269,7 +477,7 @@ bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env
         v.extent = s.extent;
         v.cell = (s.extent * 2.0f) / (float)(v.N - 1);
         v.inv_cell = 1.0f / v.cell;
-        v.density_scale = s.density_scale;
+        v.density_scale = s.format == VRT_FORMAT_TEXEL16 ? s.density_scale * 0.01f : s.density_scale;
         v.step_max = s.step_max > 0.0f ? s.step_max : std::numeric_limits<float>::infinity();
         v.tint[0] = s.material.tint[0];
         v.tint[1] = s.material.tint[1];
@@ -291,10 +499,12 @@ bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env
         float r1 = s.material.roughness + 1.0f;
         v.k = (r1 * r1) / 8.0f; /* RDXVoxelVolume.cpp:383, from the unclamped roughness */
         v.nb = (v.N - 1 + 3) / 4;
-        v.skip.clear();
-        if (s.step_max > 0.0f) build_skip_table(v);
-        v.cube_skip.clear();
-        if (prm->mode >= VRT_MODE_CUBE) build_cube_table(v);
+        if (s.format != VRT_FORMAT_F32 && s.format != VRT_FORMAT_TEXEL16) return false;
+        v.derived = derive(s, v.N, v.nb, prm->mode >= VRT_MODE_CUBE);
+        if (s.format == VRT_FORMAT_TEXEL16) v.den = v.derived->field.data();
+        v.skip = s.step_max > 0.0f ? v.derived->skip.data() : nullptr;
+        v.nib = s.step_max > 0.0f ? v.derived->nib.data() : nullptr;
+        v.cube_skip = prm->mode >= VRT_MODE_CUBE ? v.derived->cube_skip.data() : nullptr;
     }
     P.n_inst = scene->n_instances;
     for (int i = 0; i < P.n_inst; i++) {
@@ -334,8 +544,10 @@ inline float trilinear(const Volume& v, int cx, int cy, int cz, float fx, float 
 
 struct Stats {
     uint64_t primary_rays = 0, shadow_rays = 0, bounce_rays = 0;
-    uint64_t primary_steps = 0, shadow_steps = 0, hits = 0;
+    uint64_t primary_steps = 0, shadow_steps = 0, hits = 0, exhausted = 0;
 };
+/* marches (ray x instance) that ran out of budget inside the volume, counted per thread and collected by vrto_render */
+thread_local uint64_t g_exhausted = 0;
 
 struct HitRec {
     float t;
@@ -448,6 +660,7 @@ bool march_cube(const Packed& P, int ii, V3 o, V3 d, float t_cur, bool want_norm
         t = maxf(t_new, t);
         axis_in = axis;
     }
+    if (P.prm.max_steps > 0 && !(t > t_end)) g_exhausted++;
     return false;
 }
 
@@ -476,6 +689,7 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
        the path that led to this ray's origin: 0 for camera rays, the hit distance for shadow rays) */
     const float base_min = fmaf(t_base, P.prm.cone_eps, P.prm.step_min);
     const float leap_unit = (4.0f * V.cell) * inv_len; /* one brick edge in ray-parameter units */
+    const float cell_unit = leap_unit * 0.25f;         /* one cell edge */
     float t_prev = t, s_prev = 0.0f;
     for (int i = 0; i < P.prm.max_steps; i++) {
         if (t > t_end) return false;
@@ -485,17 +699,27 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
         float czf = minf(maxf(floorf(uz), 0.0f), cmax);
         float fx = ux - cxf, fy = uy - cyf, fz = uz - czf;
         int cx = (int)cxf, cy = (int)cyf, cz = (int)czf;
-        if ((P.prm.flags & VRT_FLAG_SKIP_EMPTY) && !V.skip.empty()) {
-            /* A brick with D >= 2 holds no sample below the step clamp (nor do its neighbours), so a sample here is
-               >= smax: it cannot be a hit while the threshold is below smax (factor 2: rounding margin), and
-               max(min(s*k, smax), footprint, leap) = max(footprint, leap) once leap >= smax.  Advance without sampling. */
-            const int dd = V.skip[((size_t)(cx >> 2) * V.nb + (size_t)(cz >> 2)) * V.nb + (size_t)(cy >> 2)];
-            const float leap0 = (float)(dd > 1 ? dd - 1 : 0) * leap_unit;
+        /* Empty-space leap L from the two-level table: (D-1) brick edges where the nearest near brick is D >= 2 bricks
+           away, else the sub-block's distance to the nearest active cell in cell edges.  Such a move cannot enter an
+           active cell, and the interpolant is below the step clamp only inside active cells. */
+        float leap = 0.0f;
+        if (V.skip) {
+            const size_t brick = ((size_t)(cx >> 2) * V.nb + (size_t)(cz >> 2)) * V.nb + (size_t)(cy >> 2);
+            const int dd = V.skip[brick];
+            if (dd > 1) {
+                leap = (float)(dd - 1) * leap_unit;
+            } else {
+                const int k = ((cx >> 1) & 1) * 4 + ((cz >> 1) & 1) * 2 + ((cy >> 1) & 1);
+                leap = (float)((V.nib[brick] >> (4 * k)) & 15u) * cell_unit;
+            }
+            /* No active cell here: a sample would be >= smax, so it cannot be a hit while the threshold is below smax
+               (factor 2: rounding margin), and max(min(s*k, smax), footprint, leap) = max(footprint, leap) once
+               leap >= smax.  The ray advances without sampling (no tap is read, no sample is counted). */
             const float thr = fmaf(t, P.prm.cone_eps, P.prm.eps_hit);
-            if (dd > 1 && leap0 >= smax && thr + thr <= smax) {
+            if (leap > 0.0f && leap >= smax && thr + thr <= smax) {
                 t_prev = t;
                 s_prev = smax;
-                t = t + fmaxf(fmaf(t, P.prm.cone_eps, base_min), leap0);
+                t = t + fmaxf(fmaf(t, P.prm.cone_eps, base_min), leap);
                 continue;
             }
         }
@@ -557,16 +781,11 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
             return true;
         }
         t_prev = t;
-        s_prev = s;
-        float adv_min = fmaf(t, P.prm.cone_eps, base_min);
-        if (!V.skip.empty()) {
-            /* empty-space leap: (D-1) brick edges from a brick whose nearest near brick is D away */
-            const int d = V.skip[((size_t)(cx >> 2) * V.nb + (size_t)(cz >> 2)) * V.nb + (size_t)(cy >> 2)];
-            const float leap = (float)(d > 1 ? d - 1 : 0) * leap_unit;
-            adv_min = fmaxf(adv_min, leap);
-        }
+        s_prev = fminf(s, smax); /* what a skipped sample would have recorded: the secant of an overshoot repair starts from it */
+        const float adv_min = fmaxf(fmaf(t, P.prm.cone_eps, base_min), leap);
         t = t + fmaxf(fminf(s * P.prm.k_relax, smax), adv_min);
     }
+    if (P.prm.max_steps > 0 && !(t > t_end)) g_exhausted++;
     return false;
 }
 
@@ -789,8 +1008,17 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
     bool shadows = level < MAX_DEPTH; /* TraceShadowRay's recursion guard, Ray.hlsli:83-86 */
     V3 diffuse = v3(0.0f, 0.0f, 0.0f); /* SHADOW_BRIGHTNESS */
 
+    const vrt_scene* S = P.scene;
+    const int npl = S->n_point_lights < VRT_MAX_POINT_LIGHTS ? S->n_point_lights : VRT_MAX_POINT_LIGHTS;
+    const int nsl = S->n_spot_lights < VRT_MAX_SPOT_LIGHTS ? S->n_spot_lights : VRT_MAX_SPOT_LIGHTS;
+    const bool bounce = rough < 0.3f && level <= P.prm.max_bounces && level < MAX_DEPTH;
+    /* A surface facing away from the directional light gets a contribution <= 0 from it whether the shadow ray is
+       blocked (0) or not (BRDF >= 0, Li >= 0, n.wi <= 0).  When that light is the only term of this hit's colour (no
+       point / spot light, no mirror bounce) the colour is <= 0 either way and every consumer clamps it to 0 (tone-map;
+       the parent's max(0, fade)): the shadow ray cannot change the pixel and is not cast. */
+    const bool lone_backfacing = npl == 0 && nsl == 0 && !bounce && !(dot(n, P.light_dir) > 0.0f);
     bool shadowed = false;
-    if (P.prm.shadow && shadows) {
+    if (P.prm.shadow && shadows && !lone_backfacing) {
         st.shadow_rays++;
         uint64_t ss = 0;
         shadowed = trace_any(P, so, P.light_dir, 5000.0f, t_base + h.t, ss);
@@ -803,8 +1031,6 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
         diffuse = diffuse + r;
     }
 
-    const vrt_scene* S = P.scene;
-    int npl = S->n_point_lights < VRT_MAX_POINT_LIGHTS ? S->n_point_lights : VRT_MAX_POINT_LIGHTS;
     for (int i = 0; i < npl; i++) {
         const vrt_point_light& L = S->point_lights[i];
         V3 lp = v3(L.position[0], L.position[1], L.position[2]);
@@ -828,7 +1054,6 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
             }
         }
     }
-    int nsl = S->n_spot_lights < VRT_MAX_SPOT_LIGHTS ? S->n_spot_lights : VRT_MAX_SPOT_LIGHTS;
     for (int i = 0; i < nsl; i++) {
         const vrt_spot_light& L = S->spot_lights[i];
         V3 lp = v3(L.position[0], L.position[1], L.position[2]);
@@ -864,7 +1089,7 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
     /* Mirror bounce (Raytracing.hlsl:79-90).  The reference adds it before the direct light; here it is
        added last so that the kernel can evaluate the recursion as a loop with the same rounding
        (colour = direct + reflection at every level). */
-    if (rough < 0.3f && level <= P.prm.max_bounces && level < MAX_DEPTH) {
+    if (bounce) {
         float dn = dot(d, n);
         V3 rd = normalize(v3(d.x - (2.0f * dn) * n.x, d.y - (2.0f * dn) * n.y, d.z - (2.0f * dn) * n.z));
         st.bounce_rays++;
@@ -887,6 +1112,7 @@ inline float tonemap(float c) {
 
 void render_rows(const Packed& P, int y0, int y1, int row0, float* out, Stats& st) {
     int W = P.prm.width, H = P.prm.height;
+    const uint64_t exhausted0 = g_exhausted;
     for (int y = y0; y < y1; y++) {
         for (int x = 0; x < W; x++) {
             V3 o, d;
@@ -902,6 +1128,7 @@ void render_rows(const Packed& P, int y0, int y1, int row0, float* out, Stats& s
             px[3] = 1.0f;
         }
     }
+    st.exhausted += g_exhausted - exhausted0;
 }
 
 bool mode_supported(int mode) { return mode >= VRT_MODE_INTERP && mode <= VRT_MODE_CUBE_NOTEX_UNLIT; }
@@ -958,6 +1185,7 @@ int vrto_render(const vrt_scene* scene, const vrto_volume* volumes, const uint8_
             s.primary_steps += a.primary_steps;
             s.shadow_steps += a.shadow_steps;
             s.hits += a.hits;
+            s.exhausted_rays += a.exhausted;
         }
         *stats_or_null = s;
     }
@@ -1018,6 +1246,20 @@ float vrto_sample(const vrto_volume* vol, const float p[3]) {
         f[a] = u[a] - cf[a];
     }
     return trilinear(V, (int)cf[0], (int)cf[1], (int)cf[2], f[0], f[1], f[2]);
+}
+
+int vrto_debug_tables(const vrto_volume* vol, uint8_t* skip_out, uint32_t* nib_out, float* field_out) {
+    if (!vol || !vol->density || !(vol->step_max > 0.0f)) return VRT_ERR_INVALID;
+    const int N = (1 << vol->resolution) + 1, nb = (N - 1 + 3) / 4;
+    std::shared_ptr<const Derived> d = derive(*vol, N, nb, false);
+    const size_t n = (size_t)nb * nb * nb;
+    if (skip_out) memcpy(skip_out, d->skip.data(), n);
+    if (nib_out) memcpy(nib_out, d->nib.data(), n * sizeof(uint32_t));
+    if (field_out) {
+        const float* f = vol->format == VRT_FORMAT_TEXEL16 ? d->field.data() : vol->density;
+        memcpy(field_out, f, sizeof(float) * (size_t)N * N * N);
+    }
+    return VRT_OK;
 }
 
 void vrto_env_lookup(const uint8_t* env_rgba8, int face_size, const float dir[3], float rgb_out[3]) {

@@ -37,11 +37,13 @@ typedef struct vrto_volume {
     vrt_material material;
     vrto_texture albedo_tex, normal_tex, rm_tex; /* VMaterial::{Albedo,Normal,RM}TexturePath, Material.h:29-31 */
     float tex_scale[2];                          /* VMaterial::TextureScale (default 100,100), Material.h:33 */
+    int32_t format;                              /* vrt_volume_format: VRT_FORMAT_TEXEL16 marches the reference's 16-bit texel of `density` */
 } vrto_volume;
 
 typedef struct vrto_stats {
     uint64_t primary_rays, shadow_rays, bounce_rays;
     uint64_t primary_steps, shadow_steps, hits;
+    uint64_t exhausted_rays; /* marches that ran out of budget inside the volume (vrt_timing::exhausted_rays) */
 } vrto_stats;
 
 /* Renders rows [row0,row0+rows) of the width x height frame into out_rgba (rows*width float4).
@@ -74,6 +76,11 @@ float vrto_sample(const vrto_volume* vol, const float p[3]);
  * octree skip).  Double precision.  Returns 1 and the ray parameter of the first zero
  * crossing, or 0.  Used to check that the sphere-trace converges to the reference's surface. */
 int vrto_ref_hit_t(const vrto_volume* vol, const float origin[3], const float dir[3], double* t_out);
+
+/* Debug: the two-level empty-space table the march uses for `vol` under its metric (step_max > 0) — skip_out: nb^3
+ * Chebyshev brick distances D, nib_out: nb^3 words of sub-block nibbles — and (field_out, N^3 floats) the field the march
+ * samples (the integer field +-q for VRT_FORMAT_TEXEL16).  Any pointer may be NULL. */
+int vrto_debug_tables(const vrto_volume* vol, uint8_t* skip_out, uint32_t* nib_out, float* field_out);
 
 /* Cube-map lookup used by the miss path (dir is a world direction; returns rgb). */
 void vrto_env_lookup(const uint8_t* env_rgba8, int face_size, const float dir[3], float rgb_out[3]);

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-import scenes  # noqa: E402
+from volumetricraytracer_amd import workloads as scenes  # noqa: E402
 import volumetricraytracer_amd as v  # noqa: E402
 
 CASES = {
@@ -23,6 +23,9 @@ CASES = {
     "config2_64x36": (scenes.config2_sphere, dict(resolution=6, env=16), 64, 36, 128, False),
     "config3_96x54": (scenes.config3_torus, dict(resolution=6, env=16), 96, 54, 255, True),
     "config5_96x54": (scenes.config5_instances, dict(resolution=5, env=16), 96, 54, 255, True),
+    # round 2: Voxelizer shell volume (two-level empty-space table), as fp32 and as the reference's 16-bit texel
+    "config3vox_96x54": (scenes.config3_voxelized, dict(resolution=6, env=16), 96, 54, 255, True),
+    "config3vox_texel16_96x54": (scenes.config3_voxelized, dict(resolution=6, env=16, device_format=1), 96, 54, 255, True),
 }
 
 

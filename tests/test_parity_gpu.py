@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-import scenes
+from volumetricraytracer_amd import workloads as scenes
 import volumetricraytracer_amd as v
 from oracle.binding import OracleScene
 from volumetricraytracer_amd import _abi
@@ -16,7 +16,7 @@ from volumetricraytracer_amd import _abi
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-STAT_KEYS = ("primary_rays", "shadow_rays", "bounce_rays", "primary_steps", "shadow_steps", "hits")
+STAT_KEYS = ("primary_rays", "shadow_rays", "bounce_rays", "primary_steps", "shadow_steps", "hits", "exhausted_rays")
 
 
 def gpu_render(r, sc, p):
@@ -251,28 +251,159 @@ def test_voxelizer_cli_on_the_device_writes_the_same_file(tmp_path):
     assert len(a) > 2_000_000 and a == b
 
 
+@pytest.mark.parametrize("fmt", [_abi.FORMAT_F32, _abi.FORMAT_TEXEL16])
 @pytest.mark.parametrize("path", [_abi.PATH_BRICK, _abi.PATH_DENSE, _abi.PATH_BRICK_LDS])
-def test_skip_empty_option_parity(renderer, oracle_lib, path):
-    """VRT_FLAG_SKIP_EMPTY on the shell volume (single instance), the instanced scene and the full closest hit: pixels and
-    counters equal the oracle's with the same flag, and the frame is bit-identical to the frame without the flag."""
-    for sc, w, h, single in ((scenes.config3_voxelized(6, 16), 320, 180, True), (scenes.full_closest_hit_scene(), 240, 136, False)):
-        p = v.default_params(w, h, scenes.min_cell(sc), 255, shadow=True, path=path)
-        p.max_bounces = 2
-        plain, t0 = gpu_render(renderer, sc, p)
-        p.flags |= _abi.FLAG_SKIP_EMPTY
-        img, t = assert_parity(renderer, sc, p, check_stats=single)
-        assert np.array_equal(img, plain)
-        if single:
-            assert t["primary_steps"] < 0.8 * t0["primary_steps"]
+def test_shell_volume_paths_and_formats_parity(renderer, oracle_lib, path, fmt):
+    """Voxelizer shell volumes march with the two-level empty-space table (brick bytes + sub-block nibbles) and never
+    sample where it shows no active cell.  Every data path (int16 bricks when the volume is in the reference's texel
+    format) on the single-instance scene, the instanced scene (BVH) and the full closest hit: pixels <= 1e-4, every
+    counter exact where the traversal order is the oracle's, and all paths bit-identical to each other."""
+    sc = scenes.config3_voxelized(6, 16, device_format=fmt)
+    p = v.default_params(320, 180, scenes.min_cell(sc), 255, shadow=True, path=path)
+    img, t = assert_parity(renderer, sc, p)
+    assert 0 < t["shadow_rays"] < t["hits"]
+    q = v.default_params(320, 180, scenes.min_cell(sc), 255, shadow=True, path=_abi.PATH_DENSE)
+    other, _ = gpu_render(renderer, sc, q)
+    assert np.array_equal(img, other)
     shell_instances = scenes.config5_instances(5, 16)
-    vol = scenes.voxelized_torus(5)
+    vol = scenes.voxelized_torus(5).set_device_format(fmt)
     for o in shell_instances.Objects:
         o.Volume = vol
     p = v.default_params(240, 136, vol.GetCellSize(), 255, shadow=True, path=path)
-    plain, _ = gpu_render(renderer, shell_instances, p)
-    p.flags |= _abi.FLAG_SKIP_EMPTY
-    img, _ = assert_parity(renderer, shell_instances, p, check_stats=False)
-    assert np.array_equal(img, plain)
+    assert_parity(renderer, shell_instances, p, check_stats=False)
+    full = scenes.full_closest_hit_scene()
+    for vv in full.volumes():
+        vv.set_device_format(fmt)
+    p = v.default_params(240, 136, scenes.min_cell(full), 255, shadow=True, path=path)
+    p.max_bounces = 2
+    assert_parity(renderer, full, p, check_stats=False)
+
+
+def test_reference_texel_upload_is_the_texel16_format(renderer, oracle_lib):
+    """R6: vrt_volume_upload_texels takes the reference's own RGBA8 volume texture (UpdateVolumeTexture,
+    RDXVoxelVolume.cpp:294-327).  Same frame, bit for bit, as the fp32 upload in VRT_FORMAT_TEXEL16 (which quantises on the
+    device), also after a round trip through vrt_volume_download; a scene mixing both formats marches the dense grids."""
+    sc = scenes.config3_voxelized(6, 16, device_format=_abi.FORMAT_TEXEL16)
+    vol = sc.volumes()[0]
+    p = v.default_params(256, 144, scenes.min_cell(sc), 255, shadow=True)
+    a, ta = assert_parity(renderer, sc, p)
+    renderer.SetSceneToRender(sc)
+    renderer.SyncWithScene()
+    renderer.upload_volume(0, vol, as_texels=True)
+    buf = np.empty((p.height, p.width, 4), np.float32)
+    _abi.check(renderer._lib.vrt_render(renderer._ctx, C.byref(p), buf.ctypes.data_as(C.c_void_p)), "vrt_render")
+    assert np.array_equal(a, buf)
+    back = renderer.download_volume(0, vol.Resolution, vol.VolumeExtends)
+    want = vol.density.copy()
+    q = ((np.abs(want) * np.float32(100.0)).astype(np.int64) & 0x7FFF).astype(np.float32) * np.float32(0.01)
+    assert np.array_equal(back.density, np.where(want < 0, -q, q).astype(np.float32))
+    assert np.array_equal(back.material_id, vol.material_id)
+    # mixed formats in one scene
+    mixed = scenes.config5_instances(5, 16, distinct_volumes=True)
+    for i, vv in enumerate(mixed.volumes()):
+        vv.set_device_format(_abi.FORMAT_TEXEL16 if i % 2 else _abi.FORMAT_F32)
+    pm = v.default_params(240, 136, scenes.min_cell(mixed), 255, shadow=True)
+    assert_parity(renderer, mixed, pm, check_stats=False)
+    pm.mode = _abi.MODE_CUBE_NOTEX
+    renderer.SetSceneToRender(mixed)
+    renderer.SyncWithScene()
+    rc = renderer._lib.vrt_render(renderer._ctx, C.byref(pm), None)
+    assert rc == _abi.VRT_ERR_UNSUPPORTED  # the one combination without a kernel, refused loudly
+
+
+@pytest.mark.parametrize("fmt,path", [(_abi.FORMAT_F32, _abi.PATH_BRICK), (_abi.FORMAT_F32, _abi.PATH_DENSE), (_abi.FORMAT_F32, _abi.PATH_BRICK_LDS),
+                                      (_abi.FORMAT_TEXEL16, _abi.PATH_BRICK)])
+def test_bench_volume_parity(renderer, oracle_lib, path, fmt):
+    """The volume bench.py marches — BASELINE config 3: the 256^3 Voxelizer shell of the torus mesh, shadow ray on — at
+    640x360 on every data path and in both device formats: pixels <= 1e-4 on all pixels, all seven counters exact."""
+    sc = scenes.bench_config3()
+    for vol in sc.volumes():
+        vol.set_device_format(fmt)
+    try:
+        p = v.default_params(640, 360, scenes.min_cell(sc), 255, shadow=True, path=path)
+        img, t = assert_parity(renderer, sc, p)
+        assert t["hits"] > 30000 and t["exhausted_rays"] == 0
+    finally:
+        for vol in sc.volumes():
+            vol.set_device_format(_abi.FORMAT_F32)
+
+
+def _oracle_bands(sc, p, img, bands=8, rows=16):
+    """Oracle comparison on `bands` bands of `rows` rows spread over the frame (the oracle renders row ranges)."""
+    o = OracleScene(sc)
+    worst = 0.0
+    for k in range(bands):
+        y0 = min(int((k + 0.5) * p.height / bands) // 16 * 16, p.height - rows)
+        ref, _ = o.render(p, y0, rows, threads=8)
+        worst = max(worst, float(np.abs(img[y0:y0 + rows] - ref).max()))
+    return worst
+
+
+def test_config4_real_frame_in_eight_strip_launches(renderer, oracle_lib):
+    """BASELINE config 4 at its real size: the 3840x2160 frame over the 256^3 bench volume rendered as 8 interleaved-strip
+    launches (what 8 ranks do, one after the other on this GPU) into compact tiles, un-shuffled like rank 0 does: bit-equal to
+    the single-launch 4K frame; and that frame against the oracle on 8 sampled 16-row bands."""
+    import torch
+
+    from volumetricraytracer_amd.tiles import FrameGather
+
+    sc = scenes.bench_config3()
+    W, H, n, sr = 3840, 2160, 8, 32
+    p = v.default_params(W, H, scenes.min_cell(sc), 255, shadow=True)
+    renderer.SetSceneToRender(sc)
+    renderer.ResizeRenderOutput(W, H)
+    renderer.SyncWithScene()
+    dev = torch.device("cuda", 0)
+    whole = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+    renderer.render_rows(p, 0, H, whole.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    fg = FrameGather(H, W, n, 0, dev, dtype=torch.float32, buffers=1, strip_rows=sr)
+    rays = 0
+    for g in range(n):
+        tile = fg.frames[0][g * fg.rows_per:(g + 1) * fg.rows_per]
+        renderer.render_strips(p, sr, g, n, fg.strips_per, tile.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        rays += renderer.last_timing()["primary_rays"]
+    fg.unshuffle(0)
+    torch.cuda.synchronize()
+    assert rays == W * H
+    assert torch.equal(fg.frame(0), whole)
+    img = whole.cpu().numpy()
+    assert _oracle_bands(sc, p, img) <= TOL
+
+
+def test_config5_real_size_bands(renderer, oracle_lib):
+    """BASELINE config 5 at its real size: 8 instances of a 128^3 volume + skybox at 1920x1080 through the BVH, against
+    the oracle on 8 sampled 16-row bands."""
+    sc = scenes.config5_instances(7, 256)
+    p = v.default_params(1920, 1080, scenes.min_cell(sc), 255, shadow=True)
+    img, t = gpu_render(renderer, sc, p)
+    assert t["primary_rays"] == 1920 * 1080 and t["hits"] > 100000 and t["exhausted_rays"] == 0
+    assert _oracle_bands(sc, p, img) <= TOL
+
+
+@pytest.mark.parametrize("resolution,max_steps", [(8, 255), (9, 255)])
+def test_no_ray_runs_out_of_budget_on_closed_surfaces(renderer, resolution, max_steps):
+    """A march that visits max_steps positions while still inside the volume is treated as a miss — a hole in a closed
+    surface (the reference paints it red, Raytracing.hlsl:325-334).  At the reference's budget of 255 (Raytracing.hlsl:229)
+    no ray of the 1080p frame may run out on the Voxelizer shell of the torus, at 256^3 and at 512^3 (the largest volume)."""
+    from volumetricraytracer_amd import voxelizer as vx
+
+    pos, _, idx = vx.torus_mesh(0.55, 0.22, 128, 64)
+    pts, _ = vx.importer_space(pos)
+    sc = scenes.config3_voxelized(6, 16)  # camera, light and sky of config 3; the volume comes from the device Voxelizer
+    small = sc.volumes()[0]
+    renderer.SetSceneToRender(sc)
+    renderer.SyncWithScene()
+    extent = small.VolumeExtends
+    renderer.voxelize_mesh(0, pts, idx, resolution, extent)
+    cell = 2.0 * extent / (1 << resolution)
+    p = v.default_params(1920, 1080, cell, max_steps, shadow=True)
+    buf = np.empty((p.height, p.width, 4), np.float32)
+    _abi.check(renderer._lib.vrt_render(renderer._ctx, C.byref(p), buf.ctypes.data_as(C.c_void_p)), "vrt_render")
+    t = renderer.last_timing()
+    assert t["hits"] > 300000
+    assert t["exhausted_rays"] == 0, t
 
 
 @pytest.mark.parametrize("kind", ["nan", "inf", "-inf", "mix"])
@@ -341,7 +472,7 @@ def test_cube_mode_edge_cases(renderer, oracle_lib):
         assert_parity(renderer, s2, v.default_params(64, 36, vol.GetCellSize(), 255, shadow=True, mode=_abi.MODE_CUBE_NOTEX))
 
 
-@pytest.mark.parametrize("name", ["config2_64x36", "config3_96x54", "config5_96x54"])
+@pytest.mark.parametrize("name", ["config2_64x36", "config3_96x54", "config5_96x54", "config3vox_96x54", "config3vox_texel16_96x54"])
 def test_against_frozen_golden_images(renderer, name):
     from golden.make_golden import CASES, build_case
 
@@ -489,33 +620,34 @@ def test_rgba8_output_is_the_quantised_float_frame(renderer, oracle_lib):
 
 
 def test_bench_two_rank_rehearsal(oracle_lib):
-    """bench.py's N>1 code path end to end with 2 ranks sharing this box's one GPU (strips, RGBA8 tiles,
-    gather, un-shuffle, max-over-ranks timing, counters summed over ranks).  The tiles travel over gloo via
-    host memory here (RCCL needs one GPU per rank); rank 0 checks the gathered frame bit for bit against the
-    frame one GPU renders alone.  A rehearsal of the code path, not a measurement."""
+    """bench.py's N>1 code path end to end with 2 ranks sharing this box's one GPU (strips, RGBA8 tiles, gather, un-shuffle,
+    max-over-ranks timing, counters summed over ranks), started the way the driver starts it — `python bench.py --gpus 2`
+    with WORLD_SIZE unset, so bench.py launches its ranks itself.  The tiles travel over gloo via host memory here (RCCL
+    needs one GPU per rank); rank 0 checks the gathered frame bit for bit against the frame one GPU renders alone.  A
+    rehearsal of the code path, not a measurement."""
     import json
-    import socket
     import subprocess
     import sys
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VRT_BENCH_BACKEND="gloo", VRT_BENCH_VERIFY="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--workload", "c2", "--no-cpu-baseline"]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    env = {k: val for k, val in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VRT_BENCH_BACKEND="gloo", VRT_BENCH_VERIFY="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "c2",
+           "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    W, H = int(round(1280 * 2 ** 0.5)), int(round(720 * 2 ** 0.5))
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
-    assert out["config"]["width"] == W and out["config"]["height"] == H
-    assert out["config"]["rays_per_frame"] == W * H  # config 2 has no shadow rays; every pixel rendered exactly once
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 3
+    assert out["config"]["width"] == 1280 and out["config"]["height"] == 720  # the SAME frame, split two ways
+    assert out["config"]["rays_per_frame"] == 1280 * 720  # config 2 has no shadow rays; every pixel rendered exactly once
     assert out["gathered_frame_equals_single_gpu_frame"] is True
-    assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0 and out["latency"]["ms_per_frame"] > 0
+    # a rank count that does not match --gpus is refused, not silently measured
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env2, capture_output=True,
+                         text=True, timeout=300, cwd=root)
+    assert bad.returncode != 0 and "refusing" in bad.stderr
 
 
 def test_frames_in_flight_keep_their_own_scene(oracle_lib):
@@ -590,9 +722,10 @@ def test_frames_in_flight_keep_their_own_scene(oracle_lib):
 
 
 def test_render_rows_can_be_captured_into_a_graph(renderer, oracle_lib):
-    """vrt_render_rows makes no host synchronisation and (after the first launch of a size) no allocation, so a frame
-    can be captured into a HIP graph and replayed (include/vrt.h): same pixels as the direct launch; a captured launch
-    is not event-timed (0 ms) but its counters are read back."""
+    """vrt_render_rows makes no host synchronisation and, after ONE launch of that size on the stream (include/vrt.h), no
+    allocation, so a frame can be captured into a HIP graph on that stream and replayed: same pixels as the direct launch; a
+    captured launch is not event-timed (0 ms) but its counters are read back.  The captured launch stays replayable after
+    later, larger launches on the same and on other streams (its counter buffer is retired, never freed)."""
     import torch
 
     sc = scenes.config3_torus(6, 16)
@@ -601,13 +734,14 @@ def test_render_rows_can_be_captured_into_a_graph(renderer, oracle_lib):
     renderer.SyncWithScene()
     ref, st = OracleScene(sc).render(p, threads=8)
     direct = torch.zeros((120, 200, 4), dtype=torch.float32, device="cuda:0")
-    for _ in range(4):  # every counter slot has seen this launch size: nothing left to allocate
-        renderer.render_rows(p, 0, 120, direct.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        renderer.render_rows(p, 0, 120, direct.data_ptr(), side.cuda_stream)  # the one warm-up launch the header asks for
     torch.cuda.synchronize()
     out = torch.zeros_like(direct)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        renderer.render_rows(p, 0, 120, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    with torch.cuda.graph(g, stream=side):
+        renderer.render_rows(p, 0, 120, out.data_ptr(), side.cuda_stream)
     assert float(out.abs().max()) == 0.0  # capture does not execute
     for _ in range(3):
         out.zero_()
@@ -617,6 +751,19 @@ def test_render_rows_can_be_captured_into_a_graph(renderer, oracle_lib):
     assert np.abs(out.cpu().numpy() - ref).max() <= TOL
     t = renderer.last_timing()
     assert t["kernel_ms"] == 0.0 and t["primary_steps"] == st["primary_steps"] and t["hits"] == st["hits"]
+    # larger launches on the capture stream and on five other streams (more streams than counter slots): every counter
+    # slot is grown or recycled; the graph must still replay into memory that is alive
+    big = v.default_params(640, 360, scenes.min_cell(sc), 255, shadow=True)
+    bigbuf = torch.zeros((360, 640, 4), dtype=torch.float32, device="cuda:0")
+    for stream in [side] + [torch.cuda.Stream() for _ in range(5)]:
+        with torch.cuda.stream(stream):
+            renderer.render_rows(big, 0, 360, bigbuf.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+    for _ in range(2):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, direct)
     renderer.render_rows(p, 0, 120, direct.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert renderer.last_timing()["kernel_ms"] > 0.0

@@ -29,7 +29,7 @@ def _strip_worker(rank, world, port, height, width, strip_rows, as_u8, out_path)
     import torch
     import torch.distributed as dist
 
-    import scenes
+    from volumetricraytracer_amd import workloads as scenes
     import volumetricraytracer_amd as v
     from oracle.binding import OracleScene
     from volumetricraytracer_amd.tiles import FrameGather, strip_frame_rows
@@ -62,7 +62,7 @@ def _worker(rank, world, port, height, width, out_path):
     import torch
     import torch.distributed as dist
 
-    import scenes
+    from volumetricraytracer_amd import workloads as scenes
     import volumetricraytracer_amd as v
     from oracle.binding import OracleScene
     from volumetricraytracer_amd.tiles import FrameGather
@@ -91,7 +91,7 @@ def _worker(rank, world, port, height, width, out_path):
 def test_row_tiles_gather_matches_single_rank(tmp_path, oracle_lib, world, height):
     import torch.multiprocessing as mp
 
-    import scenes
+    from volumetricraytracer_amd import workloads as scenes
     import volumetricraytracer_amd as v
     from oracle.binding import OracleScene
 
@@ -112,7 +112,7 @@ def test_interleaved_strips_gather_matches_single_rank(tmp_path, oracle_lib, wor
     un-shuffled: rank 0 holds exactly the single-rank frame (float, or the RGBA8 exchange format)."""
     import torch.multiprocessing as mp
 
-    import scenes
+    from volumetricraytracer_amd import workloads as scenes
     import volumetricraytracer_amd as v
     from oracle.binding import OracleScene
 
@@ -185,3 +185,22 @@ def test_unshuffle_puts_every_strip_where_it_belongs(world, height, strip_rows):
     got = fg.frame(0)
     assert got.shape == (height, width, 4)
     assert torch.equal(got[:, 0, 0], torch.arange(height, dtype=torch.float32))
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver calls it) must start two ranks itself: the launch
+    path without a march (--launch-check: gloo rendezvous, strip layout, gather, un-shuffle, max-over-ranks), runnable
+    without a GPU.  A rank whose WORLD_SIZE differs from --gpus is refused with a non-zero exit code."""
+    import json
+    import subprocess
+
+    env = {k: val for k, val in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    res = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--launch-check"], env=env, capture_output=True,
+                         text=True, timeout=300, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out == {**out, "launch_check": True, "n_gpus": 2, "ranks_joined": 2, "gathered_frame_ok": True}
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--launch-check"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert bad.returncode == 2 and "refusing" in bad.stderr

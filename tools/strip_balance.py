@@ -8,13 +8,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-import scenes  # noqa: E402
+from volumetricraytracer_amd import workloads as scenes  # noqa: E402
 import volumetricraytracer_amd as v  # noqa: E402
 from volumetricraytracer_amd import _abi  # noqa: E402
 from volumetricraytracer_amd.tiles import strip_layout, tile_rows  # noqa: E402

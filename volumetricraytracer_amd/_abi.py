@@ -39,7 +39,9 @@ MODE_CUBE_NOTEX_UNLIT = 7
 
 FLAG_DIAG_TIMELINE = 4
 FLAG_OUTPUT_RGBA8 = 8
-FLAG_SKIP_EMPTY = 32
+
+FORMAT_F32 = 0
+FORMAT_TEXEL16 = 1
 
 PATH_AUTO = 0
 PATH_DENSE = 1
@@ -137,6 +139,7 @@ class vrt_timing(C.Structure):
         ("primary_steps", C.c_uint64),
         ("shadow_steps", C.c_uint64),
         ("hits", C.c_uint64),
+        ("exhausted_rays", C.c_uint64),
     ]
 
 
@@ -146,6 +149,8 @@ SYMBOLS = {
     "vrt_destroy": (C.c_int, [C.c_void_p]),
     "vrt_volume_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_uint8, C.c_float, C.c_void_p, C.c_void_p]),
     "vrt_volume_upload_voxels": (C.c_int, [C.c_void_p, C.c_int, C.c_uint8, C.c_float, C.c_void_p]),
+    "vrt_set_volume_format": (C.c_int, [C.c_void_p, C.c_int]),
+    "vrt_volume_upload_texels": (C.c_int, [C.c_void_p, C.c_int, C.c_uint8, C.c_float, C.c_void_p]),
     "vrt_volume_set_material": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(vrt_material)]),
     "vrt_volume_set_metric": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float]),
     "vrt_texture_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

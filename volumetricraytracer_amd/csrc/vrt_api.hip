@@ -37,6 +37,7 @@ struct HostVolume {
     bool used = false;
     int resolution = 0, N = 0, nb = 0;
     float extent = 0.f;
+    int format = VRT_FORMAT_F32;
     float density_scale = 1.f;
     float step_max = 0.f; /* <= 0: unbounded */
     vrt_material mat = {{0.8f, 0.8f, 0.8f, 1.0f}, 0.8f, 0.0f};
@@ -51,10 +52,11 @@ struct HostTexture {
 
 struct DeviceVolume {
     float* dense = nullptr;
-    float* bricks = nullptr;
+    void* bricks = nullptr;       /* fp32 or int16 records, by the slot's format */
     uint8_t* material = nullptr;
-    uint8_t* skip = nullptr;      /* 2 x nb^3 bytes: the empty-space table and its build scratch */
-    bool skip_valid = false;      /* table built for the current metric (only when step_max > 0) */
+    uint8_t* skip = nullptr;      /* 2 x nb^3 bytes: the empty-space table (level 1) and its build scratch */
+    unsigned* nib = nullptr;      /* nb^3 words: the empty-space table, level 2 (sub-block nibbles) */
+    bool skip_valid = false;      /* tables built for the current metric (only when step_max > 0) */
     uint8_t* cube_skip = nullptr; /* 2 x nb^3 bytes: the Cube modes' distance-to-solid table and its build scratch */
 };
 
@@ -95,11 +97,17 @@ struct DeviceState {
     uint8_t* tex[VRT_MAX_TEXTURES] = {};
     float* fb = nullptr;
     size_t fb_bytes = 0;
-    /* per-wave records of the last kStatSlots launches (launch l uses slot l % kStatSlots): frames may be in
-       flight on different streams — the reference keeps 3 (DXConstants.cpp:23) — without sharing a buffer.
-       Grown on demand to the launch's block count. */
+    /* per-wave records: one counter buffer per launch STREAM (kStatSlots streams at a time, least recently used
+       slot recycled), so frames in flight on different streams — the reference keeps 3 (DXConstants.cpp:23) — never
+       share one, and launches on one stream, which run in order, reuse theirs.  Buffers only ever grow, and an
+       outgrown buffer is retired, not freed, until vrt_destroy: a launch captured into a hipGraph has its buffer's
+       address baked into the kernarg and may be replayed at any later time. */
     unsigned* d_stats[kStatSlots] = {};
     size_t stats_cap[kStatSlots] = {}; /* blocks */
+    hipStream_t stats_stream[kStatSlots] = {};
+    bool stats_bound[kStatSlots] = {};
+    uint64_t stats_used[kStatSlots] = {}; /* launch number of the last use (LRU) */
+    std::vector<unsigned*> stats_retired;
     int last_slot = 0;
     unsigned* d_diag = nullptr;  /* allocated on first use of VRT_FLAG_DIAG_TIMELINE (never in a capture) */
     int last_blocks = 0;
@@ -118,6 +126,7 @@ struct vrt_ctx {
     HostVolume vol[VRT_MAX_VOLUMES];
     HostTexture tex[VRT_MAX_TEXTURES];
     int env_size = 0;
+    int upload_format = VRT_FORMAT_F32; /* vrt_set_volume_format: device format of the following uploads */
     bool have_scene = false;
     vrt_scene scene;
     DInstance inst[VRT_MAX_INSTANCES];
@@ -326,7 +335,9 @@ void fill_dvolume(const vrt_ctx* ctx, const DeviceState& D, const HostVolume& h,
     float cell = (h.extent * 2.0f) / (float)(h.N - 1); /* RDXVoxelVolume.cpp:386 */
     out.inv_cell = 1.0f / cell;
     out.cell = cell;
-    out.density_scale = h.density_scale;
+    /* VRT_FORMAT_TEXEL16: the field is the integer +-q; its unit 0.01 (DecodeDensity, Voxel.hlsli:254-266) goes into the scale */
+    out.density_scale = h.format == VRT_FORMAT_TEXEL16 ? h.density_scale * 0.01f : h.density_scale;
+    out.format = h.format;
     out.step_max = h.step_max > 0.0f ? h.step_max : std::numeric_limits<float>::infinity();
     out.tint[0] = h.mat.tint[0];
     out.tint[1] = h.mat.tint[1];
@@ -336,21 +347,29 @@ void fill_dvolume(const vrt_ctx* ctx, const DeviceState& D, const HostVolume& h,
     float r1 = h.mat.roughness + 1.0f;
     out.k = (r1 * r1) / 8.0f; /* RDXVoxelVolume.cpp:383 */
     out.skip = (h.step_max > 0.0f && d.skip_valid) ? d.skip : nullptr;
+    out.nib = out.skip ? d.nib : nullptr;
     out.cube_skip = d.cube_skip;
 }
 
-/* (Re)builds the empty-space tables of a slot on every device for its current metric. */
+/* (Re)builds the two-level empty-space table of a slot on every device for its current metric. */
 int rebuild_skip(vrt_ctx* ctx, int slot) {
     const HostVolume& h = ctx->vol[slot];
+    const float scale = h.format == VRT_FORMAT_TEXEL16 ? h.density_scale * 0.01f : h.density_scale;
     for (auto& D : ctx->dev) {
         DeviceVolume& v = D.vol[slot];
         v.skip_valid = false;
-        if (!h.used || !(h.step_max > 0.0f) || !v.bricks) continue;
+        if (!h.used || !(h.step_max > 0.0f) || !v.dense) continue;
         HIP_TRY(hipSetDevice(D.ordinal));
         const size_t n = (size_t)h.nb * h.nb * h.nb;
         if (!v.skip) HIP_TRY(hipMalloc(&v.skip, 2 * n));
-        HIP_TRY(launch_skip_table(v.bricks, v.skip, v.skip + n, h.nb, h.density_scale, h.step_max, D.stream));
-        HIP_TRY(hipStreamSynchronize(D.stream));
+        if (!v.nib) HIP_TRY(hipMalloc(&v.nib, n * sizeof(unsigned)));
+        void* scratch = nullptr;
+        HIP_TRY(hipMalloc(&scratch, nibble_scratch_bytes(h.N)));
+        hipError_t e = launch_skip_table(v.dense, v.skip, v.skip + n, h.N, h.nb, scale, h.step_max, D.stream);
+        if (e == hipSuccess) e = launch_nibble_table(v.dense, v.nib, scratch, h.N, h.nb, scale, h.step_max, D.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(D.stream);
+        (void)hipFree(scratch);
+        HIP_TRY(e);
         v.skip_valid = true;
     }
     return VRT_OK;
@@ -373,6 +392,7 @@ int free_device_volume(DeviceState& D, int slot) {
     if (v.bricks) HIP_TRY(hipFree(v.bricks));
     if (v.material) HIP_TRY(hipFree(v.material));
     if (v.skip) HIP_TRY(hipFree(v.skip));
+    if (v.nib) HIP_TRY(hipFree(v.nib));
     if (v.cube_skip) HIP_TRY(hipFree(v.cube_skip));
     v = DeviceVolume();
     return VRT_OK;
@@ -403,6 +423,7 @@ void destroy_device(DeviceState& D) {
         if (D.vol[i].bricks) (void)hipFree(D.vol[i].bricks);
         if (D.vol[i].material) (void)hipFree(D.vol[i].material);
         if (D.vol[i].skip) (void)hipFree(D.vol[i].skip);
+        if (D.vol[i].nib) (void)hipFree(D.vol[i].nib);
         if (D.vol[i].cube_skip) (void)hipFree(D.vol[i].cube_skip);
     }
     if (D.d_vols) (void)hipFree(D.d_vols);
@@ -424,6 +445,7 @@ void destroy_device(DeviceState& D) {
     if (D.fb) (void)hipFree(D.fb);
     for (int i = 0; i < kStatSlots; i++)
         if (D.d_stats[i]) (void)hipFree(D.d_stats[i]);
+    for (unsigned* r : D.stats_retired) (void)hipFree(r);
     if (D.d_diag) (void)hipFree(D.d_diag);
     if (D.events_ok)
         for (int i = 0; i < kRing; i++) {
@@ -444,10 +466,12 @@ struct MeshSource {
 };
 
 int upload_volume(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, const float* density,
-                  const uint8_t* material, const vrt_voxel* voxels, const MeshSource* mesh = nullptr) {
+                  const uint8_t* material, const vrt_voxel* voxels, const MeshSource* mesh = nullptr, const uint8_t* texels = nullptr) {
     if (!ctx) return VRT_ERR_INVALID;
     if (!valid_slot(slot)) return VRT_ERR_SLOT;
-    if (resolution > VRT_MAX_RESOLUTION || !(extent > 0.0f) || (!density && !voxels && !mesh)) return VRT_ERR_INVALID;
+    if (resolution > VRT_MAX_RESOLUTION || !(extent > 0.0f) || (!density && !voxels && !mesh && !texels)) return VRT_ERR_INVALID;
+    const int format = texels ? VRT_FORMAT_TEXEL16 : ctx->upload_format;
+    const size_t sample_bytes = format == VRT_FORMAT_TEXEL16 ? sizeof(short) : sizeof(float);
     const int N = (1 << resolution) + 1; /* VoxelVolume.cpp:23 */
     const int nb = (N - 1 + kBrickCells - 1) / kBrickCells;
     const size_t count = (size_t)N * N * N;
@@ -458,8 +482,17 @@ int upload_volume(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, cons
         DeviceVolume& v = D.vol[slot];
         HIP_TRY(hipMalloc(&v.dense, count * sizeof(float)));
         HIP_TRY(hipMalloc(&v.material, count));
-        HIP_TRY(hipMalloc(&v.bricks, (size_t)nb * nb * nb * kBrickFloats * sizeof(float)));
-        if (mesh) {
+        HIP_TRY(hipMalloc(&v.bricks, (size_t)nb * nb * nb * kBrickFloats * sample_bytes));
+        if (texels) {
+            /* the reference's own volume texture: decode on the device (UpdateVolumeTexture's loop, inverted) */
+            void* staging = nullptr;
+            HIP_TRY(hipMalloc(&staging, count * 4));
+            hipError_t e = hipMemcpyAsync(staging, texels, count * 4, hipMemcpyHostToDevice, D.stream);
+            if (e == hipSuccess) e = launch_texels_to_field(staging, v.dense, v.material, N, D.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(D.stream);
+            (void)hipFree(staging);
+            HIP_TRY(e);
+        } else if (mesh) {
             /* device Voxelizer: background 2*extent everywhere, then the minimum over the triangles */
             void* d_frames = nullptr;
             const size_t fbytes = mesh->frames.size() * sizeof(vrt_vox::TriangleFrame);
@@ -489,10 +522,13 @@ int upload_volume(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, cons
             else
                 HIP_TRY(hipMemsetAsync(v.material, 0, count, D.stream));
         }
-        HIP_TRY(launch_retile(v.dense, v.bricks, N, nb, D.stream));
+        /* VRT_FORMAT_TEXEL16: quantise like VDXVoxelVolume::EncodeVoxel; the dense grid then holds the integer field too,
+           so that every data path and every table sees the same values */
+        if (format == VRT_FORMAT_TEXEL16 && !texels) HIP_TRY(launch_quantize_field(v.dense, count, D.stream));
+        HIP_TRY(launch_retile(v.dense, v.bricks, format, N, nb, D.stream));
         const size_t nbricks = (size_t)nb * nb * nb;
         HIP_TRY(hipMalloc(&v.cube_skip, 2 * nbricks));
-        HIP_TRY(launch_cube_table(v.bricks, v.cube_skip, v.cube_skip + nbricks, N, nb, D.stream));
+        HIP_TRY(launch_cube_table(v.dense, v.cube_skip, v.cube_skip + nbricks, N, nb, D.stream));
         HIP_TRY(hipStreamSynchronize(D.stream));
     }
     HostVolume& h = ctx->vol[slot];
@@ -502,6 +538,7 @@ int upload_volume(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, cons
     h.N = N;
     h.nb = nb;
     h.extent = extent;
+    h.format = format;
     if (!was_used) {
         h.density_scale = 1.0f;
         h.step_max = 0.0f;
@@ -574,20 +611,28 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
         return VRT_ERR_INVALID;
     if (p->mode < VRT_MODE_INTERP || p->mode > VRT_MODE_CUBE_NOTEX_UNLIT) return VRT_ERR_INVALID;
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_BRICK_LDS) return VRT_ERR_INVALID;
-    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_SKIP_EMPTY)) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
+    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8)) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
     if (!ctx->have_scene) return VRT_ERR_NOT_READY;
     return VRT_OK;
 }
 
-/* AUTO picks the fastest measured path; the LDS brick cache is wave-cooperative and currently
- * covers single-instance scenes — multi-instance scenes fall back to bricks in global memory. */
-int resolve_path(int path, bool single, int mode, int flags = 0) {
-    if (mode >= VRT_MODE_CUBE) return kPathCube; /* exact grid traversal over the bricks, whatever path was asked for */
-    if (flags & VRT_FLAG_SKIP_EMPTY) /* its own instantiations of the per-lane kernels; the LDS kernel always samples */
-        return path == VRT_PATH_DENSE ? kPathDenseSkip : kPathBrickSkip;
-    if (path == VRT_PATH_AUTO) return VRT_PATH_BRICK;
-    if (path == VRT_PATH_BRICK_LDS && !single) return VRT_PATH_BRICK;
-    return path;
+/* The internal data path of a launch.  AUTO = bricks.  Bricks come in the format of the scene's volumes: fp32, or int16
+ * when every instanced volume is VRT_FORMAT_TEXEL16; a scene that mixes the two marches the dense grids (which hold the
+ * same values in either format).  The LDS brick cache is wave-cooperative and covers single-instance fp32 scenes.  Returns
+ * a negative status for the one combination without a kernel: a Cube mode over mixed formats. */
+int resolve_path(const vrt_ctx* ctx, int path, bool single, int mode) {
+    int n16 = 0, n32 = 0;
+    for (int i = 0; i < ctx->scene.n_instances; i++)
+        (ctx->vol[ctx->scene.instances[i].volume_slot].format == VRT_FORMAT_TEXEL16 ? n16 : n32)++;
+    const bool mixed = n16 > 0 && n32 > 0, all16 = n16 > 0 && n32 == 0;
+    if (mode >= VRT_MODE_CUBE) { /* exact grid traversal over the bricks, whatever path was asked for */
+        if (mixed) return VRT_ERR_UNSUPPORTED;
+        return all16 ? kPathCube16 : kPathCube;
+    }
+    if (path == VRT_PATH_DENSE || mixed) return VRT_PATH_DENSE;
+    if (all16) return kPathBrick16;
+    if (path == VRT_PATH_BRICK_LDS && single) return VRT_PATH_BRICK_LDS;
+    return VRT_PATH_BRICK;
 }
 
 /* Rows of one launch: contiguous [row0, row0+rows), or (strip_rows > 0) n_strips interleaved strips. */
@@ -668,13 +713,29 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
     DFrame F;
     build_frame(ctx, D, p, rs, out, nullptr, F, snapshot);
     if ((long long)F.tiles_x * F.tiles_y > kMaxBlocks / 2) return VRT_ERR_INVALID;
+    const bool single = ctx->scene.n_instances == 1;
+    const int path = resolve_path(ctx, p->path, single, p->mode);
+    if (path < 0) return path;
     D.last_blocks = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
-    const int slot = (int)(ctx->launches % kStatSlots);
-    if (D.stats_cap[slot] < (size_t)D.last_blocks) { /* first launch of this size in this slot: the only allocation on this path */
-        if (D.d_stats[slot]) HIP_TRY(hipFree(D.d_stats[slot]));
-        D.d_stats[slot] = nullptr;
-        D.stats_cap[slot] = 0;
-        HIP_TRY(hipMalloc(&D.d_stats[slot], sizeof(unsigned) * kStatRecord * 4 * (size_t)D.last_blocks));
+    int slot = -1;
+    for (int i = 0; i < kStatSlots; i++)
+        if (D.stats_bound[i] && D.stats_stream[i] == stream) slot = i;
+    if (slot < 0) { /* a stream not seen lately: take the least recently used slot */
+        slot = 0;
+        for (int i = 1; i < kStatSlots; i++) {
+            const bool freer = !D.stats_bound[i] && D.stats_bound[slot];
+            const bool older = D.stats_bound[i] == D.stats_bound[slot] && D.stats_used[i] < D.stats_used[slot];
+            if (freer || older) slot = i;
+        }
+        D.stats_bound[slot] = true;
+        D.stats_stream[slot] = stream;
+    }
+    D.stats_used[slot] = ctx->launches;
+    if (D.stats_cap[slot] < (size_t)D.last_blocks) { /* first launch of this size on this stream: the only allocation on this path */
+        unsigned* grown = nullptr;
+        HIP_TRY(hipMalloc(&grown, sizeof(unsigned) * kStatRecord * 4 * (size_t)D.last_blocks));
+        if (D.d_stats[slot]) D.stats_retired.push_back(D.d_stats[slot]); /* a captured graph may still write to it */
+        D.d_stats[slot] = grown;
         D.stats_cap[slot] = (size_t)D.last_blocks;
     }
     D.last_slot = slot;
@@ -690,8 +751,7 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
     if (stream != nullptr && hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
     D.timed[ring] = cap == hipStreamCaptureStatusNone;
     if (D.timed[ring]) HIP_TRY(hipEventRecord(D.ev0[ring], stream));
-    const bool single = ctx->scene.n_instances == 1;
-    HIP_TRY(launch_march(F, resolve_path(p->path, single, p->mode, p->flags), single, stream));
+    HIP_TRY(launch_march(F, path, single, stream));
     if (D.timed[ring]) HIP_TRY(hipEventRecord(D.ev1[ring], stream));
     return VRT_OK;
 }
@@ -756,6 +816,17 @@ int vrt_volume_upload_voxels(vrt_ctx* ctx, int slot, uint8_t resolution, float e
     return upload_volume(ctx, slot, resolution, extent, nullptr, nullptr, voxels);
 }
 
+int vrt_set_volume_format(vrt_ctx* ctx, int format) {
+    if (!ctx || (format != VRT_FORMAT_F32 && format != VRT_FORMAT_TEXEL16)) return VRT_ERR_INVALID;
+    ctx->upload_format = format;
+    return VRT_OK;
+}
+
+int vrt_volume_upload_texels(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, const uint8_t* rgba8_texels) {
+    if (!ctx || !rgba8_texels) return VRT_ERR_INVALID;
+    return upload_volume(ctx, slot, resolution, extent, nullptr, nullptr, nullptr, nullptr, rgba8_texels);
+}
+
 int vrt_voxelize_mesh(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, const float* positions, size_t n_vertices,
                       const uint32_t* indices, size_t n_indices, size_t* skipped_or_null) {
     if (!ctx || (!positions && n_vertices > 0) || (!indices && n_indices > 0)) return VRT_ERR_INVALID;
@@ -799,9 +870,10 @@ int vrt_volume_download(vrt_ctx* ctx, int slot, vrt_voxel* out) {
     HIP_TRY(hipMemcpy(den.data(), v.dense, count * sizeof(float), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(mat.data(), v.material, count, hipMemcpyDeviceToHost));
     memset(out, 0, count * sizeof(vrt_voxel));
+    const bool t16 = ctx->vol[slot].format == VRT_FORMAT_TEXEL16; /* integer field +-q: decode like DecodeDensity */
     for (size_t i = 0; i < count; i++) {
         out[i].material = mat[i];
-        out[i].density = den[i];
+        out[i].density = t16 ? den[i] * 0.01f : den[i];
     }
     return VRT_OK;
 }
@@ -909,12 +981,12 @@ int vrt_env_upload(vrt_ctx* ctx, int face_size, const uint8_t* rgba8_faces) {
     for (auto& D : ctx->dev) {
         HIP_TRY(hipSetDevice(D.ordinal));
         HIP_TRY(hipDeviceSynchronize());
-        if (D.d_env) {
+        if (D.d_env && face_size != ctx->env_size) { /* same size: updated in place (captured launches keep a valid pointer) */
             HIP_TRY(hipFree(D.d_env));
             D.d_env = nullptr;
         }
         if (face_size > 0) {
-            HIP_TRY(hipMalloc(&D.d_env, bytes));
+            if (!D.d_env) HIP_TRY(hipMalloc(&D.d_env, bytes));
             HIP_TRY(hipMemcpy(D.d_env, rgba8_faces, bytes, hipMemcpyHostToDevice));
         }
     }
@@ -1155,7 +1227,7 @@ int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out) {
     if (ctx->launches == 0) return VRT_ERR_NOT_READY;
     memset(out, 0, sizeof *out);
     const int ring = (int)((ctx->launches - 1) % kRing);
-    unsigned long long tot[kStatWords] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tot[kStatWords] = {0, 0, 0, 0, 0, 0, 0};
     float kernel_ms = 0.f;
     for (int g = 0; g < ctx->last_devices; g++) {
         DeviceState& D = ctx->dev[(size_t)g];
@@ -1185,6 +1257,7 @@ int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out) {
     out->primary_steps = tot[3];
     out->shadow_steps = tot[4];
     out->hits = tot[5];
+    out->exhausted_rays = tot[6];
     return VRT_OK;
 }
 
@@ -1236,6 +1309,6 @@ const char* vrt_strerror(int status) {
     }
 }
 
-const char* vrt_version(void) { return "0.1.0 gfx950"; }
+const char* vrt_version(void) { return "0.2.0 gfx950"; }
 
 }  // extern "C"

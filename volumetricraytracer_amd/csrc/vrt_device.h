@@ -11,15 +11,17 @@ namespace vrt {
 
 constexpr int kBrickCells = 4;                 /* cells per brick edge */
 constexpr int kBrickSamples = 5;               /* samples per brick edge (cells + 1 apron) */
-constexpr int kBrickFloats = 128;              /* 125 samples padded to 512 B = 4 x 128-B lines */
-constexpr int kPathBrickSkip = 5;              /* VRT_PATH_BRICK with VRT_FLAG_SKIP_EMPTY compiled in (a run-time test in the march loop
-                                                  cost the default path 6 %) */
-constexpr int kPathDenseSkip = 6;              /* VRT_PATH_DENSE likewise */
-constexpr int kPathCube = 4;                   /* internal data path of the Cube render modes (bricks + cube_skip, exact grid traversal) */
+constexpr int kBrickFloats = 128;              /* 125 samples padded to 128 per brick record: 512 B (fp32) = four 128-B lines,
+                                                  256 B (int16, VRT_FORMAT_TEXEL16) = two */
+/* Internal data paths (template parameter of the march kernels).  1-3 are vrt_data_path's values. */
+constexpr int kPathCube = 4;                   /* Cube render modes on fp32 bricks (bricks + cube_skip, exact grid traversal) */
+constexpr int kPathBrick16 = 5;                /* VRT_PATH_BRICK on a VRT_FORMAT_TEXEL16 volume: int16 bricks */
+constexpr int kPathCube16 = 6;                 /* Cube render modes on int16 bricks */
+constexpr int kNibWindow = 16;                 /* reach, in cells, of the sub-block distance transform (nibbles cap at 15) */
 constexpr int kTile = 8;                       /* one wave = 8x8 pixels */
 constexpr int kBlockThreads = 256;             /* 4 waves = 16x16 pixels */
 constexpr int kMaxBvhNodes = 2 * 64 - 1;
-constexpr int kStatWords = 6;
+constexpr int kStatWords = 7;
 constexpr int kStatRecord = 8;                 /* words per wave record (32 B) */
 constexpr int kDiagRecord = 8;                 /* words per wave in the diagnostic timeline buffer */
 constexpr int kMaxBlocks = 1 << 20;            /* 16x16-pixel workgroups per launch (e.g. 16384 x 16384) */
@@ -38,9 +40,9 @@ inline int grid_blocks(int tiles_x, int tiles_y, int tile_map) {
 
 /* Per-volume record (VGeometryConstantBuffer analogue). */
 struct DVolume {
-    const float* dense;    /* N^3 fp32, index x*N*N + z*N + y */
-    const float* bricks;   /* nb^3 bricks x 128 floats, brick (bx,bz,by) major like the dense grid,
-                              in-brick index lx*25 + lz*5 + ly */
+    const float* dense;    /* N^3 fp32, index x*N*N + z*N + y (VRT_FORMAT_TEXEL16: the integer field +-q as floats) */
+    const void* bricks;    /* nb^3 brick records x 128 samples (fp32, or int16 for VRT_FORMAT_TEXEL16), brick (bx,bz,by)
+                              major like the dense grid, in-brick index lx*25 + lz*5 + ly */
     int32_t N;
     int32_t nb;
     float extent;
@@ -52,9 +54,12 @@ struct DVolume {
     float metallic;        /* clamped to [0,1] */
     float k;               /* (roughness+1)^2 / 8 from the unclamped roughness */
     float cell;            /* 2*extent / (N-1): the leap unit must use this very value (1/inv_cell can differ in the last bit) */
-    float pad_;
+    int32_t format;        /* vrt_volume_format of `bricks` */
     const uint8_t* skip;   /* nb^3 bytes or null: leap count max(D-1, 0), D = Chebyshev distance (bricks) to the nearest
-                              brick holding a sample closer than step_max to the surface; drives the empty-space leap */
+                              brick holding an active cell (a cell with a corner closer than step_max to the surface) */
+    const uint32_t* nib;   /* nb^3 words (with skip): per brick eight 4-bit fields, one per 2^3-cell sub-block at bit
+                              4*((lx>>1)*4 + (lz>>1)*2 + (ly>>1)): floor of the Euclidean distance, in cells, from the
+                              sub-block's cells to the nearest active cell, capped at 15.  Read where skip[] is 0 */
     /* material textures (textured render modes): R8G8B8A8, point/wrap; px null = unbound */
     const uint8_t* tex_px[3];  /* albedo, normal, rm */
     int32_t tex_w[3], tex_h[3];
@@ -149,7 +154,7 @@ struct DFrame {
     int32_t pad_;
     float* out;                /* rows x width float4 (or uint32 R8G8B8A8 when rgba8) */
     unsigned* stats;           /* one 8-word record per wave (4 per workgroup): primary_rays, shadow_rays,
-                                  bounce_rays, primary_steps, shadow_steps, hits, 0, 0 */
+                                  bounce_rays, primary_steps, shadow_steps, hits, exhausted_rays, 0 */
     unsigned* diag_buf;        /* diagnostic build only: 8 words per wave {start, end (100 MHz), fast fetches, xcc|hw_id,
                                   longest sample chain, load+lerp cycles, loop cycles, loop iterations} */
 };

@@ -3,10 +3,12 @@
  *
  * One wavefront lane per primary ray, one 64-lane wave per 8x8 pixel tile, 4 waves per
  * workgroup (16x16 pixels).  The march is a sphere-trace over the trilinear interpolant of
- * the density grid; taps come either from the dense grid or from 4^3-cell bricks
- * (5^3 samples, 512 B = four 128-B lines) so that the 8 taps of a sample share one brick.
+ * the density grid; taps come either from the dense grid or from 4^3-cell bricks (5^3 samples:
+ * 512 B of fp32 = four 128-B lines, or 256 B of int16 — the reference's own volume texel — = two)
+ * so that the 8 taps of a sample share one brick.  A two-level empty-space table (brick bytes +
+ * sub-block nibbles) lets the ray cross cells without surface without touching the bricks.
  * Normal, shadow test, shading, cube-map lookup and tone-map stay in registers.
- * Memory-bound gather work: no MFMA.
+ * Latency-bound gather work: no MFMA.
  *
  * The arithmetic contract (operation order, where FMA is used) is DESIGN.md §3; it is
  * restated independently by oracle/vrt_oracle.cpp.  This file is compiled with
@@ -60,21 +62,30 @@ typedef const float __attribute__((address_space(1))) * gfloat_p;
 typedef const unsigned __attribute__((address_space(1))) * guint_p;
 
 typedef const uint8_t __attribute__((address_space(1))) * gbyte_p;
+typedef const char __attribute__((address_space(1))) * gchar_p;
 
 struct VolRef {
-    gfloat_p p; /* dense grid or brick pool, by PATH */
-    gbyte_p skip; /* empty-space table or null */
-    gbyte_p cube; /* Cube modes: distance-to-solid table */
+    gchar_p p;      /* dense grid or brick pool, by PATH */
+    gbyte_p skip;   /* empty-space table, level 1 (brick leap counts), or null */
+    guint_p nib;    /* empty-space table, level 2 (sub-block nibbles); valid with skip */
+    gbyte_p cube;   /* Cube modes: distance-to-solid table */
     int N;
     int nb;
     float extent, inv_cell, cell, dscale, step_max;
 };
 
+/* Where the taps of an internal path come from. */
 template <int PATH>
+__device__ __host__ constexpr int data_path() {
+    return PATH == VRT_PATH_DENSE ? VRT_PATH_DENSE : (PATH == kPathBrick16 || PATH == kPathCube16) ? kPathBrick16 : VRT_PATH_BRICK;
+}
+
+template <int DP>
 __device__ __forceinline__ VolRef load_vol(const DVolume* __restrict__ v) {
     VolRef r;
-    r.p = (gfloat_p)((PATH == VRT_PATH_DENSE) ? v->dense : v->bricks);
+    r.p = (gchar_p)((DP == VRT_PATH_DENSE) ? (const void*)v->dense : v->bricks);
     r.skip = (gbyte_p)v->skip;
+    r.nib = (guint_p)v->nib;
     r.cube = (gbyte_p)v->cube_skip;
     r.N = v->N;
     r.nb = v->nb;
@@ -91,8 +102,6 @@ struct Taps {
     float y00a, y00b, y01a, y01b, y10a, y10b, y11a, y11b; /* (x,z) = 00,01,10,11; a = y, b = y+1 */
 };
 
-typedef const char __attribute__((address_space(1))) * gchar_p;
-
 /* a*b + c with 24-bit unsigned operands (full-rate v_mad_u32_u24; v_mul_lo_u32 is quarter rate). */
 __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
     unsigned r;
@@ -100,18 +109,22 @@ __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
     return r;
 }
 
-/* Index of the brick that holds cell (cx,cy,cz) — also the index into the brick tables (skip, cube_skip). */
+/* Index of the brick that holds cell (cx,cy,cz) — also the index into the brick tables (skip, nib, cube_skip). */
 __device__ __forceinline__ unsigned brick_index(const VolRef& V, int cx, int cy, int cz) {
     const unsigned nb = (unsigned)V.nb;
     return mad24(mad24((unsigned)cx >> 2, nb, (unsigned)cz >> 2), nb, (unsigned)cy >> 2);
 }
 
-/* Taps of a cell from its brick (the brick index is passed in so that the march computes it once for the
- * taps and the empty-space table). */
+/* Sample index of cell (cx,cy,cz)'s origin corner inside its brick record. */
+__device__ __forceinline__ unsigned brick_local(int cx, int cy, int cz) {
+    return ((unsigned)cx & 3u) * 25u + ((unsigned)cz & 3u) * 5u + ((unsigned)cy & 3u);
+}
+
+/* Taps of a cell from its fp32 brick (the brick index is passed in so that the march computes it once for the
+ * taps and the empty-space tables): 4 x dwordx2, one per y-pair. */
 __device__ __forceinline__ Taps fetch8_brick(const VolRef& V, unsigned brick, int cx, int cy, int cz) {
-    const unsigned local = ((unsigned)cx & 3u) * 25u + ((unsigned)cz & 3u) * 5u + ((unsigned)cy & 3u);
-    const unsigned off = ((brick << 7) + local) << 2; /* bytes */
-    const gfloat_p b = (gfloat_p)((gchar_p)V.p + off);
+    const unsigned off = ((brick << 7) + brick_local(cx, cy, cz)) << 2; /* bytes */
+    const gfloat_p b = (gfloat_p)(V.p + off);
     Taps t;
     t.y00a = b[0];
     t.y00b = b[1];
@@ -124,15 +137,40 @@ __device__ __forceinline__ Taps fetch8_brick(const VolRef& V, unsigned brick, in
     return t;
 }
 
-/* Fetch the taps of cell (cx,cy,cz).  Offsets are unsigned 32-bit byte offsets from the volume
- * base (≤ 4 GiB pools), built with 24-bit multiplies (cells < 2^10, bricks < 2^24). */
-template <int PATH>
-__device__ __forceinline__ Taps fetch8(const VolRef& V, int cx, int cy, int cz) {
+/* Taps of a cell from its int16 brick (VRT_FORMAT_TEXEL16): 4 x dword at 2-byte alignment, one per y-pair (gfx950 runs
+ * with unaligned global access enabled), each unpacked with two v_cvt_f32_i32_sdwa (sign-extended word select). */
+struct __attribute__((packed, aligned(2))) Pair16 {
+    unsigned v;
+};
+typedef const Pair16 __attribute__((address_space(1))) * gpair16_p;
+__device__ __forceinline__ float lo16f(unsigned w) { return (float)(short)(w & 0xffffu); }
+__device__ __forceinline__ float hi16f(unsigned w) { return (float)(short)(w >> 16); }
+__device__ __forceinline__ Taps fetch8_brick16(const VolRef& V, unsigned brick, int cx, int cy, int cz) {
+    const unsigned off = ((brick << 7) + brick_local(cx, cy, cz)) << 1; /* bytes */
+    const gchar_p b = V.p + off;
+    const unsigned w0 = ((gpair16_p)b)->v, w1 = ((gpair16_p)(b + 10))->v, w2 = ((gpair16_p)(b + 50))->v, w3 = ((gpair16_p)(b + 60))->v;
     Taps t;
-    if constexpr (PATH == VRT_PATH_DENSE) {
+    t.y00a = lo16f(w0);
+    t.y00b = hi16f(w0);
+    t.y01a = lo16f(w1);
+    t.y01b = hi16f(w1);
+    t.y10a = lo16f(w2);
+    t.y10b = hi16f(w2);
+    t.y11a = lo16f(w3);
+    t.y11b = hi16f(w3);
+    return t;
+}
+
+/* Fetch the taps of cell (cx,cy,cz) on data path DP (VRT_PATH_DENSE, VRT_PATH_BRICK or kPathBrick16).  Offsets are
+ * unsigned 32-bit byte offsets from the volume base (<= 4 GiB pools), built with 24-bit multiplies (cells < 2^10,
+ * bricks < 2^24). */
+template <int DP>
+__device__ __forceinline__ Taps fetch8_at(const VolRef& V, unsigned brick, int cx, int cy, int cz) {
+    if constexpr (DP == VRT_PATH_DENSE) {
+        Taps t;
         const unsigned N = (unsigned)V.N;
         const unsigned off = mad24(mad24((unsigned)cx, N, (unsigned)cz), N, (unsigned)cy);
-        const gfloat_p b = (gfloat_p)((gchar_p)V.p + ((size_t)off << 2));
+        const gfloat_p b = (gfloat_p)(V.p + ((size_t)off << 2));
         const unsigned NN = N * N;
         t.y00a = b[0];
         t.y00b = b[1];
@@ -142,10 +180,16 @@ __device__ __forceinline__ Taps fetch8(const VolRef& V, int cx, int cy, int cz) 
         t.y10b = b[NN + 1];
         t.y11a = b[NN + N];
         t.y11b = b[NN + N + 1];
+        return t;
+    } else if constexpr (DP == kPathBrick16) {
+        return fetch8_brick16(V, brick, cx, cy, cz);
     } else {
-        t = fetch8_brick(V, brick_index(V, cx, cy, cz), cx, cy, cz);
+        return fetch8_brick(V, brick, cx, cy, cz);
     }
-    return t;
+}
+template <int DP>
+__device__ __forceinline__ Taps fetch8(const VolRef& V, int cx, int cy, int cz) {
+    return fetch8_at<DP>(V, DP == VRT_PATH_DENSE ? 0u : brick_index(V, cx, cy, cz), cx, cy, cz);
 }
 
 /* Trilinear interpolant from the taps: y-lerps, z-lerps, x-lerp (each lerp is one sub + one fma, exactly as the
@@ -164,9 +208,9 @@ __device__ __forceinline__ float lerp8(const Taps& t, float fx, float fy, float 
     return lerp1(c.x, c.y, fx);
 }
 
-template <int PATH>
+template <int DP>
 __device__ __forceinline__ float trilinear(const VolRef& V, int cx, int cy, int cz, float fx, float fy, float fz) {
-    return lerp8(fetch8<PATH>(V, cx, cy, cz), fx, fy, fz);
+    return lerp8(fetch8<DP>(V, cx, cy, cz), fx, fy, fz);
 }
 
 /* Ray / box [-e,e]^3 slab test with inf-safe reciprocals (Ray.hlsli:111-134). */
@@ -211,6 +255,11 @@ __device__ __forceinline__ bool slab_box(F3 o, F3 d, const DBvhNode& n, float t_
     return !(tx < te) && !(tx < 0.0f) && !(te > t_cur);
 }
 
+/* A lane's sample counter also carries, above bit kExhaustedShift, how many of its marches ran out of budget (max_steps
+ * positions visited with the ray still inside the volume): < 2^20 samples and < 2^12 marches per lane and counter. */
+constexpr unsigned kExhaustedShift = 20;
+constexpr unsigned kExhaustedOne = 1u << kExhaustedShift;
+
 /* Diagnostic-build accumulators (wave-uniform, shader-clock cycles); unused otherwise. */
 struct DiagAcc {
     unsigned long long mem = 0;   /* address ready → interpolated value available (loads + lerps) */
@@ -234,6 +283,7 @@ struct RaySeg {
     float cmax;           /* N - 2 */
     float base_min;       /* step_min + cone_eps * t_base */
     float leap_unit;      /* one brick edge (4 cells) in ray-parameter units */
+    float cell_unit;      /* one cell edge */
 };
 
 /* Transform the ray into the instance, slab-test its volume box and derive the march constants.
@@ -256,6 +306,7 @@ __device__ __forceinline__ bool setup_ray(const DFrame& F, const DInstance* __re
     /* smallest step: one pixel-footprint radius at the total path length t_base + t */
     R.base_min = __builtin_fmaf(t_base, F.cone_eps, F.step_min);
     R.leap_unit = (4.0f * V.cell) * inv_len;
+    R.cell_unit = R.leap_unit * 0.25f;
     return true;
 }
 
@@ -279,6 +330,7 @@ __device__ __forceinline__ bool setup_shadow_ray(const DFrame& F, const DInstanc
     R.t_end = minf_(t_exit, t_cur);
     R.base_min = __builtin_fmaf(t_base, F.cone_eps, F.step_min);
     R.leap_unit = (4.0f * V.cell) * inv_len;
+    R.cell_unit = R.leap_unit * 0.25f;
     return true;
 }
 
@@ -286,13 +338,6 @@ __device__ __forceinline__ bool setup_shadow_ray(const DFrame& F, const DInstanc
 struct Cell {
     int cx, cy, cz;
     float fx, fy, fz;
-};
-/* Per-lane march state handed from the per-lane head to the LDS tail of the hybrid march. */
-struct MarchState {
-    float t, t_prev, s_prev, s_hit;
-    int i;
-    bool hit, done;
-    Cell c;
 };
 __device__ __forceinline__ Cell cell_at(const RaySeg& R, float t) {
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -313,19 +358,13 @@ __device__ __forceinline__ Cell cell_at(const RaySeg& R, float t) {
     return c;
 }
 
-/* Empty-space leap (ray-parameter units) from cell c: (D-1) brick edges when the nearest brick that
- * can hold surface is D bricks away (Chebyshev), else 0.  The byte comes from a small L2-resident
- * table and is requested together with the taps. */
-__device__ __forceinline__ float leap_at(const VolRef& V, const RaySeg& R, unsigned brick) {
-    return (float)V.skip[brick] * R.leap_unit; /* the device table holds the leap count max(D-1, 0) */
+/* Empty-space leap (ray-parameter units) of cell c from the two table words of its brick: leap count B > 0 (the
+ * nearest near brick is B+1 bricks away): B brick edges; else the cell's sub-block nibble: that many cell edges.  Both
+ * tables are small (nb^3 bytes / words) and stay in L2. */
+__device__ __forceinline__ float leap_of(const RaySeg& R, const Cell& c, unsigned B, unsigned nibw) {
+    const unsigned k = (((unsigned)c.cx >> 1) & 1u) * 4u + (((unsigned)c.cz >> 1) & 1u) * 2u + (((unsigned)c.cy >> 1) & 1u);
+    return B > 0u ? (float)B * R.leap_unit : (float)((nibw >> (4u * k)) & 15u) * R.cell_unit;
 }
-
-/* Empty-space table byte of cell c's brick and its conversion to a leap (used by the hybrid march; the
- * per-lane kernels use leap_at). */
-__device__ __forceinline__ unsigned leap_byte(const VolRef& V, const Cell& c) {
-    return (unsigned)V.skip[brick_index(V, c.cx, c.cy, c.cz)];
-}
-__device__ __forceinline__ float leap_from(const RaySeg& R, unsigned d) { return (float)d * R.leap_unit; }
 
 constexpr int kRefine = 3; /* secant samples spent on a hit that overshot into the surface */
 
@@ -403,7 +442,7 @@ __device__ __forceinline__ F3 hit_normal(const DInstance* __restrict__ I, const 
  * entered from outside, zero when the ray started inside the volume).  One step = one node visit (1 table
  * byte, + 4 B density in bricks that hold solid voxels).  Restated line by line in oracle march_cube.
  */
-template <int NORMAL>
+template <int NORMAL, bool B16>
 __device__ __forceinline__ bool march_cube(const DFrame& F, const DInstance* __restrict__ I, const DVolume* __restrict__ Vd, F3 o,
                                            F3 d, float t_cur, float& t_hit, F3& n_world, unsigned& steps) {
     const VolRef V = load_vol<VRT_PATH_BRICK>(Vd);
@@ -427,8 +466,10 @@ __device__ __forceinline__ bool march_cube(const DFrame& F, const DInstance* __r
         const int dist = (int)V.cube[brick];
         int lox, hix, loy, hiy, loz, hiz;
         if (dist == 0) {
-            const unsigned local = ((unsigned)cx & 3u) * 25u + ((unsigned)cz & 3u) * 5u + ((unsigned)cy & 3u);
-            const float den = *(gfloat_p)((gchar_p)V.p + (((brick << 7) + local) << 2));
+            const unsigned local = brick_local(cx, cy, cz);
+            float den;
+            if constexpr (B16) den = (float)*(const short __attribute__((address_space(1)))*)(V.p + (((brick << 7) + local) << 1));
+            else den = *(gfloat_p)(V.p + (((brick << 7) + local) << 2));
             if (den <= 0.0f) {
                 t_hit = t;
                 if constexpr (NORMAL != 0) {
@@ -489,7 +530,112 @@ __device__ __forceinline__ bool march_cube(const DFrame& F, const DInstance* __r
         t = maxf_(t_new, t);
         axis_in = axis;
     }
+    if (max_steps > 0 && !(t > R.t_end)) steps += kExhaustedOne;
     return false;
+}
+
+/* Per-lane march state.  The per-lane kernels run it from start to end; the hybrid (LDS) march stops it after its head
+ * and hands it to the wave-cooperative tail. */
+struct MarchState {
+    float t, t_prev, s_prev, s_hit;
+    int i;                 /* iterations so far: positions visited, sampled or skipped */
+    bool hit;
+    Cell c;
+};
+
+/*
+ * The march loop of one lane on data path DP, from state `st` until a hit, the end of the interval, or `limit`
+ * iterations.  One iteration = one position: either skipped (the two-level table shows no active cell within the
+ * leap: the ray advances, no tap is read, no sample counted) or sampled.
+ *  - table words are re-read only when the ray changes brick; a ray that was in a near brick asks for the taps of the
+ *    next brick together with its table words (it is most likely near as well): one memory round trip per new cell;
+ *  - while successive samples stay in one cell (a ray crawling along a surface takes steps of a tenth of a cell) the 8
+ *    taps stay in registers: the dependent chain of memory round trips is as long as the cells crossed, not as the
+ *    samples taken.
+ * Same positions, same values, same counters as the oracle's plain loop.
+ */
+template <int DP, bool DIAG>
+__device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, const RaySeg& R, MarchState& st, int limit, unsigned& steps,
+                                           DiagAcc* dg) {
+    float t = st.t, t_prev = st.t_prev, s_prev = st.s_prev;
+    int i = st.i;
+    Cell c = st.c;
+    const bool tables = V.skip != nullptr;
+    unsigned last_brick = 0xffffffffu, B = 1u, nibw = 0u;
+    while (i < limit && !(t > R.t_end)) {
+        unsigned long long st0 = 0, st1 = 0;
+        if constexpr (DIAG) st0 = stamp();
+        c = cell_at(R, t);
+        if constexpr (DIAG) {
+            asm volatile("" ::"v"(c.cx), "v"(c.cy), "v"(c.cz), "v"(c.fx), "v"(c.fy), "v"(c.fz));
+            st1 = stamp();
+        }
+        const unsigned brick = brick_index(V, c.cx, c.cy, c.cz);
+        Taps taps;
+        bool have_taps = false;
+        float leap = 0.0f;
+        if (tables) {
+            if (brick != last_brick) {
+                const bool spec = B == 0u; /* leaving a near brick: the next one is most likely near too */
+                B = V.skip[brick];
+                nibw = V.nib[brick];
+                if (spec) {
+                    taps = fetch8_at<DP>(V, brick, c.cx, c.cy, c.cz);
+                    have_taps = true;
+                }
+                last_brick = brick;
+            }
+            leap = leap_of(R, c, B, nibw);
+            const float thr = __builtin_fmaf(t, F.cone_eps, F.eps_hit);
+            if (leap > 0.0f && leap >= R.smax && thr + thr <= R.smax) {
+                /* no active cell within the leap: the sample could neither hit nor shorten the step (oracle: same
+                   condition, same advance) */
+                t_prev = t;
+                s_prev = R.smax;
+                t = t + __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
+                i++;
+                if constexpr (DIAG) {
+                    dg->iters++;
+                    dg->loop += stamp() - st0;
+                }
+                continue;
+            }
+        }
+        if (!have_taps) taps = fetch8_at<DP>(V, brick, c.cx, c.cy, c.cz);
+        if constexpr (DIAG) {
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(taps.y00a), "v"(taps.y00b), "v"(taps.y01a), "v"(taps.y01b), "v"(taps.y10a),
+                         "v"(taps.y10b), "v"(taps.y11a), "v"(taps.y11b));
+            const unsigned long long lat = stamp() - st1;
+            dg->mem += lat; /* address arithmetic + table words + 4 loads until the data is back */
+            dg->fetches += lat < 450 ? 1u : 0u;
+            dg->iters++;
+        }
+        for (;;) { /* samples inside this cell */
+            const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
+            steps++;
+            if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
+                st.hit = true;
+                st.s_hit = s;
+                break;
+            }
+            i++;
+            t_prev = t;
+            s_prev = __builtin_fminf(s, R.smax);
+            const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
+            t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
+            if (i >= limit || t > R.t_end) break;
+            const Cell c2 = cell_at(R, t);
+            if (c2.cx != c.cx || c2.cy != c.cy || c2.cz != c.cz) break;
+            c = c2;
+        }
+        if constexpr (DIAG) dg->loop += stamp() - st0;
+        if (st.hit) break;
+    }
+    st.t = t;
+    st.t_prev = t_prev;
+    st.s_prev = s_prev;
+    st.i = i;
+    st.c = c;
 }
 
 /*
@@ -501,11 +647,10 @@ template <int PATH, int NORMAL /* 0 none, 1 fast length, 2 exact length */, bool
 __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance* __restrict__ I,
                                                const DVolume* __restrict__ Vd, F3 o, F3 d, float t_cur, float t_base,
                                                float& t_hit, F3& n_world, unsigned& steps, DiagAcc* dg = nullptr) {
-    if constexpr (PATH == kPathCube) {
-        return march_cube<NORMAL>(F, I, Vd, o, d, t_cur, t_hit, n_world, steps);
+    if constexpr (PATH == kPathCube || PATH == kPathCube16) {
+        return march_cube<NORMAL, PATH == kPathCube16>(F, I, Vd, o, d, t_cur, t_hit, n_world, steps);
     } else {
-    constexpr bool SKIP = PATH == kPathBrickSkip || PATH == kPathDenseSkip; /* VRT_FLAG_SKIP_EMPTY */
-    constexpr int DP = PATH == kPathDenseSkip ? VRT_PATH_DENSE : (PATH == kPathBrickSkip ? VRT_PATH_BRICK : PATH); /* where the taps come from */
+    constexpr int DP = data_path<PATH>(); /* where the taps come from */
     const VolRef V = load_vol<DP>(Vd);
     RaySeg R;
     if constexpr (DIR_SHADOW) { /* d is the scene's directional light: its per-instance constants come precomputed */
@@ -513,76 +658,23 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     } else {
         if (!setup_ray(F, I, V, o, d, t_cur, t_base, R)) return false;
     }
-    float t = R.t0;
-    const int max_steps = F.max_steps;
-    bool hit = false;
-    int i = 0;
-    Cell c = {0, 0, 0, 0.0f, 0.0f, 0.0f};
-    float t_prev = t, s_prev = 0.0f, s_hit = 0.0f;
-    /* (Keeping the current cell's 8 taps in registers and skipping the loads while a ray stays in
-       the cell was measured: even the slowest rays change cell every other sample, and the extra
-       compare + branch made the frame 7 % slower.  Not done.) */
-    for (; i < max_steps; i++) {
-        if (t > R.t_end) break;
-        unsigned long long st0 = 0, st1 = 0;
-        if constexpr (DIAG) st0 = stamp();
-        c = cell_at(R, t);
-        if constexpr (DIAG) {
-            asm volatile("" ::"v"(c.cx), "v"(c.cy), "v"(c.cz), "v"(c.fx), "v"(c.fy), "v"(c.fz));
-            st1 = stamp();
-        }
-        Taps taps;
-        float leap = 0.0f;
-        const unsigned brick = brick_index(V, c.cx, c.cy, c.cz);
-        if (SKIP && V.skip != nullptr) { /* the table byte decides before the taps are asked for */
-            leap = leap_at(V, R, brick);
-            const float thr = __builtin_fmaf(t, F.cone_eps, F.eps_hit);
-            if (leap > 0.0f && leap >= R.smax && thr + thr <= R.smax) {
-                /* nothing below the step clamp in this brick or around it: the sample could neither hit nor shorten the
-                   step (oracle: same condition, same advance) */
-                t_prev = t;
-                s_prev = R.smax;
-                t = t + __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
-                continue;
-            }
-            if constexpr (DP == VRT_PATH_DENSE) taps = fetch8<DP>(V, c.cx, c.cy, c.cz);
-            else taps = fetch8_brick(V, brick, c.cx, c.cy, c.cz);
-        } else if constexpr (DP == VRT_PATH_DENSE) {
-            taps = fetch8<DP>(V, c.cx, c.cy, c.cz);
-            if (V.skip != nullptr) leap = leap_at(V, R, brick);
-        } else {
-            taps = fetch8_brick(V, brick, c.cx, c.cy, c.cz);
-            if (V.skip != nullptr) leap = leap_at(V, R, brick);
-        }
-        if constexpr (DIAG) {
-            asm volatile("s_waitcnt vmcnt(0)" ::"v"(taps.y00a), "v"(taps.y00b), "v"(taps.y01a), "v"(taps.y01b), "v"(taps.y10a),
-                         "v"(taps.y10b), "v"(taps.y11a), "v"(taps.y11b));
-            const unsigned long long lat = stamp() - st1;
-            dg->mem += lat; /* address arithmetic + 4 loads until the data is back */
-            dg->fetches += lat < 450 ? 1u : 0u;
-        }
-        const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
-        if constexpr (DIAG) {
-            asm volatile("" ::"v"(s));
-            dg->iters++;
-            dg->loop += stamp() - st0;
-        }
-        steps++;
-        if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
-            hit = true;
-            s_hit = s;
-            break;
-        }
-        t_prev = t;
-        s_prev = s;
-        const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
-        t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
+    MarchState st;
+    st.t = st.t_prev = R.t0;
+    st.s_prev = st.s_hit = 0.0f;
+    st.i = 0;
+    st.hit = false;
+    st.c = Cell{0, 0, 0, 0.0f, 0.0f, 0.0f};
+    march_lane<DP, DIAG>(F, V, R, st, F.max_steps, steps, dg);
+    if (!st.hit) {
+        if (F.max_steps > 0 && st.i >= F.max_steps && !(st.t > R.t_end)) steps += kExhaustedOne; /* budget ran out inside the volume: reported, treated as a miss */
+        return false;
     }
-    if (!hit) return false;
-    if (s_hit < 0.0f && i > 0) t = refine_hit<DP>(V, R, t_prev, s_prev, t, s_hit, c, steps);
+    float t = st.t;
+    Cell c = st.c;
+    if (st.s_hit < 0.0f && st.i > 0) t = refine_hit<DP>(V, R, st.t_prev, st.s_prev, t, st.s_hit, c, steps);
     t_hit = t;
-    if constexpr (NORMAL == 1) n_world = hit_normal<DP, false>(I, V, R, c, i);
-    if constexpr (NORMAL == 2) n_world = hit_normal<DP, true>(I, V, R, c, i);
+    if constexpr (NORMAL == 1) n_world = hit_normal<DP, false>(I, V, R, c, st.i);
+    if constexpr (NORMAL == 2) n_world = hit_normal<DP, true>(I, V, R, c, st.i);
     return true;
     }
 }
@@ -793,6 +885,9 @@ struct Counters {
 template <bool DIAG>
 __device__ __forceinline__ void write_records(const DFrame& F, int b, int wave, int lane, Counters k, const DiagAcc& dg,
                                               unsigned long long t_start) {
+    const unsigned exhausted = wave_sum((k.s_primary >> kExhaustedShift) + (k.s_shadow >> kExhaustedShift));
+    k.s_primary &= kExhaustedOne - 1u;
+    k.s_shadow &= kExhaustedOne - 1u;
     const unsigned s_primary_lane = k.s_primary, s_shadow_lane = k.s_shadow;
     k.n_primary = wave_sum(k.n_primary);
     k.n_shadow = wave_sum(k.n_shadow);
@@ -802,7 +897,7 @@ __device__ __forceinline__ void write_records(const DFrame& F, int b, int wave, 
     k.n_hits = wave_sum(k.n_hits);
     if (F.stats != nullptr && lane < 8) {
         unsigned v = lane == 0 ? k.n_primary : lane == 1 ? k.n_shadow : lane == 2 ? k.n_bounce : lane == 3 ? k.s_primary
-                   : lane == 4 ? k.s_shadow : lane == 5 ? k.n_hits : 0u;
+                   : lane == 4 ? k.s_shadow : lane == 5 ? k.n_hits : lane == 6 ? exhausted : 0u;
         F.stats[((size_t)b * 4 + wave) * kStatRecord + lane] = v;
     }
     if constexpr (DIAG) {
@@ -919,12 +1014,15 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
         int inst = 0;
         F3 n = f3(0.0f, 0.0f, 0.0f);
         F3 color;
-        if (trace_closest<PATH, SINGLE, DIAG>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, k.s_primary, &dg)) {
+        /* the normal's length is the correctly rounded one: its dot product with the light decides whether a shadow ray is cast */
+        if (trace_closest<PATH, SINGLE, DIAG, 2>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, k.s_primary, &dg)) {
             k.n_hits = 1;
             bool shadowed = false;
-            if (F.shadow && !F.unlit) {
+            const F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
+            /* A surface facing away from the light gets a contribution <= 0 from it, blocked or not, and this kernel has no
+               other term: the tone-map clamps the pixel to 0 either way, so that shadow ray is not cast (oracle: same rule) */
+            if (F.shadow && !F.unlit && dot3(n, ld) > 0.0f) {
                 k.n_shadow = 1;
-                F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
                 shadowed = trace_any<PATH, SINGLE, DIAG, true>(F, shadow_origin(F, o, d, t_hit), ld, 5000.0f, t_hit, k.s_shadow, &dg);
             }
             color = shade_hit(F, F.vols + F.inst[inst].slot, d, n, shadowed);
@@ -1082,11 +1180,15 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_full(const DFrame 
             const F3 wo = f3(-d.x, -d.y, -d.z);
             const float tb = t_base + t_hit;
             const bool shadows = F.shadow && level < kMaxDepth;
+            const bool bounce = rough < 0.3f && level <= F.max_bounces && level < kMaxDepth;
             F3 sum = f3(0.0f, 0.0f, 0.0f);
             {   /* directional light */
                 const F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
                 bool sh = false;
-                if (shadows) {
+                /* not cast where it cannot change the pixel: the surface faces away from the light (contribution <= 0
+                   blocked or not) and nothing else is added at this hit (no point / spot light, no mirror bounce) */
+                const bool lone_backfacing = F.n_point == 0 && F.n_spot == 0 && !bounce && !(dot3(n, ld) > 0.0f);
+                if (shadows && !lone_backfacing) {
                     k.n_shadow++;
                     sh = trace_any<PATH, SINGLE, false, true>(F, so, ld, 5000.0f, tb, k.s_shadow);
                 }
@@ -1129,7 +1231,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_full(const DFrame 
                     if (!sh) sum = sum + radiance(f3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo, rough, metal, kk);
                 }
             }
-            if (rough < 0.3f && level <= F.max_bounces && level < kMaxDepth) {
+            if (bounce) {
                 /* mirror bounce: continue along the reflected ray, fold this level in afterwards */
                 const float dn = dot3(d, n);
                 const F3 rd = normalize3(f3(d.x - (2.0f * dn) * n.x, d.y - (2.0f * dn) * n.y, d.z - (2.0f * dn) * n.z));
@@ -1166,37 +1268,49 @@ constexpr unsigned kTagInvalid = 0xffffffffu;
 constexpr int kHeadSteps = 12;               /* samples every ray takes from global memory before the LDS phase */
 
 /*
- * Phase 2 of the hybrid march: the rays of a wave that are still marching after kHeadSteps samples
+ * Phase 2 of the hybrid march: the rays of a wave that are still marching after kHeadSteps iterations
  * (rays that graze a surface: 100+ dependent samples, each a full L2/HBM round trip for a lone wave —
  * they set the kernel's tail) continue with their taps served from a per-wave LDS brick cache.
  * ALL 64 lanes run this loop (wave-uniform control flow); `active` marks the lanes that carry a ray.
- * Per sample a lane looks up its brick's slot (direct-mapped on the low bit of each brick
- * coordinate), reads the tag and the 8 taps together, and keeps them when the tag matches; lanes that
- * miss vote (__ballot), the first one's brick is fetched by the whole wave with one coalesced 512-B
+ * Per iteration a lane first consults the two-level empty-space table (small global tables) and advances
+ * without taps where it may; a lane that samples looks up its brick's slot (direct-mapped on the low bit of
+ * each brick coordinate), reads the tag and the 8 taps together, and keeps them when the tag matches; lanes
+ * that miss vote (__ballot), the first one's brick is fetched by the whole wave with one coalesced 512-B
  * read (64 lanes x 8 B) into its slot, and the lookup repeats.  If the slot is in use by lanes that hit
  * in this very sample, the missing lanes take their taps from global memory instead (no eviction
  * ping-pong).  LDS operations of one wave execute in order: no barrier.  The loop ends as soon as no
- * lane is active (__ballot early-out).  Same taps, same arithmetic: bit-identical results.
+ * lane is active (__ballot early-out).  Same positions, same taps, same arithmetic: bit-identical results.
  */
 __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V, const RaySeg& R, bool active, MarchState& st,
-                                               int i_start, float* __restrict__ slots, unsigned* __restrict__ tags, int lane,
-                                               unsigned& steps) {
+                                               float* __restrict__ slots, unsigned* __restrict__ tags, int lane, unsigned& steps) {
     float t = st.t, t_prev = st.t_prev, s_prev = st.s_prev;
+    int i = st.i;
     const int max_steps = F.max_steps;
     const unsigned nb = (unsigned)V.nb;
-    for (int i = i_start; i < max_steps; i++) { /* every continuing lane has taken exactly i_start samples */
-        if (active && t > R.t_end) {
-            active = false;
-            st.done = true;
-        }
+    for (;;) {
+        if (active && (i >= max_steps || t > R.t_end)) active = false;
         if (__ballot(active) == 0ull) break;
         const Cell c = cell_at(R, t);
         const unsigned bx = (unsigned)c.cx >> 2, by = (unsigned)c.cy >> 2, bz = (unsigned)c.cz >> 2;
+        float leap = 0.0f;
+        bool need = active;
+        if (V.skip != nullptr && active) {
+            const unsigned brick = (bx * nb + bz) * nb + by;
+            leap = leap_of(R, c, (unsigned)V.skip[brick], V.nib[brick]);
+            const float thr = __builtin_fmaf(t, F.cone_eps, F.eps_hit);
+            if (leap > 0.0f && leap >= R.smax && thr + thr <= R.smax) {
+                t_prev = t;
+                s_prev = R.smax;
+                t = t + __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
+                i++;
+                need = false; /* skipped: no taps this iteration */
+            }
+        }
+        const bool sample = need;
         const unsigned tag = (bx & 0xffu) | ((by & 0xffu) << 8) | ((bz & 0xffu) << 16);
         const unsigned slot = (bx & 1u) | ((by & 1u) << 1) | ((bz & 1u) << 2);
-        const unsigned local = ((unsigned)c.cx & 3u) * 25u + ((unsigned)c.cz & 3u) * 5u + ((unsigned)c.cy & 3u);
-        const float* sp = slots + (slot << 7) + local;
-        bool need = active, use_global = false;
+        const float* sp = slots + (slot << 7) + brick_local(c.cx, c.cy, c.cz);
+        bool use_global = false;
         Taps taps;
         for (;;) {
             /* speculative: tag and taps travel together, the taps are only meaningful on a tag match */
@@ -1225,7 +1339,7 @@ __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V,
                 continue;
             }
             const unsigned brick = (lbx * nb + lbz) * nb + lby;
-            const gfloat_p src = (gfloat_p)((gchar_p)V.p + (((size_t)brick << 9) + ((unsigned)lane << 3)));
+            const gfloat_p src = (gfloat_p)(V.p + (((size_t)brick << 9) + ((unsigned)lane << 3)));
             const float v0 = src[0], v1 = src[1];
             float* dst = slots + (lslot << 7) + ((unsigned)lane << 1);
             dst[0] = v0;
@@ -1237,33 +1351,37 @@ __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V,
         if (__ballot(use_global) != 0ull) {
             if (use_global) taps = fetch8<VRT_PATH_BRICK>(V, c.cx, c.cy, c.cz);
         }
-        unsigned dbyte = 0u;
-        if (V.skip != nullptr && active) dbyte = leap_byte(V, c);
         const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
-        if (active) {
+        if (sample) {
             steps++;
             st.c = c;
-            st.i = i;
             if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
                 st.hit = true;
-                st.done = true;
                 st.s_hit = s;
                 active = false;
             } else {
+                i++;
                 t_prev = t;
-                s_prev = s;
-                const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap_from(R, dbyte));
+                s_prev = __builtin_fminf(s, R.smax);
+                const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
                 t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
             }
         }
+        if (active) { /* keep the lane's state current: it is read back when the lane retires */
+            st.t = t;
+            st.t_prev = t_prev;
+            st.s_prev = s_prev;
+            st.i = i;
+        }
     }
-    st.t = t;
-    st.t_prev = t_prev;
-    st.s_prev = s_prev;
+    if (!st.hit) {
+        st.t = t;
+        st.i = i;
+    }
 }
 
 /*
- * One ray of every lane against the single instance of the scene.  Phase 1: kHeadSteps samples per
+ * One ray of every lane against the single instance of the scene.  Phase 1: kHeadSteps iterations per
  * lane with taps from the bricks in global memory (most rays finish here).  Phase 2 (only if some
  * lane is still marching): the LDS tail above.  Returns true on hit with t / cell / iteration.
  */
@@ -1274,45 +1392,16 @@ __device__ __forceinline__ bool march_hybrid(const DFrame& F, const VolRef& V, c
     st.s_prev = st.s_hit = 0.0f;
     st.i = 0;
     st.hit = false;
-    st.done = !act;
     st.c = Cell{0, 0, 0, 0.0f, 0.0f, 0.0f};
     const int max_steps = F.max_steps;
     const int head = max_steps < kHeadSteps ? max_steps : kHeadSteps;
-    if (act) {
-        float t = st.t, t_prev = st.t_prev, s_prev = 0.0f;
-        int i = 0;
-        Cell c = st.c;
-        for (; i < head; i++) {
-            if (t > R.t_end) {
-                st.done = true;
-                break;
-            }
-            c = cell_at(R, t);
-            const Taps taps = fetch8<VRT_PATH_BRICK>(V, c.cx, c.cy, c.cz);
-            unsigned dbyte = 0u;
-            if (V.skip != nullptr) dbyte = leap_byte(V, c);
-            const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
-            steps++;
-            if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
-                st.hit = true;
-                st.done = true;
-                st.s_hit = s;
-                break;
-            }
-            t_prev = t;
-            s_prev = s;
-            const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap_from(R, dbyte));
-            t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
-        }
-        st.t = t;
-        st.t_prev = t_prev;
-        st.s_prev = s_prev;
-        st.i = i;
-        st.c = c;
+    if (act) march_lane<VRT_PATH_BRICK, false>(F, V, R, st, head, steps, nullptr);
+    const bool cont = act && !st.hit && st.i < max_steps && !(st.t > R.t_end);
+    if (__ballot(cont) != 0ull) march_tail_lds(F, V, R, cont, st, slots, tags, lane, steps);
+    if (!st.hit) {
+        if (act && max_steps > 0 && st.i >= max_steps && !(st.t > R.t_end)) steps += kExhaustedOne;
+        return false;
     }
-    const bool cont = act && !st.done && st.i < max_steps;
-    if (__ballot(cont) != 0ull) march_tail_lds(F, V, R, cont, st, head, slots, tags, lane, steps);
-    if (!st.hit) return false;
     float t = st.t;
     Cell c = st.c;
     if (st.s_hit < 0.0f && st.i > 0) t = refine_hit<VRT_PATH_BRICK>(V, R, st.t_prev, st.s_prev, t, st.s_hit, c, steps);
@@ -1371,10 +1460,11 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame 
     F3 n = f3(0.0f, 0.0f, 0.0f);
     if (hit) {
         k.n_hits = 1;
-        n = hit_normal<VRT_PATH_BRICK>(I, V, R, c_hit, iter_hit);
+        n = hit_normal<VRT_PATH_BRICK, true>(I, V, R, c_hit, iter_hit);
     }
     bool shadowed = false;
-    const bool want_shadow = hit && F.shadow && !F.unlit;
+    /* no shadow ray from a surface that faces away from the light (see march_kernel) */
+    const bool want_shadow = hit && F.shadow && !F.unlit && dot3(n, f3(F.light_dir[0], F.light_dir[1], F.light_dir[2])) > 0.0f;
     if (__ballot(want_shadow) != 0ull) {
         RaySeg Rs = {};
         bool act_s = false;
@@ -1414,14 +1504,148 @@ __global__ __launch_bounds__(128) void retile_bricks_kernel(const float* __restr
     bricks[(size_t)brick * kBrickFloats + l] = v;
 }
 
-/* Empty-space table, step 1: a brick is "near" (0) when any of its 5^3 samples holds a trustworthy
- * distance below the clamp, density*density_scale < step_max; everything else starts at 255. */
-__global__ __launch_bounds__(128) void skip_seed_kernel(const float* __restrict__ bricks, uint8_t* __restrict__ table,
+/* The same for VRT_FORMAT_TEXEL16 volumes: the dense grid holds the integer field +-q as floats; bricks of 128 int16. */
+__global__ __launch_bounds__(128) void retile_bricks16_kernel(const float* __restrict__ dense, short* __restrict__ bricks, int N, int nb) {
+    const int brick = (int)blockIdx.x;
+    const int by = brick % nb;
+    const int bz = (brick / nb) % nb;
+    const int bx = brick / (nb * nb);
+    const int l = (int)threadIdx.x;
+    short v = 0;
+    if (l < 125) {
+        const int lx = l / 25, lz = (l / 5) % 5, ly = l % 5;
+        int x = bx * 4 + lx, y = by * 4 + ly, z = bz * 4 + lz;
+        x = x > N - 1 ? N - 1 : x;
+        y = y > N - 1 ? N - 1 : y;
+        z = z > N - 1 ? N - 1 : z;
+        v = (short)(int)dense[((size_t)x * N + z) * N + y]; /* |value| <= 32767, integer: exact */
+    }
+    bricks[(size_t)brick * kBrickFloats + l] = v;
+}
+
+/* VRT_FORMAT_TEXEL16: a density as the reference's volume texel keeps it — sign + 15-bit trunc(|d| * 100)
+ * (VDXVoxelVolume::EncodeVoxel, RDXVoxelVolume.cpp:399-421) — returned as the integer +-q (oracle: texel16_value). */
+__device__ __forceinline__ float texel16_value(float d) {
+    const float a = fabsf(d) * 100.0f;
+    unsigned q = 0u;
+    if (a >= 4294967040.0f) q = 0xffffffffu;
+    else if (a >= 0.0f) q = (unsigned)a; /* NaN -> 0 */
+    q &= 0x7fffu;
+    const float v = (float)q;
+    return d < 0.0f ? -v : v;
+}
+
+__global__ void quantize_field_kernel(float* __restrict__ density, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) density[i] = texel16_value(density[i]);
+}
+
+/* The reference's volume texture (N^3 RGBA8 texels, texel (x,y,z) at 4*(z*N*N + y*N + x): R = sign<<7 | q>>8, G = q & 0xff,
+ * B = A = material; UpdateVolumeTexture, RDXVoxelVolume.cpp:294-327) -> integer field +-q in the grid's own order + materials. */
+__global__ void texels_to_field_kernel(const uchar4* __restrict__ texels, float* __restrict__ density, uint8_t* __restrict__ material, int N) {
+    const size_t count = (size_t)N * N * N;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) { /* i = x*N*N + z*N + y */
+        const size_t x = i / ((size_t)N * N), z = (i / N) % N, y = i % N;
+        const uchar4 t = texels[(z * N + y) * N + x];
+        const float q = (float)((((unsigned)t.x & 0x7fu) << 8) | (unsigned)t.y);
+        density[i] = (t.x & 0x80u) ? -q : q;
+        material[i] = t.z;
+    }
+}
+
+/* Empty-space table, level 2 (oracle: build_nibble_table).  Step 1: a cell is ACTIVE when one of its 8 corners holds a
+ * trustworthy distance below the clamp. */
+__global__ void active_cells_kernel(const float* __restrict__ dense, uint8_t* __restrict__ act, int N, float density_scale, float step_max) {
+    const int C = N - 1;
+    const size_t count = (size_t)C * C * C;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) {
+        const size_t x = i / ((size_t)C * C), z = (i / C) % C, y = i % C;
+        bool a = false;
+        for (int k = 0; k < 8; k++) {
+            const size_t xx = x + (k >> 2), zz = z + ((k >> 1) & 1), yy = y + (k & 1);
+            a = a || dense[(xx * N + zz) * N + yy] * density_scale < step_max;
+        }
+        act[i] = a ? 1 : 0;
+    }
+}
+
+/* Steps 2-4: separable min-plus passes of the windowed squared Euclidean distance transform between cells (cube-to-cube
+ * distance: per axis max(|d|-1, 0)), along y (AXIS 0, from the active flags), z (AXIS 1) and x (AXIS 2).  0xffff = none
+ * within the window. */
+template <int AXIS>
+__global__ void edt_pass_kernel(const uint8_t* __restrict__ act, const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int C) {
+    const size_t count = (size_t)C * C * C;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t pitch = AXIS == 0 ? 1 : (AXIS == 1 ? (size_t)C : (size_t)C * C);
+    for (; i < count; i += stride) {
+        const int pos = AXIS == 0 ? (int)(i % C) : (AXIS == 1 ? (int)((i / C) % C) : (int)(i / ((size_t)C * C)));
+        int best = 0xffff;
+        for (int d = -kNibWindow; d <= kNibWindow; d++) {
+            const int q = pos + d;
+            if (q < 0 || q >= C) continue;
+            const size_t j = (size_t)((long long)i + (long long)d * (long long)pitch);
+            int g = (d < 0 ? -d : d);
+            g = g > 0 ? g - 1 : 0;
+            g *= g;
+            int v;
+            if constexpr (AXIS == 0) v = act[j] ? g : 0xffff;
+            else v = g + (int)in[j];
+            best = v < best ? v : best;
+        }
+        out[i] = (uint16_t)(best > 0xffff ? 0xffff : best);
+    }
+}
+
+/* Step 5: per brick the eight sub-block nibbles: min over the sub-block's cells of floor(sqrt(d2)), capped at 15. */
+__global__ __launch_bounds__(64) void nibble_kernel(const uint16_t* __restrict__ d2, unsigned* __restrict__ nib, int C, int nb) {
+    const int brick = (int)blockIdx.x;
+    const int by = brick % nb, bz = (brick / nb) % nb, bx = brick / (nb * nb);
+    const int l = (int)threadIdx.x; /* one lane per cell */
+    const int lx = l >> 4, lz = (l >> 2) & 3, ly = l & 3;
+    const int x = bx * 4 + lx, y = by * 4 + ly, z = bz * 4 + lz;
+    int r = 15;
+    if (x < C && y < C && z < C) {
+        const int v = d2[((size_t)x * C + z) * C + y];
+        r = 0;
+        while (r < 15 && (r + 1) * (r + 1) <= v) r++;
+    }
+    unsigned w = 0;
+    for (int k = 0; k < 8; k++) {
+        const bool mine = ((lx >> 1) * 4 + (lz >> 1) * 2 + (ly >> 1)) == k;
+        int m = mine ? r : 15;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int other = __shfl_xor(m, o);
+            m = other < m ? other : m;
+        }
+        w |= (unsigned)m << (4 * k);
+    }
+    if (l == 0) nib[brick] = w;
+}
+
+/* Empty-space table, level 1, step 1: a brick is "near" (0) when any of its 5^3 samples holds a trustworthy
+ * distance below the clamp, density*density_scale < step_max (equivalently: when it holds an active cell); everything
+ * else starts at 255.  Samples come from the dense grid (whatever the brick format). */
+__global__ __launch_bounds__(128) void skip_seed_kernel(const float* __restrict__ dense, uint8_t* __restrict__ table, int N, int nb,
                                                         float density_scale, float step_max) {
     const int brick = (int)blockIdx.x;
     const int l = (int)threadIdx.x;
+    const int by = brick % nb, bz = (brick / nb) % nb, bx = brick / (nb * nb);
     bool near = false;
-    if (l < 125) near = bricks[(size_t)brick * kBrickFloats + l] * density_scale < step_max;
+    if (l < 125) {
+        const int lx = l / 25, lz = (l / 5) % 5, ly = l % 5;
+        int x = bx * 4 + lx, y = by * 4 + ly, z = bz * 4 + lz;
+        x = x > N - 1 ? N - 1 : x;
+        y = y > N - 1 ? N - 1 : y;
+        z = z > N - 1 ? N - 1 : z;
+        near = dense[((size_t)x * N + z) * N + y] * density_scale < step_max;
+    }
     const unsigned long long any0 = __ballot(near);
     __shared__ int flag[2];
     if ((l & 63) == 0) flag[l >> 6] = any0 != 0ull;
@@ -1441,21 +1665,16 @@ __global__ void skip_to_leap_kernel(uint8_t* __restrict__ table, int n) {
 /* Cube modes' table, step 1: a brick is a seed (0) when one of its 4^3 cell-origin voxels is solid
  * (density <= 0); voxels beyond cell N-2 do not exist (only at resolutions < 2, where one brick covers
  * the volume). */
-__global__ __launch_bounds__(128) void cube_seed_kernel(const float* __restrict__ bricks, uint8_t* __restrict__ table, int N, int nb) {
+__global__ __launch_bounds__(64) void cube_seed_kernel(const float* __restrict__ dense, uint8_t* __restrict__ table, int N, int nb) {
     const int brick = (int)blockIdx.x;
     const int l = (int)threadIdx.x;
     const int by = brick % nb, bz = (brick / nb) % nb, bx = brick / (nb * nb);
+    const int lx = l >> 4, lz = (l >> 2) & 3, ly = l & 3;
+    const int x = bx * 4 + lx, y = by * 4 + ly, z = bz * 4 + lz;
     bool solid = false;
-    if (l < 125) {
-        const int lx = l / 25, lz = (l / 5) % 5, ly = l % 5;
-        if (lx < 4 && ly < 4 && lz < 4 && bx * 4 + lx <= N - 2 && by * 4 + ly <= N - 2 && bz * 4 + lz <= N - 2)
-            solid = bricks[(size_t)brick * kBrickFloats + l] <= 0.0f;
-    }
+    if (x <= N - 2 && y <= N - 2 && z <= N - 2) solid = dense[((size_t)x * N + z) * N + y] <= 0.0f;
     const unsigned long long any0 = __ballot(solid);
-    __shared__ int flag[2];
-    if ((l & 63) == 0) flag[l >> 6] = any0 != 0ull;
-    __syncthreads();
-    if (l == 0) table[brick] = (flag[0] || flag[1]) ? 0 : 255;
+    if (l == 0) table[brick] = any0 != 0ull ? 0 : 255;
 }
 
 /* Step k of the exact Chebyshev distance transform: bricks still at 255 that touch (3x3x3) a brick at
@@ -1551,10 +1770,6 @@ static hipError_t launch_nodiag_t(const DFrame& F, hipStream_t stream) {
     hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
     return hipGetLastError();
 }
-template <bool SINGLE>
-static hipError_t launch_cube_t(const DFrame& F, hipStream_t stream) {
-    return launch_nodiag_t<kPathCube, SINGLE>(F, stream);
-}
 
 static hipError_t launch_coop(const DFrame& F, hipStream_t stream) {
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
@@ -1574,50 +1789,82 @@ static hipError_t launch_full_t(const DFrame& F, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_march(const DFrame& F, int path, bool single, hipStream_t stream) {
-    if (path == kPathCube) {
-        if (F.full) return single ? launch_full_t<kPathCube, true>(F, stream) : launch_full_t<kPathCube, false>(F, stream);
-        return single ? launch_cube_t<true>(F, stream) : launch_cube_t<false>(F, stream);
+template <int PATH>
+static hipError_t launch_path(const DFrame& F, bool single, bool diag_build, hipStream_t stream) {
+    if (F.full) return single ? launch_full_t<PATH, true>(F, stream) : launch_full_t<PATH, false>(F, stream);
+    if constexpr (PATH == VRT_PATH_DENSE || PATH == VRT_PATH_BRICK || PATH == kPathBrick16) {
+        if (diag_build) return single ? launch_t<PATH, true>(F, stream) : launch_t<PATH, false>(F, stream);
     }
-    if (path == kPathBrickSkip || path == kPathDenseSkip) { /* VRT_FLAG_SKIP_EMPTY: no diagnostic instantiation */
-        const bool dense = path == kPathDenseSkip;
-        if (F.full) {
-            if (dense) return single ? launch_full_t<kPathDenseSkip, true>(F, stream) : launch_full_t<kPathDenseSkip, false>(F, stream);
-            return single ? launch_full_t<kPathBrickSkip, true>(F, stream) : launch_full_t<kPathBrickSkip, false>(F, stream);
-        }
-        if (dense) return single ? launch_nodiag_t<kPathDenseSkip, true>(F, stream) : launch_nodiag_t<kPathDenseSkip, false>(F, stream);
-        return single ? launch_nodiag_t<kPathBrickSkip, true>(F, stream) : launch_nodiag_t<kPathBrickSkip, false>(F, stream);
-    }
-    if (F.full) {
-        /* full closest hit: per-lane kernels on the dense grid or the bricks */
-        if (path == VRT_PATH_DENSE) return single ? launch_full_t<VRT_PATH_DENSE, true>(F, stream) : launch_full_t<VRT_PATH_DENSE, false>(F, stream);
-        return single ? launch_full_t<VRT_PATH_BRICK, true>(F, stream) : launch_full_t<VRT_PATH_BRICK, false>(F, stream);
-    }
-    if (path == VRT_PATH_BRICK_LDS && single) return launch_coop(F, stream);
-    if (path == VRT_PATH_DENSE) return single ? launch_t<VRT_PATH_DENSE, true>(F, stream) : launch_t<VRT_PATH_DENSE, false>(F, stream);
-    return single ? launch_t<VRT_PATH_BRICK, true>(F, stream) : launch_t<VRT_PATH_BRICK, false>(F, stream);
+    return single ? launch_nodiag_t<PATH, true>(F, stream) : launch_nodiag_t<PATH, false>(F, stream);
 }
 
-hipError_t launch_retile(const float* dense, float* bricks, int N, int nb, hipStream_t stream) {
-    hipLaunchKernelGGL(retile_bricks_kernel, dim3((unsigned)(nb * nb * nb)), dim3(128), 0, stream, dense, bricks, N, nb);
+hipError_t launch_march(const DFrame& F, int path, bool single, hipStream_t stream) {
+    switch (path) {
+        case kPathCube: return launch_path<kPathCube>(F, single, false, stream);
+        case kPathCube16: return launch_path<kPathCube16>(F, single, false, stream);
+        case kPathBrick16: return launch_path<kPathBrick16>(F, single, F.diag != 0, stream);
+        case VRT_PATH_DENSE: return launch_path<VRT_PATH_DENSE>(F, single, F.diag != 0, stream);
+        case VRT_PATH_BRICK_LDS:
+            if (single && !F.full) return launch_coop(F, stream);
+            return launch_path<VRT_PATH_BRICK>(F, single, F.diag != 0, stream);
+        default: return launch_path<VRT_PATH_BRICK>(F, single, F.diag != 0, stream);
+    }
+}
+
+hipError_t launch_retile(const float* dense, void* bricks, int format, int N, int nb, hipStream_t stream) {
+    if (format == VRT_FORMAT_TEXEL16)
+        hipLaunchKernelGGL(retile_bricks16_kernel, dim3((unsigned)(nb * nb * nb)), dim3(128), 0, stream, dense, static_cast<short*>(bricks), N, nb);
+    else
+        hipLaunchKernelGGL(retile_bricks_kernel, dim3((unsigned)(nb * nb * nb)), dim3(128), 0, stream, dense, static_cast<float*>(bricks), N, nb);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize_field(float* density, size_t count, hipStream_t stream) {
+    hipLaunchKernelGGL(quantize_field_kernel, dim3(2048), dim3(256), 0, stream, density, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_texels_to_field(const void* texels, float* density, uint8_t* material, int N, hipStream_t stream) {
+    hipLaunchKernelGGL(texels_to_field_kernel, dim3(2048), dim3(256), 0, stream, reinterpret_cast<const uchar4*>(texels), density, material, N);
     return hipGetLastError();
 }
 
 static hipError_t dilate_table(uint8_t* table, uint8_t* scratch, int nb, hipStream_t stream);
 
-hipError_t launch_skip_table(const float* bricks, uint8_t* table, uint8_t* scratch, int nb, float density_scale, float step_max,
+hipError_t launch_skip_table(const float* dense, uint8_t* table, uint8_t* scratch, int N, int nb, float density_scale, float step_max,
                              hipStream_t stream) {
     const int n = nb * nb * nb;
-    hipLaunchKernelGGL(skip_seed_kernel, dim3((unsigned)n), dim3(128), 0, stream, bricks, table, density_scale, step_max);
+    hipLaunchKernelGGL(skip_seed_kernel, dim3((unsigned)n), dim3(128), 0, stream, dense, table, N, nb, density_scale, step_max);
     hipError_t e = dilate_table(table, scratch, nb, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(skip_to_leap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, table, n);
     return hipGetLastError();
 }
 
-hipError_t launch_cube_table(const float* bricks, uint8_t* table, uint8_t* scratch, int N, int nb, hipStream_t stream) {
+size_t nibble_scratch_bytes(int N) {
+    const size_t C = (size_t)(N - 1);
+    return C * C * C * 5 + 64; /* active flags (1 B) + two ping-pong squared-distance grids (2 B each) per cell */
+}
+
+hipError_t launch_nibble_table(const float* dense, unsigned* nib, void* scratch, int N, int nb, float density_scale, float step_max,
+                               hipStream_t stream) {
+    const int C = N - 1;
+    const size_t cells = (size_t)C * C * C;
+    uint8_t* act = static_cast<uint8_t*>(scratch);
+    uint16_t* g = reinterpret_cast<uint16_t*>(act + ((cells + 63) & ~(size_t)63));
+    uint16_t* h = g + cells;
+    const unsigned grid = (unsigned)std::min<size_t>((cells + 255) / 256, 1u << 16);
+    hipLaunchKernelGGL(active_cells_kernel, dim3(grid), dim3(256), 0, stream, dense, act, N, density_scale, step_max);
+    hipLaunchKernelGGL((edt_pass_kernel<0>), dim3(grid), dim3(256), 0, stream, act, (const uint16_t*)nullptr, g, C);
+    hipLaunchKernelGGL((edt_pass_kernel<1>), dim3(grid), dim3(256), 0, stream, act, g, h, C);
+    hipLaunchKernelGGL((edt_pass_kernel<2>), dim3(grid), dim3(256), 0, stream, act, h, g, C);
+    hipLaunchKernelGGL(nibble_kernel, dim3((unsigned)(nb * nb * nb)), dim3(64), 0, stream, g, nib, C, nb);
+    return hipGetLastError();
+}
+
+hipError_t launch_cube_table(const float* dense, uint8_t* table, uint8_t* scratch, int N, int nb, hipStream_t stream) {
     const int n = nb * nb * nb;
-    hipLaunchKernelGGL(cube_seed_kernel, dim3((unsigned)n), dim3(128), 0, stream, bricks, table, N, nb);
+    hipLaunchKernelGGL(cube_seed_kernel, dim3((unsigned)n), dim3(64), 0, stream, dense, table, N, nb);
     return dilate_table(table, scratch, nb, stream);
 }
 

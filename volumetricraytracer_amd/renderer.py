@@ -106,9 +106,15 @@ class VHipRenderer:
         abi_scene = sc.to_abi()
         _abi.check(self._lib.vrt_scene_set(self._ctx, C.byref(abi_scene)), "vrt_scene_set")
 
-    def upload_volume(self, slot: int, vol: VVoxelVolume, as_voxels: bool = False) -> None:
+    def upload_volume(self, slot: int, vol: VVoxelVolume, as_voxels: bool = False, as_texels: bool = False) -> None:
+        """vrt_volume_upload (or _upload_voxels: VVoxel records; or _upload_texels: the reference's own RGBA8 volume
+        texture, always the 16-bit format) in the volume's device_format."""
         self._require()
-        if as_voxels:
+        _abi.check(self._lib.vrt_set_volume_format(self._ctx, int(vol.device_format)), "vrt_set_volume_format")
+        if as_texels:
+            tex = vol.reference_texels()
+            rc = self._lib.vrt_volume_upload_texels(self._ctx, slot, vol.Resolution, vol.VolumeExtends, tex.ctypes.data_as(C.c_void_p))
+        elif as_voxels:
             rec = vol.voxel_records()
             rc = self._lib.vrt_volume_upload_voxels(self._ctx, slot, vol.Resolution, vol.VolumeExtends,
                                                     rec.ctypes.data_as(C.c_void_p))
@@ -204,11 +210,14 @@ class VHipRenderer:
         _abi.check(self._lib.vrt_render_begin(self._ctx, C.byref(p), slot), "vrt_render_begin")
         return p
 
-    def render_end(self, slot: int, params: _abi.vrt_params) -> np.ndarray:
-        """vrt_render_end: wait for the frame begun on `slot` and return a copy of its pixels."""
+    def render_end(self, slot: int, params: _abi.vrt_params, copy: bool = True) -> Optional[np.ndarray]:
+        """vrt_render_end: wait for the frame begun on `slot` and return a copy of its pixels (copy=False: just wait;
+        the pixels stay in the slot's pinned host frame)."""
         self._require()
         ptr = C.c_void_p()
         _abi.check(self._lib.vrt_render_end(self._ctx, slot, C.byref(ptr)), "vrt_render_end")
+        if not copy:
+            return None
         if params.flags & _abi.FLAG_OUTPUT_RGBA8:
             buf = (C.c_uint8 * (params.width * params.height * 4)).from_address(ptr.value)
             return np.frombuffer(buf, dtype=np.uint8).reshape(params.height, params.width, 4).copy()

@@ -135,6 +135,9 @@ class VVoxelVolume:
         # safe step (<= 0: unbounded).  1 / unbounded for analytic SDFs.
         self.density_scale = 1.0
         self.step_max = 0.0
+        # how the renderer keeps the samples on the device: _abi.FORMAT_F32, or _abi.FORMAT_TEXEL16 = the reference's
+        # own 16-bit volume texel (RDXVoxelVolume.cpp:399-421)
+        self.device_format = _abi.FORMAT_F32
         self.dirty = True
 
     def GetSize(self) -> int:
@@ -150,6 +153,26 @@ class VVoxelVolume:
         """VoxelIndexToRelativePosition along one axis (VoxelVolume.cpp:139-146), fp32."""
         idx = np.arange(self.N, dtype=np.float32)
         return idx * np.float32(self.CellSize) + np.float32(-self.VolumeExtends)
+
+    def set_device_format(self, fmt: int) -> "VVoxelVolume":
+        if fmt not in (_abi.FORMAT_F32, _abi.FORMAT_TEXEL16):
+            raise ValueError("unknown device format")
+        if fmt != self.device_format:
+            self.device_format = int(fmt)
+            self.dirty = True
+        return self
+
+    def reference_texels(self) -> np.ndarray:
+        """The reference's volume texture for this volume: uint8 [N, N, N, 4] indexed [z, y, x] with
+        R = sign<<7 | q>>8, G = q & 0xff, B = A = material, q = trunc(|d| * 100) & 0x7fff
+        (VDXVoxelVolume::UpdateVolumeTexture / EncodeVoxel, Renderer/DX/Private/RDXVoxelVolume.cpp:294-327, 399-421)."""
+        d = np.asarray(self.density, dtype=np.float32)               # [x, z, y]
+        q = ((np.abs(d) * np.float32(100.0)).astype(np.int64) & 0x7FFF).astype(np.uint16)
+        tex = np.zeros((self.N, self.N, self.N, 4), dtype=np.uint8)  # [z, y, x, rgba]
+        r = ((q >> 8).astype(np.uint8) | np.where(d < 0, 0x80, 0).astype(np.uint8))
+        for ch, a in ((0, r), (1, (q & 0xFF).astype(np.uint8)), (2, self.material_id), (3, self.material_id)):
+            tex[..., ch] = np.transpose(a, (1, 2, 0))                # [x, z, y] -> [z, y, x]
+        return tex
 
     def quantize_like_reference_texels(self) -> "VVoxelVolume":
         """Rounds the densities the way the reference's GPU texture does: sign bit + 15-bit trunc(|d| * 100)

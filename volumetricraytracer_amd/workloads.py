@@ -1,5 +1,5 @@
-"""Deterministic scenes shared by the tests, smoke() and bench.py (no RNG, no files).
-They are the BASELINE.json configs at test-friendly sizes; sizes are arguments."""
+"""Deterministic workloads: the BASELINE.json configs as scenes (no RNG besides the seeded fuzz scenes, no files).
+bench.py, __graft_entry__.smoke() and the tests build their scenes here; sizes are arguments."""
 from __future__ import annotations
 
 import math
@@ -7,6 +7,10 @@ import math
 import numpy as np
 
 import volumetricraytracer_amd as v
+from volumetricraytracer_amd import _abi
+
+# Device volume format bench.py marches by default
+BENCH_VOLUME_FORMAT = _abi.FORMAT_F32
 
 
 def config2_sphere(resolution: int = 6, env: int = 64) -> v.VScene:
@@ -66,9 +70,9 @@ def voxelized_torus(resolution: int = 8, material=None) -> v.VVoxelVolume:
     return vx.convert_mesh(p, idx, be, f"torus_{resolution}", material or v.VMaterial((0.8, 0.6, 0.2, 1.0), 0.8, 0.0))
 
 
-def config3_voxelized(resolution: int = 8, env: int = 256, distance: float = 195.0) -> v.VScene:
+def config3_voxelized(resolution: int = 8, env: int = 256, distance: float = 195.0, device_format: int = _abi.FORMAT_F32) -> v.VScene:
     """BASELINE config 3: voxelized mesh at 2^resolution cells, demo light, shadow ray meaningful."""
-    vol = voxelized_torus(resolution)
+    vol = voxelized_torus(resolution).set_device_format(device_format)
     cam = v.VCamera(Position=(distance * math.cos(math.radians(35.0)), 0.0, distance * math.sin(math.radians(35.0))),
                     Rotation=tuple(v.quat_mul(v.quat_from_axis_angle(v.UP, math.pi),
                                               v.quat_from_axis_angle(v.RIGHT, math.radians(35.0)))),
