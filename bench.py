@@ -397,7 +397,7 @@ def main() -> None:
             # contract fields: ALGORITHMIC bytes (32 B per trilinear sample + 192 B per hit + the pixel store)
             # of one launch / its mean event-timed duration / the HBM peak
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_key": traffic_key(args, world, K, rgba8),
             "kernel": "march_kernel", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
             "samples_per_launch": samples,
             # physical picture: what really crosses the HBM interface, and what the kernel really waits for

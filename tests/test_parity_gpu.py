@@ -382,11 +382,13 @@ def test_config5_real_size_bands(renderer, oracle_lib):
     assert _oracle_bands(sc, p, img) <= TOL
 
 
-@pytest.mark.parametrize("resolution,max_steps", [(8, 255), (9, 255)])
-def test_no_ray_runs_out_of_budget_on_closed_surfaces(renderer, resolution, max_steps):
+@pytest.mark.parametrize("resolution", [8, 9])
+def test_no_ray_runs_out_of_budget_on_closed_surfaces(renderer, resolution):
     """A march that visits max_steps positions while still inside the volume is treated as a miss — a hole in a closed
-    surface (the reference paints it red, Raytracing.hlsl:325-334).  At the reference's budget of 255 (Raytracing.hlsl:229)
-    no ray of the 1080p frame may run out on the Voxelizer shell of the torus, at 256^3 and at 512^3 (the largest volume)."""
+    surface (the reference paints it red, Raytracing.hlsl:325-334).  With the default budget — the reference's 255
+    (Raytracing.hlsl:229) at its largest resolution 8, doubled at 9 where the cells are half the size (march_budget) — no ray
+    of the 1080p frame may run out on the Voxelizer shell of the torus, at 256^3 and at 512^3 (the largest volume)."""
+    max_steps = v.march_budget(resolution)
     from volumetricraytracer_amd import voxelizer as vx
 
     pos, _, idx = vx.torus_mesh(0.55, 0.22, 128, 64)

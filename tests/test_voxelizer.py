@@ -172,6 +172,31 @@ def test_vox_reader_is_order_agnostic_and_rejects_garbage(tmp_path):
         vx.voxelize_file(str(tmp_path / "missing.gltf"))
 
 
+def test_relative_texture_paths_resolve_against_the_vox_folder(tmp_path, monkeypatch):
+    """VMaterial::Deserialize(sourcePath, archive) (Core/Private/Material.cpp:72-100): a texture path that is not absolute
+    is relative to the folder of the .vox file, whatever the working directory; absolute paths stay.  Both readers."""
+    scene_dir = tmp_path / "assets" / "scene"
+    scene_dir.mkdir(parents=True)
+    elsewhere = tmp_path / "elsewhere"
+    elsewhere.mkdir()
+    absolute = str(tmp_path / "abs" / "rm.png")
+    mat = v.VMaterial((0.5, 0.5, 0.5, 1.0), 0.4, 0.1)
+    mat.AlbedoTexturePath, mat.NormalTexturePath, mat.RMTexturePath = "tex/albedo.png", "normal.png", absolute
+    vol = v.sphere_volume(2, 10.0, 4.0, mat)
+    path = str(scene_dir / "s.vox")
+    vox_io.save_scene(v.VScene(Objects=[v.VVoxelObject(Volume=vol)]), path)
+    monkeypatch.chdir(elsewhere)
+    want = (str(scene_dir / "tex" / "albedo.png"), str(scene_dir / "normal.png"), absolute)
+    m = vox_io.load_scene(path).volumes()[0].Material
+    assert (m.AlbedoTexturePath, m.NormalTexturePath, m.RMTexturePath) == want
+    out = str(elsewhere / "copy.vox")
+    vx.vox_rewrite(path, out)  # C++ reader -> C++ writer: the resolved paths are what the scene now holds
+    a = vox_io.read_archive(out)["V_0"]["Material"]
+    got = tuple(vox_io._read_cstring(a[k]) for k in ("AlbedoTexture", "NormalTexture", "RMTexture"))
+    assert got == want
+    assert vox_io.volume_from_archive(vox_io.read_archive(path)["V_0"]).Material.AlbedoTexturePath == "tex/albedo.png"  # no source: as stored
+
+
 def test_glb_container_gives_the_same_scene(tmp_path):
     """Binary glTF (.glb: JSON chunk + BIN chunk = buffer 0) through the same importer: the .vox is identical to the
     one from the .gltf + .bin pair."""
@@ -359,6 +384,73 @@ def test_skybox_from_face_images(tmp_path):
     os.remove(str(tmp_path / "ZM.png"))
     with pytest.raises(RuntimeError):
         vx.load_skybox_faces(str(tmp_path))
+
+
+def _dds_cube(path, faces, layout):
+    """Writes a cube-map .dds by the published layout (DDS_HEADER 124 B, DDS_PIXELFORMAT 32 B, optional DDS_HEADER_DXT10):
+    faces uint8 [6, S, S, 4] RGBA; layout: "dx10_rgba", "legacy_bgra_mips" (full mip chain per face), "legacy_rgb24"."""
+    S = faces.shape[1]
+    mips = 1
+    pf_flags, fourcc, bits, masks = 0x41, 0, 32, (0x00ff0000, 0x0000ff00, 0x000000ff, 0xff000000)
+    tail = b""
+    if layout == "dx10_rgba":
+        pf_flags, fourcc, bits, masks = 0x4, 0x30315844, 0, (0, 0, 0, 0)
+        tail = struct.pack("<5I", 28, 3, 0x4, 1, 0)  # DXGI_FORMAT_R8G8B8A8_UNORM, TEXTURE2D, TEXTURECUBE, arraySize 1
+    elif layout == "legacy_bgra_mips":
+        mips = int(np.log2(S)) + 1
+    elif layout == "legacy_rgb24":
+        pf_flags, bits, masks = 0x40, 24, (0x000000ff, 0x0000ff00, 0x00ff0000, 0)
+    hdr = struct.pack("<4s7I44x", b"DDS ", 124, 0x1 | 0x2 | 0x4 | 0x1000 | (0x20000 if mips > 1 else 0), S, S, S * 4, 0, mips)
+    hdr += struct.pack("<8I", 32, pf_flags, fourcc, bits, *masks)
+    hdr += struct.pack("<5I", 0x1008 | (0x400000 if mips > 1 else 0), 0x200 | 0xfc00, 0, 0, 0)
+    assert len(hdr) == 128
+    body = b""
+    for f in range(6):
+        img = faces[f]
+        for m in range(mips):
+            lvl = img[::1 << m, ::1 << m]
+            if layout == "dx10_rgba":
+                body += lvl.tobytes()
+            elif layout == "legacy_rgb24":
+                body += np.ascontiguousarray(lvl[..., :3]).tobytes()
+            else:
+                body += np.ascontiguousarray(lvl[..., [2, 1, 0, 3]]).tobytes()
+    open(path, "wb").write(hdr + tail + body)
+
+
+@pytest.mark.parametrize("layout", ["dx10_rgba", "legacy_bgra_mips", "legacy_rgb24"])
+def test_skybox_from_a_dds_cube_map(tmp_path, layout):
+    """The reference loads its sky box from a .dds cube map (VTextureFactory::LoadTextureCubeFromFile,
+    Renderer/Private/TextureFactory.cpp:28-67; Resources/Skybox/Skybox.dds is missing from the checkout).  Uncompressed
+    cube maps in the DX10 and the legacy header layouts, with and without a mip chain, decode to the six RGBA faces;
+    a 2D texture, a block-compressed or a truncated file is refused."""
+    rng = np.random.default_rng(4)
+    faces = rng.integers(0, 256, size=(6, 8, 8, 4), dtype=np.uint8)
+    path = str(tmp_path / "sky.dds")
+    _dds_cube(path, faces, layout)
+    cube = vx.load_skybox_faces(path)
+    want = faces.copy()
+    if layout == "legacy_rgb24":
+        want[..., 3] = 255
+    assert cube.shape == (6, 8, 8, 4) and np.array_equal(cube, want)
+    raw = bytearray(open(path, "rb").read())
+    bad = str(tmp_path / "bad.dds")
+    open(bad, "wb").write(raw[:-17])  # truncated
+    with pytest.raises(RuntimeError):
+        vx.load_skybox_faces(bad)
+    flat = bytearray(raw)
+    if layout == "dx10_rgba":
+        flat[136:140] = struct.pack("<I", 0)      # miscFlag without TEXTURECUBE
+    else:
+        flat[112:116] = struct.pack("<I", 0)      # dwCaps2 without CUBEMAP
+    open(bad, "wb").write(flat)
+    with pytest.raises(RuntimeError):
+        vx.load_skybox_faces(bad)
+    bc = bytearray(raw)
+    bc[80:88] = struct.pack("<I4s", 0x4, b"DXT1")  # block-compressed
+    open(bad, "wb").write(bc)
+    with pytest.raises(RuntimeError):
+        vx.load_skybox_faces(bad)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/VolumetricRaytracer/VolumetricRaytracer/Resources/Skybox"),

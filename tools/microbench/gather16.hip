@@ -86,7 +86,34 @@ __global__ __launch_bounds__(256) void gather32_kernel(const float* __restrict__
     out[gid] = acc;
 }
 
-int main() {
+// Calibration of the FETCH_SIZE counter for the int16 tap pattern: every cell of every brick is sampled exactly once
+// (lane = cell, 4 x dword at +0/+10/+50/+60 B), so the unique bytes are known: nbricks * 256 (250 of them touched).
+// `./gather16 calibrate` runs only this kernel (under `rocprofv3 --pmc FETCH_SIZE`) over a 512-MiB pool.
+__global__ __launch_bounds__(256) void sweep16_kernel(const char* __restrict__ bricks, size_t ncells, float* __restrict__ out) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= ncells) return;
+    const size_t b = gid >> 6;
+    const unsigned l = (unsigned)gid & 63u, lx = l >> 4, lz = (l >> 2) & 3u, ly = l & 3u;
+    const char* p = bricks + (b << 8) + ((lx * 25u + lz * 5u + ly) << 1);
+    const unsigned w0 = ((const U1*)p)->v, w1 = ((const U1*)(p + 10))->v, w2 = ((const U1*)(p + 50))->v, w3 = ((const U1*)(p + 60))->v;
+    out[gid & 0xfffff] = ((lo16(w0) + hi16(w0)) + (lo16(w1) + hi16(w1))) + ((lo16(w2) + hi16(w2)) + (lo16(w3) + hi16(w3)));
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "calibrate")) {
+        const size_t nbricks = (size_t)1 << 21;  // 512 MiB pool of 256-B bricks
+        char* bricks;
+        float* out;
+        if (hipMalloc(&bricks, nbricks * 256 + 64) != hipSuccess) return 1;
+        (void)hipMemset(bricks, 0, nbricks * 256 + 64);
+        (void)hipMalloc(&out, sizeof(float) << 20);
+        const size_t ncells = nbricks * 64;
+        for (int rep = 0; rep < 3; rep++)
+            hipLaunchKernelGGL(sweep16_kernel, dim3((unsigned)(ncells / 256)), dim3(256), 0, 0, bricks, ncells, out);
+        (void)hipDeviceSynchronize();
+        printf("sweep16_kernel: %zu bricks, %zu unique bytes read per launch\n", nbricks, nbricks * 256);
+        return 0;
+    }
     // ---- correctness of unaligned loads
     {
         const size_t n = 1 << 16;

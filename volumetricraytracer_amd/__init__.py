@@ -5,7 +5,7 @@ from . import _abi
 from .renderer import VHipRenderer, algorithmic_bytes
 from .scene import (ADD, FORWARD, IDENTITY, RIGHT, SUBTRACT, UP, VBox, VCamera, VCylinder, VDensityGenerator,
                     VLight, VMaterial, VPointLight, VScene, VSphere, VSpotLight, VVoxelObject, VVoxelVolume,
-                    csg_volume, default_params, demo_light, look_minus_x_camera, procedural_skybox,
+                    csg_volume, default_params, demo_light, march_budget, look_minus_x_camera, procedural_skybox,
                     quat_from_axis_angle, quat_from_euler_deg, quat_inverse, quat_mul, quat_rotate, sphere_volume,
                     torus_volume)
 

@@ -1,5 +1,7 @@
 #include "HipRenderer.h"
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -145,6 +147,67 @@ VObjectPtr<VTextureCube> VTextureCube::LoadFromFaceDirectory(const std::string& 
     return std::make_shared<VTextureCube>(size, std::move(all));
 }
 
+VObjectPtr<VTextureCube> VTextureCube::LoadFromDDSFile(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return nullptr;
+    std::vector<uint8_t> file;
+    uint8_t chunk[1 << 16];
+    size_t n;
+    while ((n = fread(chunk, 1, sizeof chunk, f)) > 0) file.insert(file.end(), chunk, chunk + n);
+    fclose(f);
+    auto u32 = [&](size_t off) -> uint32_t {
+        return off + 4 <= file.size() ? (uint32_t)file[off] | (uint32_t)file[off + 1] << 8 | (uint32_t)file[off + 2] << 16 | (uint32_t)file[off + 3] << 24 : 0u;
+    };
+    if (file.size() < 128 || u32(0) != 0x20534444u /* "DDS " */ || u32(4) != 124 || u32(76) != 32) return nullptr;
+    const uint32_t height = u32(12), width = u32(16);
+    uint32_t mips = u32(28);
+    const uint32_t pf_flags = u32(80), fourcc = u32(84), bits = u32(88), rmask = u32(92), gmask = u32(96), bmask = u32(100), amask = u32(104);
+    const uint32_t caps2 = u32(112);
+    if (mips == 0) mips = 1;
+    size_t data = 128;
+    int bpp = 0;          /* bytes per pixel in the file */
+    int ri = 0, gi = 1, bi = 2, ai = 3; /* byte index of each channel; ai < 0: opaque */
+    bool cube = false;
+    if ((pf_flags & 0x4u) && fourcc == 0x30315844u /* "DX10" */) {
+        if (file.size() < 148) return nullptr;
+        const uint32_t dxgi = u32(128), dim = u32(132), misc = u32(136);
+        data = 148;
+        cube = dim == 3 /* TEXTURE2D */ && (misc & 0x4u) /* TEXTURECUBE */;
+        bpp = 4;
+        if (dxgi == 28 || dxgi == 29 || dxgi == 27) { /* R8G8B8A8 (typeless, unorm, srgb) */
+        } else if (dxgi == 87 || dxgi == 91 || dxgi == 90) { ri = 2; bi = 0; /* B8G8R8A8 */
+        } else if (dxgi == 88 || dxgi == 93 || dxgi == 92) { ri = 2; bi = 0; ai = -1; /* B8G8R8X8 */
+        } else return nullptr;
+    } else if (pf_flags & 0x40u /* DDPF_RGB */) {
+        cube = (caps2 & 0x200u) && (caps2 & 0xfc00u) == 0xfc00u; /* DDSCAPS2_CUBEMAP with all six faces */
+        auto byte_of = [](uint32_t m) { return m == 0xffu ? 0 : m == 0xff00u ? 1 : m == 0xff0000u ? 2 : m == 0xff000000u ? 3 : -1; };
+        ri = byte_of(rmask); gi = byte_of(gmask); bi = byte_of(bmask);
+        ai = (pf_flags & 0x1u /* DDPF_ALPHAPIXELS */) ? byte_of(amask) : -1;
+        if (bits == 32) bpp = 4;
+        else if (bits == 24) { bpp = 3; ai = -1; }
+        else return nullptr;
+        if (ri < 0 || gi < 0 || bi < 0 || ri >= bpp || gi >= bpp || bi >= bpp) return nullptr;
+    } else {
+        return nullptr; /* block-compressed or exotic: not supported */
+    }
+    if (!cube || width == 0 || width != height || width > 16384) return nullptr;
+    size_t face_bytes = 0; /* all mip levels of one face */
+    for (uint32_t m = 0; m < mips; m++) face_bytes += (size_t)std::max(1u, width >> m) * std::max(1u, height >> m) * (size_t)bpp;
+    if (file.size() < data + 6 * face_bytes) return nullptr; /* truncated */
+    std::vector<uint8_t> rgba((size_t)6 * width * height * 4);
+    for (int face = 0; face < 6; face++) {
+        const uint8_t* src = file.data() + data + (size_t)face * face_bytes;
+        uint8_t* dst = rgba.data() + (size_t)face * width * height * 4;
+        for (size_t i = 0; i < (size_t)width * height; i++) {
+            dst[i * 4 + 0] = src[i * bpp + ri];
+            dst[i * 4 + 1] = src[i * bpp + gi];
+            dst[i * 4 + 2] = src[i * bpp + bi];
+            dst[i * 4 + 3] = ai >= 0 ? src[i * bpp + ai] : 255;
+        }
+    }
+    return std::make_shared<VTextureCube>((size_t)width, std::move(rgba));
+}
+
 VObjectPtr<VTexture2D> VTexture2D::LoadFromFile(const std::string& path) {
     if (VObjectPtr<VTexture2D> t = LoadPNG(path)) return t;
     return LoadPPM(path);
@@ -265,9 +328,14 @@ bool VHipRenderer::SyncWithScene(Scene::VScene& scene) {
     }
     if (Uploaded.size() < volumes.size()) Uploaded.resize(volumes.size(), nullptr);
     MinCell = 0.f;
+    MaxResolution = 0;
+    if (!ok(vrt_set_volume_format(Ctx, VolumeFormat), "vrt_set_volume_format")) return false;
+    const bool reformat = UploadedFormat != VolumeFormat; /* format switched: every volume is uploaded again */
+    UploadedFormat = VolumeFormat;
     for (size_t slot = 0; slot < volumes.size(); slot++) {
         const Voxel::VVoxelVolume& v = *volumes[slot];
-        if (Uploaded[slot] != &v || v.IsDirty()) {
+        MaxResolution = std::max(MaxResolution, (int)v.GetResolution());
+        if (Uploaded[slot] != &v || v.IsDirty() || reformat) {
             static_assert(sizeof(Voxel::VVoxel) == sizeof(vrt_voxel), "VVoxel must match the wire record");
             if (!ok(vrt_volume_upload_voxels(Ctx, (int)slot, v.GetResolution(), v.GetVolumeExtends(),
                                              reinterpret_cast<const vrt_voxel*>(v.GetVoxels().data())), "vrt_volume_upload_voxels"))
@@ -365,7 +433,7 @@ void VHipRenderer::Render() {
     memset(&p, 0, sizeof p);
     p.width = (int)Width;
     p.height = (int)Height;
-    p.max_steps = MaxSteps;
+    p.max_steps = MaxSteps << std::max(0, MaxResolution - 8);
     p.shadow = Shadows ? 1 : 0;
     p.mode = (int)RenderMode;
     p.path = DataPath;

@@ -50,7 +50,11 @@ public:
     unsigned GetHeight() const { return Height; }
     bool GetLastTiming(vrt_timing& out) const;
     /* march contract knobs; defaults follow the smallest cell of the scene */
-    int MaxSteps = 255;       /* Raytracing.hlsl:229 */
+    int MaxSteps = 255;       /* Raytracing.hlsl:229: the budget at the reference's largest resolution, 8; doubled per
+                                 resolution step beyond it (cells half the size need twice the positions) */
+    /* Device format of the volumes: VRT_FORMAT_F32, or VRT_FORMAT_TEXEL16 = the reference's own 16-bit volume texel
+       (VDXVoxelVolume::EncodeVoxel, RDXVoxelVolume.cpp:399-421): the march then sees exactly the DXR backend's field */
+    int VolumeFormat = VRT_FORMAT_F32;
     bool Shadows = true;      /* the reference always casts the directional shadow ray */
     int MaxBounces = 2;       /* MAX_RAY_RECURSION_DEPTH 3 = primary + 2 mirror bounces (RaytracingHlsl.h:32) */
     int DataPath = VRT_PATH_AUTO;
@@ -78,6 +82,8 @@ private:
     std::map<const VTexture2D*, int> TextureIds;
     int ResolveTexture(const std::string& path);
     float MinCell = 1.f;
+    int MaxResolution = 0;
+    int UploadedFormat = -1;
     void Collect(int slot);
     unsigned long long FrameIndex = 0;
     bool SlotBusy[VRT_FRAMES_IN_FLIGHT] = {};

@@ -34,6 +34,11 @@ public:
        reference's Resources/Skybox/ folder, the source of its Skybox.dds) in D3D cube-face order +X,-X,+Y,-Y,+Z,-Z;
        nullptr when a face is missing, undecodable, not square or of another size. */
     static std::shared_ptr<VTextureCube> LoadFromFaceDirectory(const std::string& dir);
+    /* A cube map from a .dds file — what VTextureFactory::LoadTextureCubeFromFile reads (Renderer/Private/
+       TextureFactory.cpp:28-67; the reference's Resources/Skybox/Skybox.dds): uncompressed 32-bit RGBA / BGRA / BGRX or
+       24-bit RGB, legacy or DX10 header, six faces, top mip level only.  nullptr for anything else (not a cube map,
+       block-compressed, truncated, faces not square). */
+    static std::shared_ptr<VTextureCube> LoadFromDDSFile(const std::string& path);
 
 private:
     size_t Width, Height;

@@ -1,5 +1,6 @@
 #include "HostSerialization.h"
 
+#include <filesystem>
 #include <fstream>
 #include <stdexcept>
 
@@ -102,14 +103,19 @@ std::shared_ptr<VSerializationArchive> VSerializationManager::Serialize(const VM
     return a;
 }
 
-void VSerializationManager::Deserialize(const VSerializationArchive& a, VMaterial& m) {
+/* VMaterial::Deserialize(sourcePath, archive), Core/Private/Material.cpp:72-100: texture paths that are not absolute are
+   relative to the folder of the .vox file they came from. */
+void VSerializationManager::Deserialize(const VSerializationArchive& a, VMaterial& m, const std::string& sourcePath) {
     m.AlbedoColor = a.At("Color").To<VColor>();
     m.Roughness = a.At("Roughness").To<float>();
-    /* the reference's reader stops here (Material.cpp:66-70); the remaining properties are read when present */
+    /* files written before these properties existed do not carry them: read when present */
     if (a.Has("Metallic")) m.Metallic = a.At("Metallic").To<float>();
     if (a.Has("TextureScale")) m.TextureScale = a.At("TextureScale").To<VVector2D>();
+    const std::filesystem::path folder = sourcePath.empty() ? std::filesystem::path() : std::filesystem::path(sourcePath).parent_path();
     auto str = [&](const char* k, std::string& out) {
-        if (a.Has(k) && !a.At(k).Buffer.empty()) out.assign(a.At(k).Buffer.data(), strnlen(a.At(k).Buffer.data(), a.At(k).Buffer.size()));
+        if (!a.Has(k) || a.At(k).Buffer.empty()) return;
+        out.assign(a.At(k).Buffer.data(), strnlen(a.At(k).Buffer.data(), a.At(k).Buffer.size()));
+        if (!out.empty() && !folder.empty() && !std::filesystem::path(out).is_absolute()) out = (folder / out).string();
     };
     str("AlbedoTexture", m.AlbedoTexturePath);
     str("NormalTexture", m.NormalTexturePath);
@@ -135,13 +141,13 @@ std::shared_ptr<VSerializationArchive> VSerializationManager::Serialize(const Vo
     return a;
 }
 
-void VSerializationManager::Deserialize(const VSerializationArchive& a, Voxel::VVoxelVolume& v) {
+void VSerializationManager::Deserialize(const VSerializationArchive& a, Voxel::VVoxelVolume& v, const std::string& sourcePath) {
     const uint8_t res = a.At("Resolution").To<uint8_t>();
     const float ext = a.At("Extends").To<float>();
     if (res > 10) throw std::runtime_error("volume resolution out of range");
     v.Reset(res, ext);
     VMaterial m;
-    Deserialize(a.At("Material"), m);
+    Deserialize(a.At("Material"), m, sourcePath);
     v.SetMaterial(m);
     if (a.Buffer.size() < v.GetVoxelCount() * sizeof(Voxel::VVoxel)) throw std::runtime_error("volume buffer too small");
     auto& vox = v.GetVoxels();
@@ -200,7 +206,7 @@ std::shared_ptr<VSerializationArchive> VSerializationManager::Serialize(const Sc
     return a;
 }
 
-void VSerializationManager::Deserialize(const VSerializationArchive& a, Scene::VScene& scene) {
+void VSerializationManager::Deserialize(const VSerializationArchive& a, Scene::VScene& scene, const std::string& sourcePath) {
     const uint64_t volumesCount = a.At("VCount").To<uint64_t>();
     const uint64_t objectsCount = a.At("OCount").To<uint64_t>();
     const uint64_t dirCount = a.Has("LDCount") ? a.At("LDCount").To<uint64_t>() : 0;
@@ -210,7 +216,7 @@ void VSerializationManager::Deserialize(const VSerializationArchive& a, Scene::V
     std::vector<VObjectPtr<Voxel::VVoxelVolume>> volumes;
     for (uint64_t i = 0; i < volumesCount; i++) {
         auto v = std::make_shared<Voxel::VVoxelVolume>(1, 1.f);
-        Deserialize(a.At(idx("V_", i)), *v);
+        Deserialize(a.At(idx("V_", i)), *v, sourcePath);
         volumes.push_back(v);
     }
     for (uint64_t i = 0; i < objectsCount; i++) {
@@ -251,7 +257,7 @@ VObjectPtr<Scene::VScene> VSerializationManager::LoadSceneFromFile(const std::st
     auto a = ReadArchive(filePath);
     if (!a) return nullptr;
     auto scene = std::make_shared<Scene::VScene>();
-    Deserialize(*a, *scene);
+    Deserialize(*a, *scene, filePath);
     return scene;
 }
 

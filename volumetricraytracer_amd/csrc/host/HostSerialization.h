@@ -60,9 +60,11 @@ public:
     static std::shared_ptr<VSerializationArchive> Serialize(const Scene::VScene& scene);
     static std::shared_ptr<VSerializationArchive> Serialize(const Voxel::VVoxelVolume& volume);
     static std::shared_ptr<VSerializationArchive> Serialize(const VMaterial& material);
-    static void Deserialize(const VSerializationArchive& a, Voxel::VVoxelVolume& volume);
-    static void Deserialize(const VSerializationArchive& a, VMaterial& material);
-    static void Deserialize(const VSerializationArchive& a, Scene::VScene& scene);
+    /* sourcePath: the .vox file the archive was read from; material texture paths that are not absolute are resolved
+       against its folder (VMaterial::Deserialize, Core/Private/Material.cpp:72-100).  Empty: paths stay as stored. */
+    static void Deserialize(const VSerializationArchive& a, Voxel::VVoxelVolume& volume, const std::string& sourcePath = std::string());
+    static void Deserialize(const VSerializationArchive& a, VMaterial& material, const std::string& sourcePath = std::string());
+    static void Deserialize(const VSerializationArchive& a, Scene::VScene& scene, const std::string& sourcePath = std::string());
 };
 
 }  // namespace VolumeRaytracer

@@ -7,7 +7,7 @@
  * exactly like VEngine::EngineLoop does (Engine/Private/Engine.cpp:201-232):
  * tick → Renderer->Render() → post-render.  Writes the last frame as a PPM.
  *
- *   vrt_demo [--frames N] [--size WxH] [--scene file.vox] [--out frame.ppm] [--mode 0..7 (EVRenderMode)] [--in-flight 1..3] [--skybox dir-with-XP..ZM.png]
+ *   vrt_demo [--frames N] [--size WxH] [--scene file.vox] [--out frame.ppm] [--mode 0..7 (EVRenderMode)] [--in-flight 1..3] [--skybox dir-with-XP..ZM.png | cube.dds]
  */
 #include <chrono>
 #include <cmath>
@@ -95,7 +95,8 @@ int main(int argc, char** argv) {
         light->IlluminationStrength = 6.f;
         scene->SetActiveDirectionalLight(light);
     }
-    VObjectPtr<VTextureCube> sky = skyboxDir.empty() ? nullptr : VTextureCube::LoadFromFaceDirectory(skyboxDir);
+    const bool skyIsDDS = skyboxDir.size() > 4 && skyboxDir.compare(skyboxDir.size() - 4, 4, ".dds") == 0; /* the reference's Skybox.dds */
+    VObjectPtr<VTextureCube> sky = skyboxDir.empty() ? nullptr : (skyIsDDS ? VTextureCube::LoadFromDDSFile(skyboxDir) : VTextureCube::LoadFromFaceDirectory(skyboxDir));
     if (!skyboxDir.empty() && !sky) fprintf(stderr, "cannot load a sky box from %s; using the procedural one\n", skyboxDir.c_str());
     scene->SetEnvironmentTexture(sky ? sky : ProceduralSky(256));
     scene->SetActiveSceneCamera(camera);

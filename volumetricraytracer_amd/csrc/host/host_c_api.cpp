@@ -122,12 +122,15 @@ int vrh_texture_load(const char* path, int* width, int* height, uint8_t* out, si
     return 0;
 }
 
-/* Sky box from a folder of six face images (XP/XM/YP/YM/ZP/ZM.png).  Writes the face size; copies 6*size*size*4
-   RGBA8 bytes (+X,-X,+Y,-Y,+Z,-Z) when out is non-null and cap suffices.  0 / -1. */
+/* Sky box from a .dds cube map (VTextureFactory::LoadTextureCubeFromFile) or from a folder of six face images
+   (XP/XM/YP/YM/ZP/ZM.png).  Writes the face size; copies 6*size*size*4 RGBA8 bytes (+X,-X,+Y,-Y,+Z,-Z) when out is
+   non-null and cap suffices.  0 / -1. */
 int vrh_cubemap_load(const char* dir, int* face_size, uint8_t* out, size_t cap) {
-    VObjectPtr<VTextureCube> t = VTextureCube::LoadFromFaceDirectory(dir ? dir : "");
+    const std::string where = dir ? dir : "";
+    const bool dds = where.size() > 4 && (where.compare(where.size() - 4, 4, ".dds") == 0 || where.compare(where.size() - 4, 4, ".DDS") == 0);
+    VObjectPtr<VTextureCube> t = dds ? VTextureCube::LoadFromDDSFile(where) : VTextureCube::LoadFromFaceDirectory(where);
     if (!t) {
-        g_error = std::string("cannot load six equal square faces from ") + (dir ? dir : "(null)");
+        g_error = (dds ? std::string("cannot read an uncompressed cube map from ") : std::string("cannot load six equal square faces from ")) + where;
         return -1;
     }
     if (face_size) *face_size = (int)t->GetWidth();

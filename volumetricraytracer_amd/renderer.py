@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from . import _abi
-from .scene import VScene, VVoxelVolume, default_params
+from .scene import VScene, VVoxelVolume, default_params, march_budget
 
 
 class VHipRenderer:
@@ -180,7 +180,8 @@ class VHipRenderer:
             p = _abi.vrt_params.from_buffer_copy(self.params_override)
         else:
             cell = min((v.GetCellSize() for v in self._scene.volumes()), default=1.0) if self._scene else 1.0
-            p = default_params(self.Width, self.Height, cell, max_steps=self.MaxSteps, shadow=self.Shadows)
+            res = max((v.Resolution for v in self._scene.volumes()), default=0) if self._scene else 0
+            p = default_params(self.Width, self.Height, cell, max_steps=march_budget(res, self.MaxSteps), shadow=self.Shadows)
             p.max_bounces = self.MaxBounces
         p.width, p.height = self.Width, self.Height
         p.mode = self.RenderMode

@@ -488,6 +488,12 @@ def procedural_skybox(face_size: int = 256) -> np.ndarray:
     return out
 
 
+def march_budget(resolution: int, base: int = 255) -> int:
+    """Positions a ray may visit per instance: the reference's 255 (Raytracing.hlsl:229) up to its largest resolution, 8;
+    doubled per resolution step beyond it (cells half the size need twice the positions for the same path)."""
+    return int(base) << max(0, int(resolution) - 8)
+
+
 def default_params(width: int, height: int, cell: float, max_steps: int = 128, shadow: bool = False,
                    mode: int = _abi.MODE_INTERP_NOTEX, path: int = _abi.PATH_AUTO, fov_deg: float = 60.0,
                    cone: bool = True) -> _abi.vrt_params:

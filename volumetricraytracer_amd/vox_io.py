@@ -9,6 +9,7 @@ Scene/Private/VoxelObject.cpp:37-71, Light.cpp:17-57, PointLight.cpp:17-33, Spot
 """
 from __future__ import annotations
 
+import os
 import struct
 from typing import BinaryIO, Dict, Tuple
 
@@ -110,7 +111,9 @@ def volume_archive(v: VVoxelVolume) -> Archive:
     return a
 
 
-def volume_from_archive(a: Archive) -> VVoxelVolume:
+def volume_from_archive(a: Archive, source_path: str = "") -> VVoxelVolume:
+    """source_path: the .vox file the archive came from — material texture paths that are not absolute are resolved against
+    its folder (VMaterial::Deserialize, Core/Private/Material.cpp:72-100); empty: paths stay as stored."""
     res = a["Resolution"].unpack("<B")
     ext = a["Extends"].unpack("<f")
     v = VVoxelVolume(res, ext)
@@ -124,7 +127,10 @@ def volume_from_archive(a: Archive) -> VVoxelVolume:
         v.Material.TextureScale = tuple(m["TextureScale"].unpack("<2f"))
     for key, attr in (("AlbedoTexture", "AlbedoTexturePath"), ("NormalTexture", "NormalTexturePath"), ("RMTexture", "RMTexturePath")):
         if key in m:
-            setattr(v.Material, attr, _read_cstring(m[key]))
+            path = _read_cstring(m[key])
+            if path and source_path and not os.path.isabs(path):
+                path = os.path.join(os.path.dirname(os.path.abspath(source_path)), path)
+            setattr(v.Material, attr, path)
     return v
 
 
@@ -178,7 +184,7 @@ def save_scene(scene: VScene, path: str) -> None:
 
 def load_scene(path: str) -> VScene:
     root = read_archive(path)
-    vols = [volume_from_archive(root[f"V_{i}"]) for i in range(root["VCount"].unpack("<Q"))]
+    vols = [volume_from_archive(root[f"V_{i}"], path) for i in range(root["VCount"].unpack("<Q"))]
     sc = VScene()
     for i in range(root["OCount"].unpack("<Q")):
         pos, rot, scale = _read_level_object(root[f"O_{i}"])

@@ -213,8 +213,9 @@ def load_texture(path: str) -> np.ndarray:
 
 
 def load_skybox_faces(directory: str) -> np.ndarray:
-    """Sky box from <directory>/XP.png ... ZM.png (the reference's Resources/Skybox layout) through the C++ host loader;
-    returns uint8 [6, S, S, 4] in the order vrt_env_upload / VScene.EnvironmentMap expect (+X,-X,+Y,-Y,+Z,-Z)."""
+    """Sky box from <directory>/XP.png ... ZM.png (the reference's Resources/Skybox layout), or from a .dds cube map (what
+    VTextureFactory::LoadTextureCubeFromFile reads: uncompressed RGBA / BGRA / BGRX / RGB, top mip), through the C++ host
+    loader; returns uint8 [6, S, S, 4] in the order vrt_env_upload / VScene.EnvironmentMap expect (+X,-X,+Y,-Y,+Z,-Z)."""
     lib = load_host()
     lib.vrh_cubemap_load.restype = C.c_int
     lib.vrh_cubemap_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
