@@ -137,6 +137,8 @@ struct Volume {
     /* Cube modes: per brick the Chebyshev distance, in bricks, to the nearest brick that holds a solid
        voxel (density <= 0 at one of its 4^3 cell-origin voxels); 0 = this brick holds one.  Built on demand. */
     const uint8_t* cube_skip = nullptr;
+    /* Active box (with skip): object-space bounding box of the near bricks; the sphere-trace is clipped to it. */
+    float alo[3] = {0, 0, 0}, ahi[3] = {0, 0, 0};
     std::shared_ptr<const struct Derived> derived; /* owner of the three tables and of the quantised field */
 };
 
@@ -150,6 +152,7 @@ struct Derived {
     std::vector<uint8_t> skip;
     std::vector<uint32_t> nib;
     std::vector<uint8_t> cube_skip;
+    int abox[6] = {0, 0, 0, -1, -1, -1}; /* bounding box of the near bricks {min x, z, y, max x, z, y} */
     bool has_cube = false;
 };
 
@@ -248,7 +251,7 @@ void parallel_slabs(int n, F fn) {
  * to the nearest near brick.  From any point of a brick with D >= 2 the ray may advance (D-1) brick edges: that
  * cannot reach a near brick.
  */
-void build_skip_table(const float* den, int N, int nb, float density_scale, float step_max, std::vector<uint8_t>& out) {
+void build_skip_table(const float* den, int N, int nb, float density_scale, float step_max, std::vector<uint8_t>& out, int abox[6]) {
     std::vector<uint8_t> cur((size_t)nb * nb * nb, 255);
     parallel_slabs(nb, [&](int b0, int b1) {
         for (int bx = b0; bx < b1; bx++)
@@ -267,6 +270,19 @@ void build_skip_table(const float* den, int N, int nb, float density_scale, floa
                     if (near) cur[((size_t)bx * nb + bz) * nb + by] = 0;
                 }
     });
+    abox[0] = abox[1] = abox[2] = nb;
+    abox[3] = abox[4] = abox[5] = -1;
+    for (int bx = 0; bx < nb; bx++)
+        for (int bz = 0; bz < nb; bz++)
+            for (int by = 0; by < nb; by++)
+                if (cur[((size_t)bx * nb + bz) * nb + by] == 0) {
+                    abox[0] = bx < abox[0] ? bx : abox[0];
+                    abox[1] = bz < abox[1] ? bz : abox[1];
+                    abox[2] = by < abox[2] ? by : abox[2];
+                    abox[3] = bx > abox[3] ? bx : abox[3];
+                    abox[4] = bz > abox[4] ? bz : abox[4];
+                    abox[5] = by > abox[5] ? by : abox[5];
+                }
     chebyshev_dilate(cur, nb);
     out.swap(cur);
 }
@@ -449,7 +465,7 @@ std::shared_ptr<const Derived> derive(const vrto_volume& s, int N, int nb, bool 
             scale = s.density_scale * 0.01f;
         }
         if (s.step_max > 0.0f) {
-            build_skip_table(field, N, nb, scale, s.step_max, d->skip);
+            build_skip_table(field, N, nb, scale, s.step_max, d->skip, d->abox);
             build_nibble_table(field, N, nb, scale, s.step_max, d->nib);
         }
     }
@@ -504,6 +520,14 @@ bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env
         if (s.format == VRT_FORMAT_TEXEL16) v.den = v.derived->field.data();
         v.skip = s.step_max > 0.0f ? v.derived->skip.data() : nullptr;
         v.nib = s.step_max > 0.0f ? v.derived->nib.data() : nullptr;
+        for (int a = 0; a < 3; a++) { /* brick box {x, z, y} -> object-space box per axis x, y, z */
+            const int ax = a == 0 ? 0 : (a == 1 ? 2 : 1);
+            const int lo_cell = v.derived->abox[ax] * 4;
+            int hi_cell = (v.derived->abox[3 + ax] + 1) * 4;
+            hi_cell = hi_cell < v.N - 1 ? hi_cell : v.N - 1;
+            v.alo[a] = (float)lo_cell * v.cell - v.extent;
+            v.ahi[a] = (float)hi_cell * v.cell - v.extent;
+        }
         v.cube_skip = prm->mode >= VRT_MODE_CUBE ? v.derived->cube_skip.data() : nullptr;
     }
     P.n_inst = scene->n_instances;
@@ -685,6 +709,28 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
 
     float t = (t_enter > 0.0f ? t_enter : 0.0f) + P.prm.eps_in;
     float t_end = minf(t_exit, t_cur);
+    bool clipped = false;
+    if (V.skip) {
+        /* The active box: bounding box of the bricks that can hold surface.  Outside it the table would only leap; the
+           march is clipped to it (same slab arithmetic, same reciprocals as the volume box). */
+        const float inf = std::numeric_limits<float>::infinity();
+        const float oo3[3] = {oo.x, oo.y, oo.z}, od3[3] = {od.x, od.y, od.z};
+        float tmin[3], tmax[3];
+        for (int a = 0; a < 3; a++) {
+            const bool pos = od3[a] > 0.0f;
+            const float inv = od3[a] != 0.0f ? 1.0f / od3[a] : (pos ? inf : -inf);
+            tmin[a] = ((pos ? V.alo[a] : V.ahi[a]) - oo3[a]) * inv;
+            tmax[a] = ((pos ? V.ahi[a] : V.alo[a]) - oo3[a]) * inv;
+        }
+        const float ta = maxf(maxf(tmin[0], tmin[1]), tmin[2]);
+        const float tb = minf(minf(tmax[0], tmax[1]), tmax[2]);
+        if (!(tb > ta) || !(tb >= 0.0f)) return false;
+        if (ta > t) {
+            t = ta;
+            clipped = true;
+        }
+        t_end = minf(t_end, tb);
+    }
     /* smallest step: one pixel-footprint radius at the total path length t_base + t (t_base = length of
        the path that led to this ray's origin: 0 for camera rays, the hit distance for shadow rays) */
     const float base_min = fmaf(t_base, P.prm.cone_eps, P.prm.step_min);
@@ -753,7 +799,7 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
             t_hit = t;
             if (want_normal) {
                 V3 n;
-                if (i == 0 && t_enter >= 0.0f) {
+                if (i == 0 && t_enter >= 0.0f && !clipped) {
                     /* surface cut by the volume boundary: AABB-face normal (Raytracing.hlsl:198-226) */
                     float tb = t_enter - 0.1f;
                     V3 rp = v3(fmaf(od.x, tb, oo.x), fmaf(od.y, tb, oo.y), fmaf(od.z, tb, oo.z));

@@ -531,7 +531,7 @@ def test_shell_volume_with_step_clamp(renderer, oracle_lib):
     sc = v.VScene(Camera=v.look_minus_x_camera(250.0), DirectionalLight=v.demo_light(), Objects=[v.VVoxelObject(Volume=vol)],
                   EnvironmentMap=v.procedural_skybox(8))
     img, t = assert_parity(renderer, sc, v.default_params(320, 180, vol.GetCellSize(), 255, shadow=True))
-    assert t["primary_steps"] / t["primary_rays"] > 3  # clamped steps near the shell, leaps through the empty bricks
+    assert t["primary_steps"] / t["hits"] > 2 and t["hits"] > 5000  # several clamped steps near the shell per hit; the rest is skipped
     assert_parity(renderer, sc, v.default_params(320, 180, vol.GetCellSize(), 255, shadow=True, path=_abi.PATH_BRICK_LDS))
 
 
@@ -874,7 +874,7 @@ def test_voxelized_shell_volume_parity(renderer, oracle_lib, path):
     sc = scenes.config3_voxelized(6, 32)
     p = v.default_params(480, 270, scenes.min_cell(sc), 255, shadow=True, path=path)
     img, t = assert_parity(renderer, sc, p)
-    assert (t["primary_steps"] + t["shadow_steps"]) / (t["primary_rays"] + t["shadow_rays"]) > 5
+    assert (t["primary_steps"] + t["shadow_steps"]) / t["hits"] > 5 and t["hits"] > 10000
 
 
 def test_cpp_host_adaptor_renders_the_demo_scene(renderer, tmp_path):

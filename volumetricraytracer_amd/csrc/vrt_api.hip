@@ -38,6 +38,7 @@ struct HostVolume {
     int resolution = 0, N = 0, nb = 0;
     float extent = 0.f;
     int format = VRT_FORMAT_F32;
+    int abox[6] = {0, 0, 0, -1, -1, -1}; /* bounding box of the near bricks {min x, z, y, max x, z, y} (with the empty-space table) */
     float density_scale = 1.f;
     float step_max = 0.f; /* <= 0: unbounded */
     vrt_material mat = {{0.8f, 0.8f, 0.8f, 1.0f}, 0.8f, 0.0f};
@@ -348,12 +349,19 @@ void fill_dvolume(const vrt_ctx* ctx, const DeviceState& D, const HostVolume& h,
     out.k = (r1 * r1) / 8.0f; /* RDXVoxelVolume.cpp:383 */
     out.skip = (h.step_max > 0.0f && d.skip_valid) ? d.skip : nullptr;
     out.nib = out.skip ? d.nib : nullptr;
+    for (int a = 0; a < 3; a++) { /* brick box {x, z, y} -> object-space box per axis x, y, z */
+        const int ax = a == 0 ? 0 : (a == 1 ? 2 : 1);
+        const int lo_cell = h.abox[ax] * kBrickCells;
+        const int hi_cell = std::min((h.abox[3 + ax] + 1) * kBrickCells, h.N - 1);
+        out.abox_lo[a] = (float)lo_cell * cell - h.extent;
+        out.abox_hi[a] = (float)hi_cell * cell - h.extent;
+    }
     out.cube_skip = d.cube_skip;
 }
 
 /* (Re)builds the two-level empty-space table of a slot on every device for its current metric. */
 int rebuild_skip(vrt_ctx* ctx, int slot) {
-    const HostVolume& h = ctx->vol[slot];
+    HostVolume& h = ctx->vol[slot];
     const float scale = h.format == VRT_FORMAT_TEXEL16 ? h.density_scale * 0.01f : h.density_scale;
     for (auto& D : ctx->dev) {
         DeviceVolume& v = D.vol[slot];
@@ -365,11 +373,16 @@ int rebuild_skip(vrt_ctx* ctx, int slot) {
         if (!v.nib) HIP_TRY(hipMalloc(&v.nib, n * sizeof(unsigned)));
         void* scratch = nullptr;
         HIP_TRY(hipMalloc(&scratch, nibble_scratch_bytes(h.N)));
-        hipError_t e = launch_skip_table(v.dense, v.skip, v.skip + n, h.N, h.nb, scale, h.step_max, D.stream);
+        int* d_box = static_cast<int*>(scratch); /* the first 24 bytes of the scratch: read back before the nibble pass reuses them */
+        int box[6] = {h.nb, h.nb, h.nb, -1, -1, -1};
+        hipError_t e = launch_skip_table(v.dense, v.skip, v.skip + n, d_box, h.N, h.nb, scale, h.step_max, D.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(box, d_box, sizeof box, hipMemcpyDeviceToHost, D.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(D.stream);
         if (e == hipSuccess) e = launch_nibble_table(v.dense, v.nib, scratch, h.N, h.nb, scale, h.step_max, D.stream);
         if (e == hipSuccess) e = hipStreamSynchronize(D.stream);
         (void)hipFree(scratch);
         HIP_TRY(e);
+        memcpy(ctx->vol[slot].abox, box, sizeof box);
         v.skip_valid = true;
     }
     return VRT_OK;

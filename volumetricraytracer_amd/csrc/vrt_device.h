@@ -67,6 +67,9 @@ struct DVolume {
     float roughness_raw, metallic_raw; /* unclamped: the textured modes clamp after the RM factor */
     const uint8_t* cube_skip; /* nb^3 bytes: Chebyshev distance (bricks) to the nearest brick holding a solid voxel
                                  (density <= 0 at a cell-origin voxel); the Cube modes' octree stand-in */
+    float abox_lo[3], abox_hi[3]; /* with skip: object-space bounding box of the near bricks, (float)(cell index) * cell - extent
+                                     per axis; the sphere-trace is clipped to it.  lo > hi: no near brick, every ray misses */
+    float pad2_[2];
 };
 
 struct DInstance {

@@ -72,6 +72,7 @@ struct VolRef {
     int N;
     int nb;
     float extent, inv_cell, cell, dscale, step_max;
+    float alo[3], ahi[3]; /* active box (object space) of volumes with an empty-space table: the bounding box of the near bricks */
 };
 
 /* Where the taps of an internal path come from. */
@@ -94,6 +95,10 @@ __device__ __forceinline__ VolRef load_vol(const DVolume* __restrict__ v) {
     r.cell = v->cell;
     r.dscale = v->density_scale;
     r.step_max = v->step_max;
+    for (int a = 0; a < 3; a++) {
+        r.alo[a] = v->abox_lo[a];
+        r.ahi[a] = v->abox_hi[a];
+    }
     return r;
 }
 
@@ -228,6 +233,25 @@ __device__ __forceinline__ bool slab(F3 o, F3 d, float e, float t_cur, float& t_
     return t_exit > t_enter && t_exit >= 0.0f && t_enter <= t_cur;
 }
 
+/* Interval of the ray inside the box [lo,hi] with the reciprocals given: the volume's ACTIVE box — the bounding box of
+ * the bricks that can hold surface.  Outside it the empty-space table would only leap; clipping the march to it saves
+ * those iterations (most rays of a frame never enter it).  Oracle: same operations in the same order. */
+__device__ __forceinline__ void slab_interval(F3 o, F3 d, F3 inv, const float* lo, const float* hi, float& t_enter, float& t_exit) {
+    const bool px = d.x > 0.0f, py = d.y > 0.0f, pz = d.z > 0.0f;
+    const float tminx = ((px ? lo[0] : hi[0]) - o.x) * inv.x, tmaxx = ((px ? hi[0] : lo[0]) - o.x) * inv.x;
+    const float tminy = ((py ? lo[1] : hi[1]) - o.y) * inv.y, tmaxy = ((py ? hi[1] : lo[1]) - o.y) * inv.y;
+    const float tminz = ((pz ? lo[2] : hi[2]) - o.z) * inv.z, tmaxz = ((pz ? hi[2] : lo[2]) - o.z) * inv.z;
+    t_enter = maxf_(maxf_(tminx, tminy), tminz);
+    t_exit = minf_(minf_(tmaxx, tmaxy), tmaxz);
+}
+
+/* Inf-safe reciprocals of a direction (Ray.hlsli:111-134). */
+__device__ __forceinline__ F3 safe_rcp3(F3 d) {
+    const float inf = __builtin_inff();
+    return f3(d.x != 0.0f ? 1.0f / d.x : (d.x > 0.0f ? inf : -inf), d.y != 0.0f ? 1.0f / d.y : (d.y > 0.0f ? inf : -inf),
+              d.z != 0.0f ? 1.0f / d.z : (d.z > 0.0f ? inf : -inf));
+}
+
 /* The same test with the reciprocals given (they only depend on the direction). */
 __device__ __forceinline__ bool slab_inv(F3 o, F3 d, F3 inv, float e, float t_cur, float& t_enter, float& t_exit) {
     const bool px = d.x > 0.0f, py = d.y > 0.0f, pz = d.z > 0.0f;
@@ -284,17 +308,36 @@ struct RaySeg {
     float base_min;       /* step_min + cone_eps * t_base */
     float leap_unit;      /* one brick edge (4 cells) in ray-parameter units */
     float cell_unit;      /* one cell edge */
+    bool clipped;         /* the march starts at the active box, not at the volume's own face */
 };
+
+/* Clip the march interval [t0, t_end] of a ray set up against the volume box to the volume's active box.  False: the ray
+ * misses the active box (nothing to march). */
+__device__ __forceinline__ bool clip_to_active_box(const VolRef& V, F3 inv, RaySeg& R) {
+    R.clipped = false;
+    if (V.skip == nullptr) return true;
+    float ta, tb;
+    slab_interval(R.oo, R.od, inv, V.alo, V.ahi, ta, tb);
+    if (!(tb > ta) || !(tb >= 0.0f)) return false;
+    if (ta > R.t0) {
+        R.t0 = ta;
+        R.clipped = true;
+    }
+    R.t_end = minf_(R.t_end, tb);
+    return true;
+}
 
 /* Transform the ray into the instance, slab-test its volume box and derive the march constants.
  * Returns false when the box is missed (nothing else is then valid). */
+template <bool CLIP = true>
 __device__ __forceinline__ bool setup_ray(const DFrame& F, const DInstance* __restrict__ I, const VolRef& V, F3 o, F3 d,
                                           float t_cur, float t_base, RaySeg& R) {
     F3 rel = f3(o.x - I->pos[0], o.y - I->pos[1], o.z - I->pos[2]);
     R.oo = mul33(I->w2o, rel);
     R.od = mul33(I->w2o, d);
     float t_exit;
-    if (!slab(R.oo, R.od, V.extent, t_cur, R.t_enter, t_exit)) return false;
+    const F3 inv = safe_rcp3(R.od);
+    if (!slab_inv(R.oo, R.od, inv, V.extent, t_cur, R.t_enter, t_exit)) return false;
     const float inv_len = 1.0f / sqrtf(dot3(R.od, R.od));
     R.ds = V.dscale * inv_len;
     R.smax = V.step_max * inv_len;
@@ -307,6 +350,8 @@ __device__ __forceinline__ bool setup_ray(const DFrame& F, const DInstance* __re
     R.base_min = __builtin_fmaf(t_base, F.cone_eps, F.step_min);
     R.leap_unit = (4.0f * V.cell) * inv_len;
     R.cell_unit = R.leap_unit * 0.25f;
+    R.clipped = false;
+    if constexpr (CLIP) return clip_to_active_box(V, inv, R); /* (the Cube modes march the whole volume box) */
     return true;
 }
 
@@ -331,7 +376,7 @@ __device__ __forceinline__ bool setup_shadow_ray(const DFrame& F, const DInstanc
     R.base_min = __builtin_fmaf(t_base, F.cone_eps, F.step_min);
     R.leap_unit = (4.0f * V.cell) * inv_len;
     R.cell_unit = R.leap_unit * 0.25f;
-    return true;
+    return clip_to_active_box(V, f3(I->sh_inv[0], I->sh_inv[1], I->sh_inv[2]), R);
 }
 
 /* Cell + fraction of the sample at ray parameter t: cell = clamp(floor(u), 0, N-2) (v_med3_f32). */
@@ -402,7 +447,7 @@ template <int PATH, bool EXACT = false>
 __device__ __forceinline__ F3 hit_normal(const DInstance* __restrict__ I, const VolRef& V, const RaySeg& R, const Cell& c,
                                          int iter) {
     F3 n;
-    if (iter == 0 && R.t_enter >= 0.0f) {
+    if (iter == 0 && R.t_enter >= 0.0f && !R.clipped) {
         /* surface cut by the volume boundary: AABB-face normal (Raytracing.hlsl:198-226) */
         float tb = R.t_enter - 0.1f;
         float rx = __builtin_fmaf(R.od.x, tb, R.oo.x);
@@ -447,7 +492,7 @@ __device__ __forceinline__ bool march_cube(const DFrame& F, const DInstance* __r
                                            F3 d, float t_cur, float& t_hit, F3& n_world, unsigned& steps) {
     const VolRef V = load_vol<VRT_PATH_BRICK>(Vd);
     RaySeg R;
-    if (!setup_ray(F, I, V, o, d, t_cur, 0.0f, R)) return false;
+    if (!setup_ray<false>(F, I, V, o, d, t_cur, 0.0f, R)) return false;
     const float inf = __builtin_inff();
     const float ix = R.ud.x != 0.0f ? 1.0f / R.ud.x : inf;
     const float iy = R.ud.y != 0.0f ? 1.0f / R.ud.y : inf;
@@ -1653,6 +1698,19 @@ __global__ __launch_bounds__(128) void skip_seed_kernel(const float* __restrict_
     if (l == 0) table[brick] = (flag[0] || flag[1]) ? 0 : 255;
 }
 
+/* Bounding box, in bricks, of the near bricks (distance 0): box = {min x, z, y, max x, z, y}, preset to {nb.., -1..}. */
+__global__ void active_box_kernel(const uint8_t* __restrict__ table, int nb, int* __restrict__ box) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= nb * nb * nb || table[i] != 0) return;
+    const int by = i % nb, bz = (i / nb) % nb, bx = i / (nb * nb);
+    atomicMin(&box[0], bx);
+    atomicMin(&box[1], bz);
+    atomicMin(&box[2], by);
+    atomicMax(&box[3], bx);
+    atomicMax(&box[4], bz);
+    atomicMax(&box[5], by);
+}
+
 /* The march wants the leap count, not the distance: L = max(D-1, 0) (one convert + one multiply per sample). */
 __global__ void skip_to_leap_kernel(uint8_t* __restrict__ table, int n) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -1831,12 +1889,16 @@ hipError_t launch_texels_to_field(const void* texels, float* density, uint8_t* m
 
 static hipError_t dilate_table(uint8_t* table, uint8_t* scratch, int nb, hipStream_t stream);
 
-hipError_t launch_skip_table(const float* dense, uint8_t* table, uint8_t* scratch, int N, int nb, float density_scale, float step_max,
-                             hipStream_t stream) {
+hipError_t launch_skip_table(const float* dense, uint8_t* table, uint8_t* scratch, int* box6, int N, int nb, float density_scale,
+                             float step_max, hipStream_t stream) {
     const int n = nb * nb * nb;
     hipLaunchKernelGGL(skip_seed_kernel, dim3((unsigned)n), dim3(128), 0, stream, dense, table, N, nb, density_scale, step_max);
     hipError_t e = dilate_table(table, scratch, nb, stream);
     if (e != hipSuccess) return e;
+    const int preset[6] = {nb, nb, nb, -1, -1, -1};
+    e = hipMemcpyAsync(box6, preset, sizeof preset, hipMemcpyHostToDevice, stream); /* pageable source: staged before return */
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(active_box_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, table, nb, box6);
     hipLaunchKernelGGL(skip_to_leap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, table, n);
     return hipGetLastError();
 }

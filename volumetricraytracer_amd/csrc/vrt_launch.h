@@ -17,9 +17,10 @@ hipError_t launch_retile(const float* dense, void* bricks, int format, int N, in
 hipError_t launch_quantize_field(float* density, size_t count, hipStream_t stream);
 /* The reference's RGBA8 volume texture (device copy) -> integer field + materials in the grid's own order. */
 hipError_t launch_texels_to_field(const void* texels, float* density, uint8_t* material, int N, hipStream_t stream);
-/* Empty-space table, level 1: nb^3 leap-count bytes from the dense grid (scratch: another nb^3 bytes). */
-hipError_t launch_skip_table(const float* dense, uint8_t* table, uint8_t* scratch, int N, int nb, float density_scale, float step_max,
-                             hipStream_t stream);
+/* Empty-space table, level 1: nb^3 leap-count bytes from the dense grid (scratch: another nb^3 bytes), and (box6, six
+   device ints) the bounding box of the near bricks in brick coordinates {min x, z, y, max x, z, y} ({nb.., -1..}: none). */
+hipError_t launch_skip_table(const float* dense, uint8_t* table, uint8_t* scratch, int* box6, int N, int nb, float density_scale,
+                             float step_max, hipStream_t stream);
 /* Empty-space table, level 2: nb^3 words of sub-block nibbles (scratch: nibble_scratch_bytes(N)). */
 size_t nibble_scratch_bytes(int N);
 hipError_t launch_nibble_table(const float* dense, unsigned* nib, void* scratch, int N, int nb, float density_scale, float step_max,
