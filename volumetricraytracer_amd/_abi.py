@@ -200,7 +200,7 @@ def load(path: str | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("VRT_LIB") or LIB_PATH  # VRT_LIB: an A/B build of the same library (tools/ab_lib_variants.sh)
     if not os.path.exists(p):
         raise RuntimeError(
             f"{p} is missing: the HIP library is not built. Run "

@@ -718,6 +718,7 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.env_size = ctx->env_size;
     F.out = out;
     F.stats = stats;
+    F.vol0 = ctx->scene.n_instances == 1 ? F.vols + ctx->scene.instances[0].volume_slot : nullptr;
 }
 
 /* Enqueue one tile on one device.  No allocation, no host sync. */

@@ -160,6 +160,9 @@ struct DFrame {
                                   bounce_rays, primary_steps, shadow_steps, hits, exhausted_rays, 0 */
     unsigned* diag_buf;        /* diagnostic build only: 8 words per wave {start, end (100 MHz), fast fetches, xcc|hw_id,
                                   longest sample chain, load+lerp cycles, loop cycles, loop iterations} */
+    const DVolume* vol0;       /* single-instance scenes: vols + inst[0].slot, resolved on the host so that a wave loads its instance
+                                  and its volume record side by side instead of one after the other (four out of five waves of
+                                  a frame only need them to find out that their rays miss) */
 };
 
 }  // namespace vrt

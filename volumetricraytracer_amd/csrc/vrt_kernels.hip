@@ -592,11 +592,8 @@ struct MarchState {
  * The march loop of one lane on data path DP, from state `st` until a hit, the end of the interval, or `limit`
  * iterations.  One iteration = one position: either skipped (the two-level table shows no active cell within the
  * leap: the ray advances, no tap is read, no sample counted) or sampled.
- *  - table words are re-read only when the ray changes brick; a ray that was in a near brick asks for the taps of the
- *    next brick together with its table words (it is most likely near as well): one memory round trip per new cell;
- *  - while successive samples stay in one cell (a ray crawling along a surface takes steps of a tenth of a cell) the 8
- *    taps stay in registers: the dependent chain of memory round trips is as long as the cells crossed, not as the
- *    samples taken.
+ * Table words are re-read only when the ray changes brick.  (Two refinements are compiled out after measurement, see the
+ * VRT_AB_* blocks: speculative taps for the next brick, and keeping a cell's taps in registers across samples.)
  * Same positions, same values, same counters as the oracle's plain loop.
  */
 template <int DP, bool DIAG>
@@ -620,8 +617,17 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
         bool have_taps = false;
         float leap = 0.0f;
         if (tables) {
+#ifdef VRT_AB_NO_BRICK_CACHE /* A/B build (tools/ab_lib_variants.sh): table words re-read at every position */
+            last_brick = 0xffffffffu;
+#endif
             if (brick != last_brick) {
-                const bool spec = B == 0u; /* leaving a near brick: the next one is most likely near too */
+#ifdef VRT_AB_SPEC /* A/B build: a ray leaving a near brick asks for the next brick's taps together with its table words.
+                      Measured (profiles/r02_ab_march_variants.txt): 7 % slower — the wasted taps cost more TA time than the
+                      saved round trip gains */
+                const bool spec = B == 0u;
+#else
+                const bool spec = false;
+#endif
                 B = V.skip[brick];
                 nibw = V.nib[brick];
                 if (spec) {
@@ -669,6 +675,11 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
             const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
             t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
             if (i >= limit || t > R.t_end) break;
+#ifndef VRT_AB_INCELL /* A/B build: while successive samples stay in one cell the 8 taps stay in registers.  Measured
+                         (profiles/r02_ab_march_variants.txt): 12 % slower with one frame in flight — the lanes of a wave that
+                         changed cell wait for the in-cell samples of the others before any of them may fetch */
+            break;
+#endif
             const Cell c2 = cell_at(R, t);
             if (c2.cx != c.cx || c2.cy != c.cy || c2.cz != c.cz) break;
             c = c2;
@@ -731,7 +742,7 @@ __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float
     if constexpr (SINGLE) {
         float t;
         F3 n;
-        if (march_instance<PATH, NORMAL, DIAG>(F, F.inst, F.vols + F.inst->slot, o, d, t_max, t_base, t, n, steps, dg)) {
+        if (march_instance<PATH, NORMAL, DIAG>(F, F.inst, F.vol0, o, d, t_max, t_base, t, n, steps, dg)) {
             t_best = t;
             inst_best = 0;
             n_best = n;
@@ -776,7 +787,7 @@ __device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_m
     float t;
     F3 n;
     if constexpr (SINGLE) {
-        return march_instance<PATH, 0, DIAG, DIR_SHADOW>(F, F.inst, F.vols + F.inst->slot, o, d, t_max, t_base, t, n, steps, dg);
+        return march_instance<PATH, 0, DIAG, DIR_SHADOW>(F, F.inst, F.vol0, o, d, t_max, t_base, t, n, steps, dg);
     } else {
         int stack[16];
         int sp = 0;
@@ -797,8 +808,8 @@ __device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_m
 }
 
 /* Cube-map point lookup with SampleLevel(dir.xzy) (Raytracing.hlsl:444-449). */
-__device__ __forceinline__ F3 env_lookup(const uint8_t* __restrict__ env, int S, F3 dir) {
-    if (env == nullptr) return f3(0.0f, 0.0f, 0.0f);
+__device__ __forceinline__ unsigned env_fetch(const uint8_t* __restrict__ env, int S, F3 dir) {
+    if (env == nullptr) return 0u;
     float vx = dir.x, vy = dir.z, vz = dir.y;
     float ax = fabsf(vx), ay = fabsf(vy), az = fabsf(vz);
     int face;
@@ -822,10 +833,13 @@ __device__ __forceinline__ F3 env_lookup(const uint8_t* __restrict__ env, int S,
     int iy = (int)floorf(v * (float)S);
     ix = ix < 0 ? 0 : (ix > S - 1 ? S - 1 : ix);
     iy = iy < 0 ? 0 : (iy > S - 1 ? S - 1 : iy);
-    const unsigned px = ((guint_p)env)[(face * S + iy) * S + ix]; /* little-endian R,G,B,A bytes */
+    return ((guint_p)env)[(face * S + iy) * S + ix]; /* little-endian R,G,B,A bytes */
+}
+__device__ __forceinline__ F3 env_decode(unsigned px) {
     const float k = 1.0f / 255.0f;
     return f3((float)(px & 0xffu) * k, (float)((px >> 8) & 0xffu) * k, (float)((px >> 16) & 0xffu) * k);
 }
+__device__ __forceinline__ F3 env_lookup(const uint8_t* __restrict__ env, int S, F3 dir) { return env_decode(env_fetch(env, S, dir)); }
 
 /* Radiance(), Lighting.hlsli:50-101 (F enters twice, PI = 3.141592f as in Constants.hlsli). */
 /* BRDF(wi, wo) of Lighting.hlsli:77-96; Radiance = (BRDF * Li) * dot(n, wi)  (:98-101). */
@@ -906,6 +920,26 @@ __device__ __forceinline__ void tile_of_block(const DFrame& F, int b, int nblk, 
     }
 }
 
+/* Workgroup shape of the per-lane march kernels.  Product: 4 waves = one 16x16-pixel tile per workgroup.  VRT_AB_WAVE_BLOCKS
+ * (A/B build): one wave = one 8x8 tile per workgroup, four consecutive workgroups OF THE SAME XCD (blockIdx % 8) cover the
+ * 16x16 tile, so the tile -> XCD map is unchanged while the dispatcher refills single wave slots. */
+#ifdef VRT_AB_WAVE_BLOCKS
+constexpr int kMarchThreads = 64;
+constexpr int kMarchGridMul = 4;
+__device__ __forceinline__ void block_and_wave(int& b, int& wave) {
+    const int raw = (int)blockIdx.x, xcd = raw & 7, q = raw >> 3;
+    wave = q & 3;
+    b = ((q >> 2) << 3) | xcd;
+}
+#else
+constexpr int kMarchThreads = kBlockThreads;
+constexpr int kMarchGridMul = 1;
+__device__ __forceinline__ void block_and_wave(int& b, int& wave) {
+    b = (int)blockIdx.x;
+    wave = (int)threadIdx.x >> 6;
+}
+#endif
+
 /* Camera ray of pixel (px,py) (Ray.hlsli:36-48, then normalised). */
 __device__ __forceinline__ void camera_ray(const DFrame& F, int px, int py, F3& o, F3& d) {
     float sx = (((float)px + 0.5f) / (float)F.width) * 2.0f - 1.0f;
@@ -927,19 +961,31 @@ struct Counters {
  * at the memory side and cost more than the march itself) and no workgroup barrier (it would pin
  * the three fast waves of a tile until its slowest wave retires).
  */
-template <bool DIAG>
+/* UNIT: every ray / hit counter of a lane is 0 or 1 (the lean kernels): one ballot + popcount each on the scalar unit instead of
+   a 12-instruction shuffle reduction. */
+template <bool DIAG, bool UNIT = false>
 __device__ __forceinline__ void write_records(const DFrame& F, int b, int wave, int lane, Counters k, const DiagAcc& dg,
                                               unsigned long long t_start) {
-    const unsigned exhausted = wave_sum((k.s_primary >> kExhaustedShift) + (k.s_shadow >> kExhaustedShift));
+    const unsigned ex_lane = (k.s_primary >> kExhaustedShift) + (k.s_shadow >> kExhaustedShift);
+    const unsigned exhausted = __ballot(ex_lane != 0u) == 0ull ? 0u : wave_sum(ex_lane); /* practically never set */
     k.s_primary &= kExhaustedOne - 1u;
     k.s_shadow &= kExhaustedOne - 1u;
     const unsigned s_primary_lane = k.s_primary, s_shadow_lane = k.s_shadow;
-    k.n_primary = wave_sum(k.n_primary);
-    k.n_shadow = wave_sum(k.n_shadow);
-    k.n_bounce = wave_sum(k.n_bounce);
-    k.s_primary = wave_sum(k.s_primary);
-    k.s_shadow = wave_sum(k.s_shadow);
-    k.n_hits = wave_sum(k.n_hits);
+    if constexpr (UNIT) {
+        k.n_primary = (unsigned)__builtin_popcountll(__ballot(k.n_primary != 0u));
+        k.n_shadow = (unsigned)__builtin_popcountll(__ballot(k.n_shadow != 0u));
+        k.n_bounce = 0u;
+        k.n_hits = (unsigned)__builtin_popcountll(__ballot(k.n_hits != 0u));
+        k.s_primary = __ballot(k.s_primary != 0u) == 0ull ? 0u : wave_sum(k.s_primary); /* sky waves take no sample */
+        k.s_shadow = __ballot(k.s_shadow != 0u) == 0ull ? 0u : wave_sum(k.s_shadow);
+    } else {
+        k.n_primary = wave_sum(k.n_primary);
+        k.n_shadow = wave_sum(k.n_shadow);
+        k.n_bounce = wave_sum(k.n_bounce);
+        k.s_primary = wave_sum(k.s_primary);
+        k.s_shadow = wave_sum(k.s_shadow);
+        k.n_hits = wave_sum(k.n_hits);
+    }
     if (F.stats != nullptr && lane < 8) {
         unsigned v = lane == 0 ? k.n_primary : lane == 1 ? k.n_shadow : lane == 2 ? k.n_bounce : lane == 3 ? k.s_primary
                    : lane == 4 ? k.s_shadow : lane == 5 ? k.n_hits : lane == 6 ? exhausted : 0u;
@@ -1035,13 +1081,13 @@ __device__ __forceinline__ int frame_row(const DFrame& F, int pyl) {
 }
 
 template <int PATH, bool SINGLE, bool DIAG>
-__global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
+__global__ __launch_bounds__(kMarchThreads) void march_kernel(const DFrame F) {
     unsigned long long t_start = 0;
     if constexpr (DIAG) t_start = __builtin_amdgcn_s_memrealtime(); /* 100 MHz; diagnostic build only */
-    const int b = (int)blockIdx.x;
+    int b, wave;
+    block_and_wave(b, wave);
     int tile_x, tile_y;
-    tile_of_block(F, b, (int)gridDim.x, tile_x, tile_y);
-    const int wave = (int)threadIdx.x >> 6;
+    tile_of_block(F, b, (int)gridDim.x / kMarchGridMul, tile_x, tile_y);
     const int lane = (int)threadIdx.x & 63;
     const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
     const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
@@ -1059,6 +1105,9 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
         int inst = 0;
         F3 n = f3(0.0f, 0.0f, 0.0f);
         F3 color;
+        /* the sky texel is asked for before the march (one register across it): four out of five waves of a frame see only
+           sky, and for them it is the last link of a chain of dependent loads (kernarg -> instance / volume -> texel -> store) */
+        const unsigned sky = env_fetch(F.env, F.env_size, d);
         /* the normal's length is the correctly rounded one: its dot product with the light decides whether a shadow ray is cast */
         if (trace_closest<PATH, SINGLE, DIAG, 2>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, k.s_primary, &dg)) {
             k.n_hits = 1;
@@ -1070,13 +1119,13 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel(const DFrame F) {
                 k.n_shadow = 1;
                 shadowed = trace_any<PATH, SINGLE, DIAG, true>(F, shadow_origin(F, o, d, t_hit), ld, 5000.0f, t_hit, k.s_shadow, &dg);
             }
-            color = shade_hit(F, F.vols + F.inst[inst].slot, d, n, shadowed);
+            color = shade_hit(F, SINGLE ? F.vol0 : F.vols + F.inst[inst].slot, d, n, shadowed);
         } else {
-            color = env_lookup(F.env, F.env_size, d);
+            color = env_decode(sky);
         }
         store_pixel(F, px, pyl, color);
     }
-    write_records<DIAG>(F, b, wave, lane, k, dg, t_start);
+    write_records<DIAG, true>(F, b, wave, lane, k, dg, t_start);
 }
 
 /* ---- tri-planar material textures (SH/Include/Textures.hlsli:16-59, Quaternion.hlsli:18-82) ----------
@@ -1177,11 +1226,11 @@ __device__ __forceinline__ void textured_surface(const DVolume* __restrict__ V, 
 constexpr int kMaxDepth = 3;
 
 template <int PATH, bool SINGLE>
-__global__ __launch_bounds__(kBlockThreads) void march_kernel_full(const DFrame F) {
-    const int b = (int)blockIdx.x;
+__global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DFrame F) {
+    int b, wave;
+    block_and_wave(b, wave);
     int tile_x, tile_y;
-    tile_of_block(F, b, (int)gridDim.x, tile_x, tile_y);
-    const int wave = (int)threadIdx.x >> 6;
+    tile_of_block(F, b, (int)gridDim.x / kMarchGridMul, tile_x, tile_y);
     const int lane = (int)threadIdx.x & 63;
     const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
     const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
@@ -1209,12 +1258,12 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_full(const DFrame 
                 break;
             }
             k.n_hits++;
-            const DVolume* V = F.vols + F.inst[inst].slot;
+            const DVolume* V = SINGLE ? F.vol0 : F.vols + F.inst[inst].slot;
             F3 albedo = f3(V->tint[0], V->tint[1], V->tint[2]);
             float rough = V->roughness, metal = V->metallic;
             if (F.textured) {
                 const F3 hp = f3(__builtin_fmaf(d.x, t_hit, o.x), __builtin_fmaf(d.y, t_hit, o.y), __builtin_fmaf(d.z, t_hit, o.z));
-                textured_surface(V, F.inst + inst, hp, albedo, n, rough, metal);
+                textured_surface(V, SINGLE ? F.inst : F.inst + inst, hp, albedo, n, rough, metal);
             }
             if (F.unlit) {
                 color = albedo;
@@ -1486,7 +1535,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame 
     Counters k;
     DiagAcc dg;
     const DInstance* I = F.inst;
-    const DVolume* Vd = F.vols + I->slot;
+    const DVolume* Vd = F.vol0;
     const VolRef V = load_vol<VRT_PATH_BRICK>(Vd);
 
     F3 o = f3(0.0f, 0.0f, 0.0f), d = f3(1.0f, 0.0f, 0.0f);
@@ -1526,7 +1575,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame 
         F3 color = hit ? shade_hit(F, Vd, d, n, shadowed) : env_lookup(F.env, F.env_size, d);
         store_pixel(F, px, pyl, color);
     }
-    write_records<DIAG>(F, b, wave, lane, k, dg, t_start);
+    write_records<DIAG, true>(F, b, wave, lane, k, dg, t_start);
 }
 
 /* dense N^3 grid → 4^3-cell bricks with a one-sample apron (5^3 samples, padded to 128 floats). */
@@ -1814,9 +1863,9 @@ static hipError_t launch_t(const DFrame& F, hipStream_t stream) {
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
     if (F.diag)
-        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, true>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, true>), dim3((unsigned)(grid * kMarchGridMul)), dim3(kMarchThreads), 0, stream, F);
     else
-        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul)), dim3(kMarchThreads), 0, stream, F);
     return hipGetLastError();
 }
 
@@ -1825,7 +1874,7 @@ template <int PATH, bool SINGLE>
 static hipError_t launch_nodiag_t(const DFrame& F, hipStream_t stream) {
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
+    hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul)), dim3(kMarchThreads), 0, stream, F);
     return hipGetLastError();
 }
 
@@ -1843,7 +1892,7 @@ template <int PATH, bool SINGLE>
 static hipError_t launch_full_t(const DFrame& F, hipStream_t stream) {
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
+    hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE>), dim3((unsigned)(grid * kMarchGridMul)), dim3(kMarchThreads), 0, stream, F);
     return hipGetLastError();
 }
 
