@@ -60,7 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--strip-rows", type=int, default=32, help="N>1: rows per interleaved strip; 0 = contiguous row tiles")
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="frames launched before the first one must have finished, each on its own HIP stream and tile "
-                         "buffer (the reference keeps 3 in flight, DXConstants.cpp:23); 0 = 2 on one GPU, 3 on several")
+                         "buffer; 0 = 3, what the reference keeps in flight (FrameCount, DXConstants.cpp:23)")
     ap.add_argument("--tile-map", default="supertile", choices=["supertile", "band", "linear"], help="blockIdx -> tile map (speed only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the latency / end_to_end / config4 legs")
@@ -309,7 +309,7 @@ def main() -> None:
         label += f" -- the same {W}x{H} frame split over {world} GPUs (strong scaling)"
     rgba8 = args.output == "rgba8" or (args.output == "auto" and world > 1)
     strip_rows = args.strip_rows if world > 1 else 0
-    K = args.frames_in_flight or (2 if world == 1 else 3)
+    K = args.frames_in_flight or 3  # FrameCount, DXConstants.cpp:23
     path = {"auto": _abi.PATH_AUTO, "dense": _abi.PATH_DENSE, "brick": _abi.PATH_BRICK, "lds": _abi.PATH_BRICK_LDS}[args.path]
     fmt = {"auto": workloads.BENCH_VOLUME_FORMAT, "f32": _abi.FORMAT_F32, "texel16": _abi.FORMAT_TEXEL16}[args.format]
     for vol in sc.volumes():

@@ -5,7 +5,7 @@
 # Usage: tools/ab_lib_variants.sh build | run [bench args...]
 set -uo pipefail
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
-variants=(${VRT_AB_VARIANTS:-"base:" "incell:-DVRT_AB_INCELL" "spec:-DVRT_AB_SPEC" "no_brick_cache:-DVRT_AB_NO_BRICK_CACHE" "wave_blocks:-DVRT_AB_WAVE_BLOCKS"})
+variants=(${VRT_AB_VARIANTS:-"base:" "incell:-DVRT_AB_INCELL" "spec:-DVRT_AB_SPEC" "no_brick_cache:-DVRT_AB_NO_BRICK_CACHE" "quad_blocks:-DVRT_AB_QUAD_BLOCKS"})
 mode="${1:-build}"; shift || true
 if [ "$mode" = build ]; then
   for v in "${variants[@]}"; do

@@ -654,6 +654,59 @@ struct RowSet {
     int strip_rows = 0, strip_first = 0, strip_stride = 0;
 };
 
+/* Screen rectangle of everything a primary ray can reach (DFrame::cull_*): the corners of every instance's active box
+   (object space -> world -> camera -> pixel), double precision, two pixels of margin.  Any corner at or behind the camera
+   plane: the whole frame. */
+void cull_rect(const vrt_ctx* ctx, const vrt_params* p, DFrame& F) {
+    F.cull_x0 = 0;
+    F.cull_y0 = 0;
+    F.cull_x1 = p->width - 1;
+    F.cull_y1 = p->height - 1;
+    double x0 = 1e30, y0 = 1e30, x1 = -1e30, y1 = -1e30;
+    for (int i = 0; i < ctx->scene.n_instances; i++) {
+        const HostVolume& h = ctx->vol[ctx->scene.instances[i].volume_slot];
+        const DInstance& I = ctx->inst[i];
+        double lo[3], hi[3];
+        const double cell = ((double)h.extent * 2.0) / (double)(h.N - 1);
+        for (int a = 0; a < 3; a++) {
+            lo[a] = -(double)h.extent;
+            hi[a] = (double)h.extent;
+            if (h.step_max > 0.0f) { /* the march is clipped to the active box; a little slack for its float rounding */
+                const int ax = a == 0 ? 0 : (a == 1 ? 2 : 1);
+                lo[a] = std::max(lo[a], (double)(h.abox[ax] * kBrickCells) * cell - (double)h.extent - 0.01 * cell);
+                hi[a] = std::min(hi[a], (double)std::min((h.abox[3 + ax] + 1) * kBrickCells, h.N - 1) * cell - (double)h.extent + 0.01 * cell);
+            }
+        }
+        if (lo[0] > hi[0] || lo[1] > hi[1] || lo[2] > hi[2]) continue; /* nothing to hit in this volume */
+        for (int k = 0; k < 8; k++) {
+            const double c[3] = {(k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2]};
+            double w[3];
+            for (int a = 0; a < 3; a++)
+                w[a] = (double)I.o2w[a * 3 + 0] * c[0] + (double)I.o2w[a * 3 + 1] * c[1] + (double)I.o2w[a * 3 + 2] * c[2] + (double)I.pos[a] - (double)F.cam_o[a];
+            const double ca = w[0] * F.r0[0] + w[1] * F.r0[1] + w[2] * F.r0[2];
+            const double cb = w[0] * F.r1[0] + w[1] * F.r1[1] + w[2] * F.r1[2];
+            const double cc = -(w[0] * F.r2[0] + w[1] * F.r2[1] + w[2] * F.r2[2]); /* depth along the view direction */
+            if (!(cc > 1e-6 * (fabs(ca) + fabs(cb) + 1.0))) return; /* at or behind the camera plane: no culling */
+            const double sx = (ca / cc) / (double)F.cx, sy = -(cb / cc) / (double)F.cy;
+            const double px = (sx + 1.0) * 0.5 * (double)p->width - 0.5, py = (sy + 1.0) * 0.5 * (double)p->height - 0.5;
+            x0 = std::min(x0, px);
+            x1 = std::max(x1, px);
+            y0 = std::min(y0, py);
+            y1 = std::max(y1, py);
+        }
+    }
+    if (x1 < x0) { /* no instance can be hit: an empty rectangle */
+        F.cull_x0 = F.cull_y0 = 1;
+        F.cull_x1 = F.cull_y1 = 0;
+        return;
+    }
+    const double m = 2.0;
+    F.cull_x0 = (int)std::max(0.0, std::min((double)p->width, floor(x0 - m)));
+    F.cull_y0 = (int)std::max(0.0, std::min((double)p->height, floor(y0 - m)));
+    F.cull_x1 = (int)std::max(-1.0, std::min((double)p->width - 1.0, ceil(x1 + m)));
+    F.cull_y1 = (int)std::max(-1.0, std::min((double)p->height - 1.0, ceil(y1 + m)));
+}
+
 void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, const RowSet& rs, float* out,
                  unsigned* stats, DFrame& F, const SceneArrays* snapshot = nullptr) {
     const int row0 = rs.row0, rows = rs.rows;
@@ -719,6 +772,7 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.out = out;
     F.stats = stats;
     F.vol0 = ctx->scene.n_instances == 1 ? F.vols + ctx->scene.instances[0].volume_slot : nullptr;
+    cull_rect(ctx, p, F);
 }
 
 /* Enqueue one tile on one device.  No allocation, no host sync. */

@@ -160,6 +160,10 @@ struct DFrame {
                                   bounce_rays, primary_steps, shadow_steps, hits, exhausted_rays, 0 */
     unsigned* diag_buf;        /* diagnostic build only: 8 words per wave {start, end (100 MHz), fast fetches, xcc|hw_id,
                                   longest sample chain, load+lerp cycles, loop cycles, loop iterations} */
+    /* Primary rays outside this pixel rectangle (inclusive) cannot reach any instance: it bounds the projection of every
+       instance's active box (its whole box for volumes without an empty-space table), two pixels of margin included; the
+       whole frame when a box reaches behind the camera.  A wave whose pixels all lie outside goes straight to the sky */
+    int32_t cull_x0, cull_y0, cull_x1, cull_y1;
     const DVolume* vol0;       /* single-instance scenes: vols + inst[0].slot, resolved on the host so that a wave loads its instance
                                   and its volume record side by side instead of one after the other (four out of five waves of
                                   a frame only need them to find out that their rays miss) */

@@ -920,10 +920,11 @@ __device__ __forceinline__ void tile_of_block(const DFrame& F, int b, int nblk, 
     }
 }
 
-/* Workgroup shape of the per-lane march kernels.  Product: 4 waves = one 16x16-pixel tile per workgroup.  VRT_AB_WAVE_BLOCKS
- * (A/B build): one wave = one 8x8 tile per workgroup, four consecutive workgroups OF THE SAME XCD (blockIdx % 8) cover the
- * 16x16 tile, so the tile -> XCD map is unchanged while the dispatcher refills single wave slots. */
-#ifdef VRT_AB_WAVE_BLOCKS
+/* Workgroup shape of the per-lane march kernels: one wave = one 8x8-pixel tile per workgroup; four consecutive workgroups OF
+ * THE SAME XCD (blockIdx % 8) cover a 16x16 tile, so the tile -> XCD map is the one described above while the dispatcher
+ * refills single wave slots (waves of a tile retire at very different times).  VRT_AB_QUAD_BLOCKS (A/B build): round 1's four
+ * waves per workgroup; measured 3.5 % (two frames in flight) to 5 % (one) slower, profiles/r02_ab_march_variants.txt. */
+#ifndef VRT_AB_QUAD_BLOCKS
 constexpr int kMarchThreads = 64;
 constexpr int kMarchGridMul = 4;
 __device__ __forceinline__ void block_and_wave(int& b, int& wave) {
@@ -939,6 +940,14 @@ __device__ __forceinline__ void block_and_wave(int& b, int& wave) {
     wave = (int)threadIdx.x >> 6;
 }
 #endif
+
+/* False for a whole wave when none of its pixels lies inside the frame's cull rectangle (DFrame::cull_*): its primary rays
+ * cannot reach any instance, so the scene is never looked at — no instance / volume record loaded, no slab test.  Four out
+ * of five waves of the benchmark frame.  Wave-uniform on purpose: a wave that straddles the rectangle marches all its rays. */
+__device__ __forceinline__ bool wave_can_reach(const DFrame& F, bool valid, int px, int py) {
+    const bool inside = px >= F.cull_x0 && px <= F.cull_x1 && py >= F.cull_y0 && py <= F.cull_y1;
+    return __ballot(valid && inside) != 0ull;
+}
 
 /* Camera ray of pixel (px,py) (Ray.hlsli:36-48, then normalised). */
 __device__ __forceinline__ void camera_ray(const DFrame& F, int px, int py, F3& o, F3& d) {
@@ -1096,6 +1105,7 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel(const DFrame F) {
 
     Counters k;
     DiagAcc dg;
+    const bool reach = wave_can_reach(F, valid, px, py);
 
     if (valid) {
         F3 o, d;
@@ -1109,7 +1119,7 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel(const DFrame F) {
            sky, and for them it is the last link of a chain of dependent loads (kernarg -> instance / volume -> texel -> store) */
         const unsigned sky = env_fetch(F.env, F.env_size, d);
         /* the normal's length is the correctly rounded one: its dot product with the light decides whether a shadow ray is cast */
-        if (trace_closest<PATH, SINGLE, DIAG, 2>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, k.s_primary, &dg)) {
+        if (reach && trace_closest<PATH, SINGLE, DIAG, 2>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, k.s_primary, &dg)) {
             k.n_hits = 1;
             bool shadowed = false;
             const F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
@@ -1239,6 +1249,7 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DFrame 
 
     Counters k;
     DiagAcc dg;
+    const bool reach = wave_can_reach(F, valid, px, py);
     if (valid) {
         F3 o, d;
         camera_ray(F, px, py, o, d);
@@ -1253,7 +1264,7 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DFrame 
             float t_hit = 0.0f;
             int inst = 0;
             F3 n = f3(0.0f, 0.0f, 0.0f);
-            if (!trace_closest<PATH, SINGLE, false, 2>(F, o, d, 10000.0f, t_base, t_hit, inst, n, k.s_primary)) {
+            if ((level == 1 && !reach) || !trace_closest<PATH, SINGLE, false, 2>(F, o, d, 10000.0f, t_base, t_hit, inst, n, k.s_primary)) {
                 color = env_lookup(F.env, F.env_size, d);
                 break;
             }
@@ -1541,10 +1552,11 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame 
     F3 o = f3(0.0f, 0.0f, 0.0f), d = f3(1.0f, 0.0f, 0.0f);
     RaySeg R = {};
     bool act = false;
+    const bool reach = wave_can_reach(F, valid, px, py);
     if (valid) {
         camera_ray(F, px, py, o, d);
         k.n_primary = 1;
-        act = setup_ray(F, I, V, o, d, 10000.0f, 0.0f, R);
+        if (reach) act = setup_ray(F, I, V, o, d, 10000.0f, 0.0f, R);
     }
     float t_hit = 0.0f;
     Cell c_hit = {0, 0, 0, 0.0f, 0.0f, 0.0f};
