@@ -62,6 +62,10 @@ def parse_args(argv=None):
                     help="frames launched before the first one must have finished, each on its own HIP stream and tile "
                          "buffer; 0 = 3, what the reference keeps in flight (FrameCount, DXConstants.cpp:23)")
     ap.add_argument("--tile-map", default="supertile", choices=["supertile", "band", "linear"], help="blockIdx -> tile map (speed only)")
+    ap.add_argument("--gather", default="torch", choices=["torch", "native"],
+                    help="N>1: the per-frame tile gather: torch.distributed.gather (RCCL under torch), or the C-ABI's own "
+                         "vrt_gather_tiles (ncclGather on the march stream); the other one is exercised once after the timed "
+                         "region and reported under native_gather_check")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the latency / end_to_end / config4 legs")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of the baseline sample")
@@ -137,16 +141,29 @@ def measured_traffic(key: dict):
     return None
 
 
+class _StreamEvent:
+    """The part of torch.distributed's Work object the pipeline uses, for work enqueued on a HIP stream: wait() makes the
+    CURRENT stream wait for everything that was in `stream` when this object was made."""
+
+    def __init__(self, torch, stream):
+        self._torch = torch
+        self._ev = torch.cuda.Event()
+        self._ev.record(stream)
+
+    def wait(self):
+        self._torch.cuda.current_stream().wait_event(self._ev)
+
+
 class Pipeline:
     """K frames in flight: K tile buffers, K HIP streams; the gather of frame i overlaps the march of i+1.."""
 
-    def __init__(self, r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal):
+    def __init__(self, r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=False):
         import torch
 
         from volumetricraytracer_amd.tiles import FrameGather
 
         self.torch, self.r, self.p, self.world, self.rank, self.K = torch, r, p, world, rank, K
-        self.strip_rows, self.rehearsal = strip_rows, rehearsal
+        self.strip_rows, self.rehearsal, self.native = strip_rows, rehearsal, native and not rehearsal and world > 1
         pix = torch.uint8 if rgba8 else torch.float32
         self.fg = FrameGather(H, W, world, rank, torch.device("cpu") if rehearsal else dev, dtype=pix, buffers=K, strip_rows=strip_rows)
         self.march_tiles = [torch.zeros_like(x, device=dev) for x in self.fg.tiles] if rehearsal else self.fg.tiles
@@ -174,7 +191,11 @@ class Pipeline:
             if self.world > 1:
                 if self.unshuffled[b] is not None:
                     self.streams[b].wait_event(self.unshuffled[b])
-                self.pending[b] = fg.gather(b, async_op=True)  # RCCL gather over xGMI, overlaps the following frames' march
+                if self.native:  # ncclGather right behind the march on the same stream; "pending" = an event after it
+                    fg.native_gather(self.r, b, self.streams[b].cuda_stream)
+                    self.pending[b] = _StreamEvent(torch, self.streams[b])
+                else:
+                    self.pending[b] = fg.gather(b, async_op=True)  # RCCL gather over xGMI, overlaps the following frames' march
         if self.unshuffle:
             with torch.cuda.stream(self.copy_stream):
                 self.pending[b].wait()  # the copy stream (not the host) waits for this gather (gloo rehearsal: the host does)
@@ -330,7 +351,26 @@ def main() -> None:
     r.ResizeRenderOutput(W, H)
     r.SyncWithScene()
 
-    pipe = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal)
+    native_ready, native_error = False, None
+    if world > 1 and not rehearsal:
+        # the C-ABI's own communicator: rank 0 makes the id, torch.distributed carries it to the others
+        try:
+            idt = torch.zeros(_abi.VRT_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(v.VHipRenderer.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            r.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
+            native_ready = True
+        except Exception as e:  # reported, never fatal: torch.distributed.gather remains
+            native_error = repr(e)
+        flag = torch.tensor([1 if native_ready else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        native_ready = bool(flag.item())
+    use_native = args.gather == "native" and native_ready
+    if args.gather == "native" and world > 1 and not native_ready and not rehearsal:
+        raise SystemExit(f"[bench] --gather native: vrt_comm_init failed on some rank ({native_error})")
+
+    pipe = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=use_native)
     elapsed = timed_run(pipe, args.steps, args.warmup, world, cdev)
 
     t = r.last_timing()  # this rank's tile, last frame (every frame is identical)
@@ -360,11 +400,26 @@ def main() -> None:
     value = rays_per_frame * args.steps / elapsed / 1e6 if args.steps > 0 else 0.0
 
     # ---- extra legs (outside the timed region) ------------------------------------------------------------------
+    native_check = None
+    if world > 1 and native_ready and not args.no_extra_legs and args.steps > 0:
+        # the other gather implementation, a few frames: same pixels on rank 0, and its frame time
+        try:
+            other = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=not use_native)
+            osteps = max(min(args.steps, 30), 3)
+            eo = timed_run(other, osteps, 2, world, cdev)
+            same = True
+            if rank == 0:
+                same = bool(torch.equal(other.fg.frame((osteps - 1) % K), pipe.fg.frame((args.steps - 1) % K)))
+            native_check = {"gather": "torch" if use_native else "native (vrt_gather_tiles: ncclGather on the march stream)",
+                            "ms_per_frame": round(eo / osteps * 1e3, 4), "same_frame_as_timed_run": same}
+            del other
+        except Exception as e:
+            native_check = {"error": repr(e)}
     latency = end_to_end = config4 = None
     if not args.no_extra_legs and args.steps > 0:
         lsteps = max(min(args.steps, 50), 5)
         # one frame in flight: what an application that waits for every frame sees
-        p1 = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, 1, rehearsal)
+        p1 = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, 1, rehearsal, native=use_native)
         e1 = timed_run(p1, lsteps, 3, world, cdev)
         k1 = r.timing_history(lsteps)
         latency = {"frames_in_flight": 1, "ms_per_frame": round(e1 / lsteps * 1e3, 4), "value": round(rays_per_frame * lsteps / e1 / 1e6, 2),
@@ -376,7 +431,7 @@ def main() -> None:
             W4, H4 = 3840, 2160
             p4 = params(W4, H4)
             r.ResizeRenderOutput(W4, H4)
-            pipe4 = Pipeline(r, p4, W4, H4, world, rank, dev, rgba8, strip_rows, K, rehearsal)
+            pipe4 = Pipeline(r, p4, W4, H4, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=use_native)
             s4 = max(lsteps // 2, 5)
             e4 = timed_run(pipe4, s4, 3, world, cdev)
             c4 = job_counts(r.last_timing())
@@ -429,6 +484,9 @@ def main() -> None:
             "roofline": roofline, "cpu_baseline": cpu,
             "latency": latency, "end_to_end": end_to_end, "config4": config4,
         }
+        if world > 1:
+            out["gather"] = "native (vrt_gather_tiles: ncclGather on the march stream)" if use_native else "torch.distributed.gather (RCCL)"
+            out["native_gather_check"] = native_check if native_check is not None else ({"error": native_error} if native_error else None)
         if verified is not None:
             out["gathered_frame_equals_single_gpu_frame"] = verified
         print(json.dumps(out), flush=True)

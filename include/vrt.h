@@ -198,8 +198,10 @@ typedef struct vrt_timing {
 
 typedef struct vrt_ctx vrt_ctx;
 
-/* device_count >= 1; devices[i] are HIP ordinals.  One context may drive 1..8 devices: the
- * framebuffer is split into contiguous row tiles, volumes are replicated. */
+/* device_count >= 1; devices[i] are HIP ordinals.  One context may drive 1..8 devices: vrt_render deals the frame's 32-row
+ * strips round-robin to them (device g renders strips g, g+n, ...; contiguous tiles would put every object row on the middle
+ * devices), volumes are replicated, and every device copies its strips into device 0's frame over the peer links as soon as
+ * its own march is done.  One process per GPU uses vrt_render_strips + vrt_gather_tiles instead. */
 int vrt_create(vrt_ctx** out, int device_count, const int* devices);
 int vrt_destroy(vrt_ctx* ctx);
 
@@ -285,6 +287,23 @@ int vrt_render_rows(vrt_ctx* ctx, const vrt_params* params, int row0, int rows,
  * DXRenderer.cpp:827-867 — the reference is single-adapter, NodeMask 0.) */
 int vrt_render_strips(vrt_ctx* ctx, const vrt_params* params, int strip_rows, int first_strip,
                       int strip_stride, int n_strips, void* device_rgba, void* hip_stream);
+
+/* ---- multi-GPU exchange (one process per GPU) --------------------------------------------------------------------------
+ * The reference is single-adapter (every D3D12 object is created with NodeMask 0, DXRenderer.cpp:253); the frame of this
+ * build shards by rows / interleaved strips (vrt_render_rows / vrt_render_strips above), volumes replicated, and ONE
+ * collective per frame brings the tiles to rank `root`: RCCL's ncclGather over xGMI (rccl.h:745), resolved from librccl at
+ * run time (the library loads without it; these entry points then return VRT_ERR_UNSUPPORTED).
+ *   vrt_comm_unique_id   rank 0 makes the 128-byte communicator id (ncclGetUniqueId) and hands it to the other ranks by
+ *                        any means of the application (torch.distributed broadcast, MPI, a file)
+ *   vrt_comm_init        every rank: ncclCommInitRank on the context's first device; collective, blocks until all joined
+ *   vrt_gather_tiles     asynchronously on hip_stream: every rank contributes tile_bytes from device_tile; on `root`,
+ *                        device_frame receives world x tile_bytes, rank-major (other ranks pass NULL).  In-order with the
+ *                        march launches of the same stream: no host synchronisation */
+#define VRT_COMM_ID_BYTES 128
+int vrt_comm_unique_id(void* id_out);
+int vrt_comm_init(vrt_ctx* ctx, int world, int rank, const void* id);
+int vrt_comm_destroy(vrt_ctx* ctx);
+int vrt_gather_tiles(vrt_ctx* ctx, const void* device_tile, void* device_frame_or_null, size_t tile_bytes, int root, void* hip_stream);
 
 /* Pipelined rendering — the reference keeps FrameCount = 3 frames in flight and paces them with fences
  * (DXConstants.cpp:23, DXRenderer.cpp:974-989); a frame's last third is a few latency-bound waves, which the next frame's

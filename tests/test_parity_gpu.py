@@ -652,6 +652,41 @@ def test_bench_two_rank_rehearsal(oracle_lib):
     assert bad.returncode != 0 and "refusing" in bad.stderr
 
 
+def test_native_tile_gather_with_one_rank(oracle_lib):
+    """vrt_comm_unique_id / vrt_comm_init / vrt_gather_tiles — RCCL's ncclGather behind the C-ABI, resolved from librccl at
+    run time — with the one rank this box has: the gather enqueued on the march stream right behind vrt_render_strips must
+    deliver the tile bytes into the frame buffer (world 1: rank-major = the tile itself), without a host synchronisation
+    in between.  (With N > 1 the same call sequence runs in bench.py --gather native / native_gather_check.)"""
+    import torch
+
+    sc = scenes.config2_sphere(5, 16)
+    p = v.default_params(160, 96, scenes.min_cell(sc), 128)
+    p.flags |= _abi.FLAG_OUTPUT_RGBA8
+    r = v.VHipRenderer()
+    assert r.Start()
+    try:
+        r.SetSceneToRender(sc)
+        r.SyncWithScene()
+        uid = v.VHipRenderer.comm_unique_id()
+        assert len(uid) == _abi.VRT_COMM_ID_BYTES and any(uid)
+        r.comm_init(1, 0, uid)
+        with pytest.raises(_abi.VrtError):
+            r.comm_init(1, 0, uid)  # one communicator per context
+        stream = torch.cuda.Stream()
+        tile = torch.zeros((96, 160, 4), dtype=torch.uint8, device="cuda:0")
+        frame = torch.zeros_like(tile)
+        with torch.cuda.stream(stream):
+            r.render_strips(p, 32, 0, 1, 3, tile.data_ptr(), stream.cuda_stream)
+            r.gather_tiles(tile.data_ptr(), frame.data_ptr(), tile.numel(), 0, stream.cuda_stream)
+        torch.cuda.synchronize()
+        assert int(frame.sum()) > 0 and torch.equal(frame, tile)
+        whole = np.empty((96, 160, 4), np.uint8)
+        _abi.check(r._lib.vrt_render(r._ctx, C.byref(p), whole.ctypes.data_as(C.c_void_p)), "vrt_render")
+        assert np.array_equal(frame.cpu().numpy(), whole)
+    finally:
+        r.Stop()
+
+
 def test_frames_in_flight_keep_their_own_scene(oracle_lib):
     """vrt_render_begin / vrt_render_end (the reference's three frames in flight, DXConstants.cpp:23): frame i is begun,
     then the objects, the camera, a light and a material are already changed for frame i+1 (vrt_scene_set,

@@ -17,6 +17,7 @@ VRT_MAX_POINT_LIGHTS = 5
 VRT_MAX_SPOT_LIGHTS = 5
 VRT_MAX_INSTANCES = 64
 VRT_MAX_DEVICES = 8
+VRT_COMM_ID_BYTES = 128
 
 VRT_OK = 0
 VRT_ERR_INVALID = -1
@@ -165,6 +166,10 @@ SYMBOLS = {
     "vrt_render": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_void_p]),
     "vrt_render_rows": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vrt_render_strips": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vrt_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "vrt_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vrt_comm_destroy": (C.c_int, [C.c_void_p]),
+    "vrt_gather_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "vrt_render_begin": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int]),
     "vrt_render_end": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "vrt_last_timing": (C.c_int, [C.c_void_p, C.POINTER(vrt_timing)]),

@@ -11,6 +11,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -29,6 +30,35 @@
 using namespace vrt;
 
 namespace {
+
+/* RCCL, resolved at run time (librccl is not a link-time dependency: the library loads on hosts without it).  Only what
+   the tile gather needs; signatures from /opt/rocm/include/rccl/rccl.h:187,220,260,339,745. */
+struct RcclApi {
+    typedef struct { char internal[VRT_COMM_ID_BYTES]; } UniqueId;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    int (*Gather)(const void*, void*, size_t, int /*ncclDataType_t*/, int, void*, hipStream_t) = nullptr;
+    bool ok = false;
+};
+RcclApi* rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.ok ? &api : nullptr;
+    tried = true;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) /* the copy a host application (e.g. PyTorch) already mapped wins */
+        if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+    if (!h) return nullptr;
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    api.Gather = reinterpret_cast<decltype(api.Gather)>(dlsym(h, "ncclGather"));
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GetErrorString && api.Gather;
+    return api.ok ? &api : nullptr;
+}
 
 constexpr int kStatSlots = 4; /* launches that may be in flight at once without sharing a counter buffer */
 constexpr int kRing = 256; /* per-launch event pairs + stat slots kept for vrt_timing_history */
@@ -142,6 +172,8 @@ struct vrt_ctx {
     float last_gather_ms = 0.f, last_total_ms = 0.f;
     float* gather = nullptr; /* full frame on device 0 (multi-device only) */
     size_t gather_bytes = 0;
+    void* comm = nullptr;    /* ncclComm_t of vrt_comm_init (one process per GPU) */
+    int comm_world = 0, comm_rank = 0;
 };
 
 namespace {
@@ -671,7 +703,8 @@ void cull_rect(const vrt_ctx* ctx, const vrt_params* p, DFrame& F) {
         for (int a = 0; a < 3; a++) {
             lo[a] = -(double)h.extent;
             hi[a] = (double)h.extent;
-            if (h.step_max > 0.0f) { /* the march is clipped to the active box; a little slack for its float rounding */
+            if (h.step_max > 0.0f && p->mode < VRT_MODE_CUBE) { /* the sphere-trace is clipped to the active box (a little slack for
+                                                                   its float rounding); the Cube modes visit the whole volume box */
                 const int ax = a == 0 ? 0 : (a == 1 ? 2 : 1);
                 lo[a] = std::max(lo[a], (double)(h.abox[ax] * kBrickCells) * cell - (double)h.extent - 0.01 * cell);
                 hi[a] = std::min(hi[a], (double)std::min((h.abox[3 + ax] + 1) * kBrickCells, h.N - 1) * cell - (double)h.extent + 0.01 * cell);
@@ -864,6 +897,7 @@ int vrt_create(vrt_ctx** out, int device_count, const int* devices) {
 
 int vrt_destroy(vrt_ctx* ctx) {
     if (!ctx) return VRT_ERR_INVALID;
+    (void)vrt_comm_destroy(ctx);
     for (auto& D : ctx->dev) {
         if (hipSetDevice(D.ordinal) == hipSuccess) (void)hipDeviceSynchronize();
     }
@@ -1188,13 +1222,9 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
 
     float gather_ms = 0.f;
     if (n > 1) {
-        /* wait for the kernels, then gather every strip into device 0's frame over the peer links (the copies of
-           one source device go in its own stream, all devices concurrently) */
-        for (int g = 0; g < n; g++) {
-            HIP_TRY(hipSetDevice(ctx->dev[(size_t)g].ordinal));
-            HIP_TRY(hipStreamSynchronize(ctx->dev[(size_t)g].stream));
-        }
-        auto g0 = std::chrono::steady_clock::now();
+        /* every device copies its strips into device 0's frame over the peer links right behind its own march, in its own
+           stream: no host synchronisation between march and gather, a device that is done early transfers while the others
+           still march.  gather_ms = what the frame waits for after the slowest march has finished. */
         for (int g = 0; g < n; g++) {
             DeviceState& D = ctx->dev[(size_t)g];
             HIP_TRY(hipSetDevice(D.ordinal));
@@ -1207,11 +1237,16 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
                 HIP_TRY(hipMemcpyPeerAsync(dst, ctx->dev[0].ordinal, src, D.ordinal, (size_t)rows * row_bytes, D.stream));
             }
         }
+        float march_ms = 0.f;
         for (int g = 0; g < n; g++) {
-            HIP_TRY(hipSetDevice(ctx->dev[(size_t)g].ordinal));
-            HIP_TRY(hipStreamSynchronize(ctx->dev[(size_t)g].stream));
+            DeviceState& D = ctx->dev[(size_t)g];
+            HIP_TRY(hipSetDevice(D.ordinal));
+            HIP_TRY(hipStreamSynchronize(D.stream));
+            float ms = 0.f;
+            if (D.timed[ring] && hipEventElapsedTime(&ms, D.ev0[ring], D.ev1[ring]) == hipSuccess) march_ms = std::max(march_ms, ms);
         }
-        gather_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - g0).count();
+        const float all_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        gather_ms = std::max(0.f, all_ms - march_ms);
         if (host_rgba_or_null) {
             HIP_TRY(hipSetDevice(ctx->dev[0].ordinal));
             HIP_TRY(hipMemcpy(host_rgba_or_null, ctx->gather, (size_t)H * row_bytes, hipMemcpyDeviceToHost));
@@ -1225,6 +1260,68 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
     }
     ctx->last_gather_ms = gather_ms;
     ctx->last_total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return VRT_OK;
+}
+
+int vrt_comm_unique_id(void* id_out) {
+    if (!id_out) return VRT_ERR_INVALID;
+    RcclApi* R = rccl();
+    if (!R) return VRT_ERR_UNSUPPORTED;
+    RcclApi::UniqueId id;
+    const int rc = R->GetUniqueId(&id);
+    if (rc != 0) {
+        fprintf(stderr, "[vrt] ncclGetUniqueId failed: %s\n", R->GetErrorString(rc));
+        return VRT_ERR_HIP;
+    }
+    memcpy(id_out, id.internal, VRT_COMM_ID_BYTES);
+    return VRT_OK;
+}
+
+int vrt_comm_init(vrt_ctx* ctx, int world, int rank, const void* id) {
+    if (!ctx || !id || world < 1 || rank < 0 || rank >= world || ctx->comm) return VRT_ERR_INVALID;
+    RcclApi* R = rccl();
+    if (!R) return VRT_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->dev[0].ordinal));
+    RcclApi::UniqueId uid;
+    memcpy(uid.internal, id, VRT_COMM_ID_BYTES);
+    void* comm = nullptr;
+    const int rc = R->CommInitRank(&comm, world, uid, rank);
+    if (rc != 0) {
+        fprintf(stderr, "[vrt] ncclCommInitRank failed: %s\n", R->GetErrorString(rc));
+        return VRT_ERR_HIP;
+    }
+    ctx->comm = comm;
+    ctx->comm_world = world;
+    ctx->comm_rank = rank;
+    return VRT_OK;
+}
+
+int vrt_comm_destroy(vrt_ctx* ctx) {
+    if (!ctx) return VRT_ERR_INVALID;
+    if (!ctx->comm) return VRT_OK;
+    RcclApi* R = rccl();
+    if (R) {
+        (void)hipSetDevice(ctx->dev[0].ordinal);
+        (void)hipDeviceSynchronize();
+        (void)R->CommDestroy(ctx->comm);
+    }
+    ctx->comm = nullptr;
+    return VRT_OK;
+}
+
+int vrt_gather_tiles(vrt_ctx* ctx, const void* device_tile, void* device_frame_or_null, size_t tile_bytes, int root, void* hip_stream) {
+    if (!ctx || !ctx->comm) return VRT_ERR_NOT_READY;
+    if (root < 0 || root >= ctx->comm_world || (!device_tile && tile_bytes > 0) ||
+        (ctx->comm_rank == root && !device_frame_or_null && tile_bytes > 0))
+        return VRT_ERR_INVALID;
+    RcclApi* R = rccl();
+    if (!R) return VRT_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->dev[0].ordinal));
+    const int rc = R->Gather(device_tile, device_frame_or_null, tile_bytes, 1 /* ncclUint8 */, root, ctx->comm, static_cast<hipStream_t>(hip_stream));
+    if (rc != 0) {
+        fprintf(stderr, "[vrt] ncclGather failed: %s\n", R->GetErrorString(rc));
+        return VRT_ERR_HIP;
+    }
     return VRT_OK;
 }
 

@@ -225,6 +225,28 @@ class VHipRenderer:
         buf = (C.c_float * (params.width * params.height * 4)).from_address(ptr.value)
         return np.frombuffer(buf, dtype=np.float32).reshape(params.height, params.width, 4).copy()
 
+    # -- multi-GPU exchange, one process per GPU (vrt_comm_* / vrt_gather_tiles: RCCL ncclGather) --------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0: the 128-byte communicator id to hand to every rank (vrt_comm_unique_id)."""
+        buf = (C.c_uint8 * _abi.VRT_COMM_ID_BYTES)()
+        _abi.check(_abi.load().vrt_comm_unique_id(buf), "vrt_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, world: int, rank: int, unique_id: bytes) -> None:
+        """Every rank (collective): join the communicator of `unique_id` on this renderer's device."""
+        self._require()
+        if len(unique_id) != _abi.VRT_COMM_ID_BYTES:
+            raise ValueError("unique_id must be VRT_COMM_ID_BYTES long")
+        buf = (C.c_uint8 * _abi.VRT_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _abi.check(self._lib.vrt_comm_init(self._ctx, int(world), int(rank), buf), "vrt_comm_init")
+
+    def gather_tiles(self, tile_ptr: int, frame_ptr: int, tile_bytes: int, root: int = 0, stream: int = 0) -> None:
+        """Asynchronous ncclGather of this rank's device tile into rank `root`'s device frame (rank-major)."""
+        self._require()
+        _abi.check(self._lib.vrt_gather_tiles(self._ctx, C.c_void_p(tile_ptr), C.c_void_p(frame_ptr) if frame_ptr else None, int(tile_bytes),
+                                              int(root), C.c_void_p(stream)), "vrt_gather_tiles")
+
     def last_timing(self) -> dict:
         self._require()
         t = _abi.vrt_timing()

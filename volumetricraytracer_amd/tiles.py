@@ -8,9 +8,10 @@ Two partitions, both seamless because every rank renders from global pixel coord
            into a compact tile (`vrt_render_strips`).  Contiguous tiles put every object row on the
            middle GPUs and sky on the outer ones; interleaving evens the load (SURVEY §8e "risk").
 
-The tiles are equal-sized buffers gathered with ONE collective (`torch.distributed.gather`; backend
-"nccl" is RCCL over xGMI on MI355X, "gloo" on CPU for tests).  For strips rank 0 then un-shuffles the
-gathered [rank, strip] order into frame order with one strided device copy."""
+The tiles are equal-sized buffers gathered with ONE collective: `torch.distributed.gather` (backend
+"nccl" is RCCL over xGMI on MI355X, "gloo" on CPU for tests), or — `native_gather` — the C-ABI's own
+`vrt_gather_tiles` (ncclGather on the march stream, no torch in the data path).  For strips rank 0 then
+un-shuffles the gathered [rank, strip] order into frame order with one strided device copy."""
 from __future__ import annotations
 
 from typing import List, Optional, Tuple
@@ -86,6 +87,16 @@ class FrameGather:
         if self.rank == 0:
             glist = [self.frames[b][k * self.rows_per:(k + 1) * self.rows_per] for k in range(self.world)]
         return dist.gather(self.tiles[b], glist, dst=0, async_op=async_op)
+
+    def native_gather(self, renderer, b: int, stream: int = 0) -> None:
+        """The same gather through the C-ABI (vrt_gather_tiles: ncclGather of the raw tile bytes), enqueued on HIP stream
+        `stream` behind the march that produced tile buffer `b`.  The renderer must have joined a communicator
+        (VHipRenderer.comm_init) of `world` ranks."""
+        tile = self.tiles[b]
+        frame_ptr = self.frames[b].data_ptr() if self.rank == 0 and self.frames is not None else 0
+        if self.world == 1:
+            return
+        renderer.gather_tiles(tile.data_ptr(), frame_ptr, tile.numel() * tile.element_size(), 0, stream)
 
     def unshuffle(self, b: int) -> None:
         """Strips, rank 0: gathered [rank, strip, row] order → frame order, one strided copy on the
