@@ -50,7 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3sdf", "c4", "c5"])
-    ap.add_argument("--path", default="auto", choices=["auto", "dense", "brick", "lds"])
+    ap.add_argument("--path", default="auto", choices=["auto", "dense", "brick", "lds", "cells"])
     ap.add_argument("--format", default="auto", choices=["auto", "f32", "texel16"],
                     help="device volume format: f32 bricks, or the reference's 16-bit texel (sign + 15-bit |d|*100)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -331,7 +331,7 @@ def main() -> None:
     rgba8 = args.output == "rgba8" or (args.output == "auto" and world > 1)
     strip_rows = args.strip_rows if world > 1 else 0
     K = args.frames_in_flight or 3  # FrameCount, DXConstants.cpp:23
-    path = {"auto": _abi.PATH_AUTO, "dense": _abi.PATH_DENSE, "brick": _abi.PATH_BRICK, "lds": _abi.PATH_BRICK_LDS}[args.path]
+    path = {"auto": _abi.PATH_AUTO, "dense": _abi.PATH_DENSE, "brick": _abi.PATH_BRICK, "lds": _abi.PATH_BRICK_LDS, "cells": _abi.PATH_CELLS}[args.path]
     fmt = {"auto": workloads.BENCH_VOLUME_FORMAT, "f32": _abi.FORMAT_F32, "texel16": _abi.FORMAT_TEXEL16}[args.format]
     for vol in sc.volumes():
         vol.set_device_format(fmt)

@@ -83,7 +83,10 @@ enum vrt_data_path {
     VRT_PATH_AUTO = 0,
     VRT_PATH_DENSE = 1,       /* taps from the dense N^3 grid in global memory */
     VRT_PATH_BRICK = 2,       /* taps from 4^3-cell (5^3-sample) bricks in global memory */
-    VRT_PATH_BRICK_LDS = 3    /* bricks staged through a per-wave LDS brick cache */
+    VRT_PATH_BRICK_LDS = 3,   /* bricks staged through a per-wave LDS brick cache */
+    VRT_PATH_CELLS = 4        /* VRT_FORMAT_TEXEL16 volumes only (others: VRT_PATH_BRICK): taps from 16-byte cell records — every cell
+                                 keeps its own 8 corner texels, one aligned 16-byte load per sample instead of four 4-byte ones,
+                                 for 4x the bytes of the int16 bricks */
 };
 
 /* How a volume's densities are kept on the device (per upload, vrt_set_volume_format). */
@@ -322,7 +325,9 @@ int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out);
 int vrt_timing_history(vrt_ctx* ctx, int n, float* kernel_ms_out);
 
 /* Diagnostics: per-wave records of the last launch on the first device, 8 words each, record
- * index = blockIdx*4 + wave.  which = 0: counters {primary_rays, shadow_rays, bounce_rays,
+ * index = blockIdx*4 + wave, for the waves of the launch's march region (the tiles that touch the screen rectangle of the
+ * instances; the sky around it is written by a streaming kernel without records, its rays are added to
+ * vrt_timing::primary_rays).  which = 0: counters {primary_rays, shadow_rays, bounce_rays,
  * primary_steps, shadow_steps, hits, exhausted_rays, 0}.  which = 1 (only after a VRT_FLAG_DIAG_TIMELINE launch):
  * {start, end (100 MHz ticks), iterations whose taps were back within 450 cycles, XCC_ID | HW_ID<<4, longest
  * per-lane sample chain, tap-fetch cycles, march-loop cycles, march-loop iterations} of the lane with the longest

@@ -252,7 +252,7 @@ def test_voxelizer_cli_on_the_device_writes_the_same_file(tmp_path):
 
 
 @pytest.mark.parametrize("fmt", [_abi.FORMAT_F32, _abi.FORMAT_TEXEL16])
-@pytest.mark.parametrize("path", [_abi.PATH_BRICK, _abi.PATH_DENSE, _abi.PATH_BRICK_LDS])
+@pytest.mark.parametrize("path", [_abi.PATH_BRICK, _abi.PATH_DENSE, _abi.PATH_BRICK_LDS, _abi.PATH_CELLS])
 def test_shell_volume_paths_and_formats_parity(renderer, oracle_lib, path, fmt):
     """Voxelizer shell volumes march with the two-level empty-space table (brick bytes + sub-block nibbles) and never
     sample where it shows no active cell.  Every data path (int16 bricks when the volume is in the reference's texel
@@ -312,7 +312,7 @@ def test_reference_texel_upload_is_the_texel16_format(renderer, oracle_lib):
 
 
 @pytest.mark.parametrize("fmt,path", [(_abi.FORMAT_F32, _abi.PATH_BRICK), (_abi.FORMAT_F32, _abi.PATH_DENSE), (_abi.FORMAT_F32, _abi.PATH_BRICK_LDS),
-                                      (_abi.FORMAT_TEXEL16, _abi.PATH_BRICK)])
+                                      (_abi.FORMAT_TEXEL16, _abi.PATH_BRICK), (_abi.FORMAT_TEXEL16, _abi.PATH_CELLS)])
 def test_bench_volume_parity(renderer, oracle_lib, path, fmt):
     """The volume bench.py marches — BASELINE config 3: the 256^3 Voxelizer shell of the torus mesh, shadow ray on — at
     640x360 on every data path and in both device formats: pixels <= 1e-4 on all pixels, all seven counters exact."""

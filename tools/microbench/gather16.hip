@@ -68,6 +68,27 @@ __global__ __launch_bounds__(256) void gather16_kernel(const char* __restrict__ 
     out[gid] = acc;
 }
 
+// Variant C: "cell records" — every cell keeps its own 8 corner values as 8 x int16 = 16 B (64 cells = 1 KB per brick, 4x
+// the bytes of the int16 brick): ONE aligned global_load_dwordx4 per sample.
+__global__ __launch_bounds__(256) void gather_cells16_kernel(const uint4v* __restrict__ cells, unsigned nbricks_mask, int iters, float* __restrict__ out) {
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned state = gid * 2654435761u + 12345u;
+    unsigned brick = (gid >> 6) * 97u;
+    float acc = 0.0f;
+    const float fx = 0.3f, fy = 0.6f, fz = 0.2f;
+    for (int i = 0; i < iters; i++) {
+        state = state * 1664525u + 1013904223u;
+        const unsigned lx = (state >> 8) & 3u, ly = (state >> 12) & 3u, lz = (state >> 16) & 3u;
+        if (((state >> 20) & 7u) == 0u) brick += 1u + ((state >> 24) & 3u);
+        const unsigned b = brick & nbricks_mask;
+        const uint4v u = cells[((size_t)b << 6) + (lx * 16u + lz * 4u + ly)];
+        const float a00 = lerp1(lo16(u.x), hi16(u.x), fy), a01 = lerp1(lo16(u.y), hi16(u.y), fy), a10 = lerp1(lo16(u.z), hi16(u.z), fy),
+                    a11 = lerp1(lo16(u.w), hi16(u.w), fy);
+        acc += lerp1(lerp1(a00, a01, fz), lerp1(a10, a11, fz), fx);
+    }
+    out[gid] = acc;
+}
+
 __global__ __launch_bounds__(256) void gather32_kernel(const float* __restrict__ bricks, unsigned nbricks_mask, int iters, float* __restrict__ out) {
     const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned state = gid * 2654435761u + 12345u;
@@ -158,13 +179,17 @@ int main(int argc, char** argv) {
         hipMemset(b16, 0, (size_t)c.nbricks * 256 + 64);
         hipMalloc(&b32, (size_t)c.nbricks * 512);
         hipMemset(b32, 0, (size_t)c.nbricks * 512);
-        for (int variant = 0; variant < 3; variant++) {
+        uint4v* c16;
+        hipMalloc(&c16, (size_t)c.nbricks * 1024);
+        hipMemset(c16, 0, (size_t)c.nbricks * 1024);
+        for (int variant = 0; variant < 4; variant++) {
             float best = 1e30f;
             for (int rep = 0; rep < 5; rep++) {
                 hipEventRecord(e0);
                 if (variant == 0) hipLaunchKernelGGL(gather16_kernel<0>, dim3(blocks), dim3(threads), 0, 0, b16, c.nbricks - 1, iters, out);
                 else if (variant == 1) hipLaunchKernelGGL(gather16_kernel<1>, dim3(blocks), dim3(threads), 0, 0, b16, c.nbricks - 1, iters, out);
-                else hipLaunchKernelGGL(gather32_kernel, dim3(blocks), dim3(threads), 0, 0, b32, c.nbricks - 1, iters, out);
+                else if (variant == 2) hipLaunchKernelGGL(gather32_kernel, dim3(blocks), dim3(threads), 0, 0, b32, c.nbricks - 1, iters, out);
+                else hipLaunchKernelGGL(gather_cells16_kernel, dim3(blocks), dim3(threads), 0, 0, c16, c.nbricks - 1, iters, out);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float ms;
@@ -172,11 +197,13 @@ int main(int argc, char** argv) {
                 if (rep > 0 && ms < best) best = ms;
             }
             const double samples = (double)blocks * threads * iters;
-            const char* vn[] = {"int16 bricks, 4 x dword (2-byte aligned)", "int16 bricks, 2 x dwordx4 (2-byte aligned)", "fp32 bricks, 4 x dwordx2 (round 1)"};
+            const char* vn[] = {"int16 bricks, 4 x dword (2-byte aligned)", "int16 bricks, 2 x dwordx4 (2-byte aligned)", "fp32 bricks, 4 x dwordx2 (round 1)",
+                                "int16 cell records, 1 x dwordx4 (4x bytes)"};
             printf("%-32s %-44s %8.3f ms  %7.1f Gsamples/s\n", c.name, vn[variant], best, samples / best / 1e6);
         }
         hipFree(b16);
         hipFree(b32);
+        hipFree(c16);
     }
     return 0;
 }

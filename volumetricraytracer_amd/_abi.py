@@ -48,6 +48,7 @@ PATH_AUTO = 0
 PATH_DENSE = 1
 PATH_BRICK = 2
 PATH_BRICK_LDS = 3
+PATH_CELLS = 4
 
 
 class vrt_voxel(C.Structure):

@@ -14,9 +14,10 @@ constexpr int kBrickSamples = 5;               /* samples per brick edge (cells 
 constexpr int kBrickFloats = 128;              /* 125 samples padded to 128 per brick record: 512 B (fp32) = four 128-B lines,
                                                   256 B (int16, VRT_FORMAT_TEXEL16) = two */
 /* Internal data paths (template parameter of the march kernels).  1-3 are vrt_data_path's values. */
-constexpr int kPathCube = 4;                   /* Cube render modes on fp32 bricks (bricks + cube_skip, exact grid traversal) */
-constexpr int kPathBrick16 = 5;                /* VRT_PATH_BRICK on a VRT_FORMAT_TEXEL16 volume: int16 bricks */
-constexpr int kPathCube16 = 6;                 /* Cube render modes on int16 bricks */
+constexpr int kPathCube = 8;                   /* Cube render modes on fp32 bricks (bricks + cube_skip, exact grid traversal) */
+constexpr int kPathBrick16 = 9;                /* VRT_PATH_BRICK on a VRT_FORMAT_TEXEL16 volume: int16 bricks */
+constexpr int kPathCube16 = 10;                /* Cube render modes on int16 bricks */
+constexpr int kPathCells16 = 11;               /* VRT_PATH_CELLS: int16 cell records (VRT_FORMAT_TEXEL16 volumes) */
 constexpr int kNibWindow = 16;                 /* reach, in cells, of the sub-block distance transform (nibbles cap at 15) */
 constexpr int kTile = 8;                       /* one wave = 8x8 pixels */
 constexpr int kBlockThreads = 256;             /* 4 waves = 16x16 pixels */
@@ -43,6 +44,8 @@ struct DVolume {
     const float* dense;    /* N^3 fp32, index x*N*N + z*N + y (VRT_FORMAT_TEXEL16: the integer field +-q as floats) */
     const void* bricks;    /* nb^3 brick records x 128 samples (fp32, or int16 for VRT_FORMAT_TEXEL16), brick (bx,bz,by)
                               major like the dense grid, in-brick index lx*25 + lz*5 + ly */
+    const void* cells;     /* VRT_FORMAT_TEXEL16: nb^3 x 64 cell records of 8 int16 (the cell's corners in tap order: (x,z) = 00, 01, 10, 11,
+                              y then y+1), cell (lx,lz,ly) of a brick at record lx*16 + lz*4 + ly; else null */
     int32_t N;
     int32_t nb;
     float extent;
@@ -133,7 +136,10 @@ struct DFrame {
     /* frame geometry */
     int32_t width, height;
     int32_t row0, rows;        /* this launch renders rows [row0,row0+rows) */
-    int32_t tiles_x, tiles_y;  /* 16x16-pixel blocks covering width x rows */
+    int32_t tiles_x, tiles_y;  /* size, in 16x16-pixel tiles, of the MARCH REGION of this launch: the tiles that touch the cull
+                                  rectangle below.  The march kernels run over it; every pixel outside it is sky and is written
+                                  by sky_kernel */
+    int32_t tile_x0, tile_y0;  /* origin of the march region in the launch's local tile grid */
     int32_t tile_map;          /* kMapSupertile / kMapBand / kMapLinear */
     int32_t diag;              /* 1: diagnostic kernel build that stamps per-wave timeline records */
     int32_t full;              /* 1: full closest hit needed (point/spot lights, or bounces allowed and a smooth material in the scene) */

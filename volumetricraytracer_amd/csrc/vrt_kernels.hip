@@ -78,13 +78,13 @@ struct VolRef {
 /* Where the taps of an internal path come from. */
 template <int PATH>
 __device__ __host__ constexpr int data_path() {
-    return PATH == VRT_PATH_DENSE ? VRT_PATH_DENSE : (PATH == kPathBrick16 || PATH == kPathCube16) ? kPathBrick16 : VRT_PATH_BRICK;
+    return PATH == VRT_PATH_DENSE ? VRT_PATH_DENSE : PATH == kPathCells16 ? kPathCells16 : (PATH == kPathBrick16 || PATH == kPathCube16) ? kPathBrick16 : VRT_PATH_BRICK;
 }
 
 template <int DP>
 __device__ __forceinline__ VolRef load_vol(const DVolume* __restrict__ v) {
     VolRef r;
-    r.p = (gchar_p)((DP == VRT_PATH_DENSE) ? (const void*)v->dense : v->bricks);
+    r.p = (gchar_p)((DP == VRT_PATH_DENSE) ? (const void*)v->dense : (DP == kPathCells16) ? v->cells : v->bricks);
     r.skip = (gbyte_p)v->skip;
     r.nib = (guint_p)v->nib;
     r.cube = (gbyte_p)v->cube_skip;
@@ -166,7 +166,24 @@ __device__ __forceinline__ Taps fetch8_brick16(const VolRef& V, unsigned brick, 
     return t;
 }
 
-/* Fetch the taps of cell (cx,cy,cz) on data path DP (VRT_PATH_DENSE, VRT_PATH_BRICK or kPathBrick16).  Offsets are
+/* Taps of a cell from its 16-byte cell record (VRT_PATH_CELLS): ONE aligned dwordx4. */
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Taps fetch8_cells16(const VolRef& V, unsigned brick, int cx, int cy, int cz) {
+    const unsigned rec = (brick << 6) + (((unsigned)cx & 3u) << 4) + (((unsigned)cz & 3u) << 2) + ((unsigned)cy & 3u);
+    const uint4v w = *(const uint4v __attribute__((address_space(1)))*)(V.p + ((size_t)rec << 4));
+    Taps t;
+    t.y00a = lo16f(w.x);
+    t.y00b = hi16f(w.x);
+    t.y01a = lo16f(w.y);
+    t.y01b = hi16f(w.y);
+    t.y10a = lo16f(w.z);
+    t.y10b = hi16f(w.z);
+    t.y11a = lo16f(w.w);
+    t.y11b = hi16f(w.w);
+    return t;
+}
+
+/* Fetch the taps of cell (cx,cy,cz) on data path DP (VRT_PATH_DENSE, VRT_PATH_BRICK, kPathBrick16 or kPathCells16).  Offsets are
  * unsigned 32-bit byte offsets from the volume base (<= 4 GiB pools), built with 24-bit multiplies (cells < 2^10,
  * bricks < 2^24). */
 template <int DP>
@@ -188,6 +205,8 @@ __device__ __forceinline__ Taps fetch8_at(const VolRef& V, unsigned brick, int c
         return t;
     } else if constexpr (DP == kPathBrick16) {
         return fetch8_brick16(V, brick, cx, cy, cz);
+    } else if constexpr (DP == kPathCells16) {
+        return fetch8_cells16(V, brick, cx, cy, cz);
     } else {
         return fetch8_brick(V, brick, cx, cy, cz);
     }
@@ -1098,10 +1117,10 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel(const DFrame F) {
     int tile_x, tile_y;
     tile_of_block(F, b, (int)gridDim.x / kMarchGridMul, tile_x, tile_y);
     const int lane = (int)threadIdx.x & 63;
-    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int px = (tile_x + F.tile_x0) * 16 + (wave & 1) * 8 + (lane & 7);
+    const int pyl = (tile_y + F.tile_y0) * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int py = frame_row(F, pyl);
-    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows && py < F.height;
+    const bool valid = tile_x < F.tiles_x && tile_y < F.tiles_y && px < F.width && pyl < F.rows && py < F.height;
 
     Counters k;
     DiagAcc dg;
@@ -1136,6 +1155,45 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel(const DFrame F) {
         store_pixel(F, px, pyl, color);
     }
     write_records<DIAG, true>(F, b, wave, lane, k, dg, t_start);
+}
+
+/*
+ * Everything outside the march region of a launch (DFrame::tile_x0.., the tiles that touch the cull rectangle) is sky:
+ * VRMiss alone (Raytracing.hlsl:444-449) — camera ray, cube-map texel, tone-map, store; the very functions the march
+ * kernels use for a miss, so the pixels are the same bits.  Four bands around the march region, one pixel per lane,
+ * neighbouring lanes on neighbouring pixels (1 KB of float4 per wave-store).  Four fifths of the benchmark frame: as 8x8
+ * tiles of the march kernel they cost a wave slot for ~4 us each; here they are a streaming pass.
+ */
+__global__ __launch_bounds__(256) void sky_kernel(const DFrame F, int mx0, int mx1, int my0, int my1) {
+    const int W = F.width;
+    const long long n_top = (long long)my0 * W, n_bot = (long long)(F.rows - my1) * W;
+    const long long n_left = (long long)(my1 - my0) * mx0;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int px, pyl;
+    if (i < n_top) {
+        pyl = (int)(i / W);
+        px = (int)(i - (long long)pyl * W);
+    } else if ((i -= n_top) < n_bot) {
+        pyl = (int)(i / W);
+        px = (int)(i - (long long)pyl * W);
+        pyl += my1;
+    } else if ((i -= n_bot) < n_left) {
+        pyl = (int)(i / mx0);
+        px = (int)(i - (long long)pyl * mx0);
+        pyl += my0;
+    } else {
+        i -= n_left;
+        const int wr = W - mx1;
+        if (wr <= 0 || i >= (long long)(my1 - my0) * wr) return;
+        pyl = (int)(i / wr);
+        px = (int)(i - (long long)pyl * wr) + mx1;
+        pyl += my0;
+    }
+    const int py = frame_row(F, pyl);
+    if (pyl >= F.rows || py >= F.height) return;
+    F3 o, d;
+    camera_ray(F, px, py, o, d);
+    store_pixel(F, px, pyl, env_lookup(F.env, F.env_size, d));
 }
 
 /* ---- tri-planar material textures (SH/Include/Textures.hlsli:16-59, Quaternion.hlsli:18-82) ----------
@@ -1242,10 +1300,10 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DFrame 
     int tile_x, tile_y;
     tile_of_block(F, b, (int)gridDim.x / kMarchGridMul, tile_x, tile_y);
     const int lane = (int)threadIdx.x & 63;
-    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int px = (tile_x + F.tile_x0) * 16 + (wave & 1) * 8 + (lane & 7);
+    const int pyl = (tile_y + F.tile_y0) * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int py = frame_row(F, pyl);
-    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows && py < F.height;
+    const bool valid = tile_x < F.tiles_x && tile_y < F.tiles_y && px < F.width && pyl < F.rows && py < F.height;
 
     Counters k;
     DiagAcc dg;
@@ -1532,10 +1590,10 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame 
     tile_of_block(F, b, (int)gridDim.x, tile_x, tile_y);
     const int wave = (int)threadIdx.x >> 6;
     const int lane = (int)threadIdx.x & 63;
-    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int px = (tile_x + F.tile_x0) * 16 + (wave & 1) * 8 + (lane & 7);
+    const int pyl = (tile_y + F.tile_y0) * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int py = frame_row(F, pyl);
-    const bool valid = tile_x < F.tiles_x && px < F.width && pyl < F.rows && py < F.height;
+    const bool valid = tile_x < F.tiles_x && tile_y < F.tiles_y && px < F.width && pyl < F.rows && py < F.height;
 
     float* slots = s_slots[wave];
     unsigned* tags = s_tags[wave];
@@ -1627,6 +1685,29 @@ __global__ __launch_bounds__(128) void retile_bricks16_kernel(const float* __res
         v = (short)(int)dense[((size_t)x * N + z) * N + y]; /* |value| <= 32767, integer: exact */
     }
     bricks[(size_t)brick * kBrickFloats + l] = v;
+}
+
+/* VRT_PATH_CELLS: the 8 corner texels of every cell as one 16-byte record (cells beyond the grid repeat the last sample,
+ * like the bricks' apron). */
+__global__ __launch_bounds__(64) void retile_cells16_kernel(const float* __restrict__ dense, short* __restrict__ cells, int N, int nb) {
+    const int brick = (int)blockIdx.x;
+    const int by = brick % nb, bz = (brick / nb) % nb, bx = brick / (nb * nb);
+    const int l = (int)threadIdx.x; /* record lx*16 + lz*4 + ly */
+    const int lx = l >> 4, lz = (l >> 2) & 3, ly = l & 3;
+    short v[8];
+    for (int k = 0; k < 8; k++) { /* tap order: (x,z) = 00, 01, 10, 11; y then y+1 */
+        int x = bx * 4 + lx + (k >> 2), z = bz * 4 + lz + ((k >> 1) & 1), y = by * 4 + ly + (k & 1);
+        x = x > N - 1 ? N - 1 : x;
+        y = y > N - 1 ? N - 1 : y;
+        z = z > N - 1 ? N - 1 : z;
+        v[k] = (short)(int)dense[((size_t)x * N + z) * N + y];
+    }
+    uint4v w;
+    w.x = (unsigned)(unsigned short)v[0] | ((unsigned)(unsigned short)v[1] << 16);
+    w.y = (unsigned)(unsigned short)v[2] | ((unsigned)(unsigned short)v[3] << 16);
+    w.z = (unsigned)(unsigned short)v[4] | ((unsigned)(unsigned short)v[5] << 16);
+    w.w = (unsigned)(unsigned short)v[6] | ((unsigned)(unsigned short)v[7] << 16);
+    reinterpret_cast<uint4v*>(cells)[(size_t)brick * 64 + l] = w;
 }
 
 /* VRT_FORMAT_TEXEL16: a density as the reference's volume texel keeps it — sign + 15-bit trunc(|d| * 100)
@@ -1911,10 +1992,19 @@ static hipError_t launch_full_t(const DFrame& F, hipStream_t stream) {
 template <int PATH>
 static hipError_t launch_path(const DFrame& F, bool single, bool diag_build, hipStream_t stream) {
     if (F.full) return single ? launch_full_t<PATH, true>(F, stream) : launch_full_t<PATH, false>(F, stream);
-    if constexpr (PATH == VRT_PATH_DENSE || PATH == VRT_PATH_BRICK || PATH == kPathBrick16) {
+    if constexpr (PATH == VRT_PATH_DENSE || PATH == VRT_PATH_BRICK || PATH == kPathBrick16 || PATH == kPathCells16) {
         if (diag_build) return single ? launch_t<PATH, true>(F, stream) : launch_t<PATH, false>(F, stream);
     }
     return single ? launch_nodiag_t<PATH, true>(F, stream) : launch_nodiag_t<PATH, false>(F, stream);
+}
+
+hipError_t launch_sky(const DFrame& F, hipStream_t stream) {
+    const int mx0 = std::min(F.tile_x0 * 16, F.width), mx1 = std::min((F.tile_x0 + F.tiles_x) * 16, F.width);
+    const int my0 = std::min(F.tile_y0 * 16, F.rows), my1 = std::min((F.tile_y0 + F.tiles_y) * 16, F.rows);
+    const long long n = (long long)F.width * F.rows - (long long)(mx1 - mx0) * (my1 - my0);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sky_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, F, mx0, mx1, my0, my1);
+    return hipGetLastError();
 }
 
 hipError_t launch_march(const DFrame& F, int path, bool single, hipStream_t stream) {
@@ -1922,6 +2012,7 @@ hipError_t launch_march(const DFrame& F, int path, bool single, hipStream_t stre
         case kPathCube: return launch_path<kPathCube>(F, single, false, stream);
         case kPathCube16: return launch_path<kPathCube16>(F, single, false, stream);
         case kPathBrick16: return launch_path<kPathBrick16>(F, single, F.diag != 0, stream);
+        case kPathCells16: return launch_path<kPathCells16>(F, single, F.diag != 0, stream);
         case VRT_PATH_DENSE: return launch_path<VRT_PATH_DENSE>(F, single, F.diag != 0, stream);
         case VRT_PATH_BRICK_LDS:
             if (single && !F.full) return launch_coop(F, stream);
@@ -1935,6 +2026,11 @@ hipError_t launch_retile(const float* dense, void* bricks, int format, int N, in
         hipLaunchKernelGGL(retile_bricks16_kernel, dim3((unsigned)(nb * nb * nb)), dim3(128), 0, stream, dense, static_cast<short*>(bricks), N, nb);
     else
         hipLaunchKernelGGL(retile_bricks_kernel, dim3((unsigned)(nb * nb * nb)), dim3(128), 0, stream, dense, static_cast<float*>(bricks), N, nb);
+    return hipGetLastError();
+}
+
+hipError_t launch_retile_cells16(const float* dense, void* cells, int N, int nb, hipStream_t stream) {
+    hipLaunchKernelGGL(retile_cells16_kernel, dim3((unsigned)(nb * nb * nb)), dim3(64), 0, stream, dense, static_cast<short*>(cells), N, nb);
     return hipGetLastError();
 }
 
