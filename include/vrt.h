@@ -274,7 +274,7 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
  * the stream you are going to capture on makes the launch safe to capture into a hipGraph.  Counter buffers are
  * never freed before vrt_destroy, so a captured launch stays replayable after later, larger launches; it must be
  * re-captured after vrt_volume_upload* / vrt_volume_free / vrt_texture_* / a vrt_env_upload of another size /
- * vrt_scene_set (they replace device buffers or arrays the launch dereferences).  Up to 4 streams may have
+ * vrt_scene_set (they replace device buffers or arrays the launch dereferences).  Up to 8 streams may have
  * launches in flight at once (the reference keeps 3 frames in flight, DXConstants.cpp:23): each stream has its
  * own counter buffer, each launch its own event pair. */
 int vrt_render_rows(vrt_ctx* ctx, const vrt_params* params, int row0, int rows,
@@ -325,9 +325,7 @@ int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out);
 int vrt_timing_history(vrt_ctx* ctx, int n, float* kernel_ms_out);
 
 /* Diagnostics: per-wave records of the last launch on the first device, 8 words each, record
- * index = blockIdx*4 + wave, for the waves of the launch's march region (the tiles that touch the screen rectangle of the
- * instances; the sky around it is written by a streaming kernel without records, its rays are added to
- * vrt_timing::primary_rays).  which = 0: counters {primary_rays, shadow_rays, bounce_rays,
+ * index = blockIdx*4 + wave.  which = 0: counters {primary_rays, shadow_rays, bounce_rays,
  * primary_steps, shadow_steps, hits, exhausted_rays, 0}.  which = 1 (only after a VRT_FLAG_DIAG_TIMELINE launch):
  * {start, end (100 MHz ticks), iterations whose taps were back within 450 cycles, XCC_ID | HW_ID<<4, longest
  * per-lane sample chain, tap-fetch cycles, march-loop cycles, march-loop iterations} of the lane with the longest

@@ -60,7 +60,7 @@ RcclApi* rccl() {
     return api.ok ? &api : nullptr;
 }
 
-constexpr int kStatSlots = 4; /* launches that may be in flight at once without sharing a counter buffer */
+constexpr int kStatSlots = 8; /* streams that may have launches in flight at once without sharing a counter buffer */
 constexpr int kRing = 256; /* per-launch event pairs + stat slots kept for vrt_timing_history */
 
 struct HostVolume {
@@ -141,7 +141,6 @@ struct DeviceState {
     uint64_t stats_used[kStatSlots] = {}; /* launch number of the last use (LRU) */
     std::vector<unsigned*> stats_retired;
     int last_slot = 0;
-    uint64_t sky_rays[kStatSlots] = {}; /* primary rays of the slot's last launch that sky_kernel wrote (no wave records) */
     unsigned* d_diag = nullptr;  /* allocated on first use of VRT_FLAG_DIAG_TIMELINE (never in a capture) */
     int last_blocks = 0;
     bool last_diag = false;
@@ -749,50 +748,6 @@ void cull_rect(const vrt_ctx* ctx, const vrt_params* p, DFrame& F) {
     F.cull_y1 = (int)std::max(-1.0, std::min((double)p->height - 1.0, ceil(y1 + m)));
 }
 
-/* Frame row of local row l of a launch (the kernels' frame_row). */
-int frame_row_of(const RowSet& rs, int l) {
-    if (rs.strip_rows > 0) {
-        const int s = l / rs.strip_rows;
-        return (s * rs.strip_stride + rs.strip_first) * rs.strip_rows + (l - s * rs.strip_rows);
-    }
-    return rs.row0 + l;
-}
-
-/* The march region of a launch: the 16x16-pixel tiles of its local tile grid that touch the cull rectangle (frame rows
-   grow with local rows, also for interleaved strips, so they form one rectangle).  Returns through F.tile_x0 / tile_y0 /
-   tiles_x / tiles_y; empty (0 x 0) when the launch has no pixel inside the rectangle. */
-void march_region(const RowSet& rs, DFrame& F) {
-    F.tile_x0 = F.tile_y0 = 0;
-    F.tiles_x = F.tiles_y = 0;
-    if (F.cull_x1 < F.cull_x0 || F.cull_y1 < F.cull_y0) return;
-    int l0 = -1, l1 = -1;
-    for (int l = 0; l < rs.rows; l++) {
-        const int y = frame_row_of(rs, l);
-        if (y >= F.height) break;
-        if (y >= F.cull_y0 && y <= F.cull_y1) {
-            if (l0 < 0) l0 = l;
-            l1 = l;
-        }
-    }
-    if (l0 < 0) return;
-    F.tile_x0 = F.cull_x0 / 16;
-    F.tile_y0 = l0 / 16;
-    F.tiles_x = F.cull_x1 / 16 - F.tile_x0 + 1;
-    F.tiles_y = l1 / 16 - F.tile_y0 + 1;
-}
-
-/* Pixels of the launch that sky_kernel writes: everything outside the march region, rows beyond the frame excluded. */
-uint64_t sky_pixels(const RowSet& rs, const DFrame& F) {
-    const int mx0 = std::min(F.tile_x0 * 16, F.width), mx1 = std::min((F.tile_x0 + F.tiles_x) * 16, F.width);
-    const int my0 = std::min(F.tile_y0 * 16, rs.rows), my1 = std::min((F.tile_y0 + F.tiles_y) * 16, rs.rows);
-    uint64_t n = 0;
-    for (int l = 0; l < rs.rows; l++) {
-        if (frame_row_of(rs, l) >= F.height) continue;
-        n += (uint64_t)((l >= my0 && l < my1) ? F.width - (mx1 - mx0) : F.width);
-    }
-    return n;
-}
-
 void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, const RowSet& rs, float* out,
                  unsigned* stats, DFrame& F, const SceneArrays* snapshot = nullptr) {
     const int row0 = rs.row0, rows = rs.rows;
@@ -859,7 +814,6 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.stats = stats;
     F.vol0 = ctx->scene.n_instances == 1 ? F.vols + ctx->scene.instances[0].volume_slot : nullptr;
     cull_rect(ctx, p, F);
-    march_region(rs, F);
 }
 
 /* Enqueue one tile on one device.  No allocation, no host sync. */
@@ -867,13 +821,11 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
                  int ring, const SceneArrays* snapshot = nullptr) {
     DFrame F;
     build_frame(ctx, D, p, rs, out, nullptr, F, snapshot);
-    const int full_tx = (p->width + 15) / 16, full_ty = (rs.rows + 15) / 16; /* the launch's whole tile grid: bounds the march region */
-    if ((long long)full_tx * full_ty > kMaxBlocks / 2) return VRT_ERR_INVALID;
+    if ((long long)F.tiles_x * F.tiles_y > kMaxBlocks / 2) return VRT_ERR_INVALID;
     const bool single = ctx->scene.n_instances == 1;
     const int path = resolve_path(ctx, p->path, single, p->mode);
     if (path < 0) return path;
     D.last_blocks = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
-    const size_t cap_blocks = (size_t)grid_blocks(full_tx, full_ty, F.tile_map); /* the march region moves with the camera: size for all of it */
     int slot = -1;
     for (int i = 0; i < kStatSlots; i++)
         if (D.stats_bound[i] && D.stats_stream[i] == stream) slot = i;
@@ -888,15 +840,14 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
         D.stats_stream[slot] = stream;
     }
     D.stats_used[slot] = ctx->launches;
-    if (D.stats_cap[slot] < cap_blocks) { /* first launch of this size on this stream: the only allocation on this path */
+    if (D.stats_cap[slot] < (size_t)D.last_blocks) { /* first launch of this size on this stream: the only allocation on this path */
         unsigned* grown = nullptr;
-        HIP_TRY(hipMalloc(&grown, sizeof(unsigned) * kStatRecord * 4 * cap_blocks));
+        HIP_TRY(hipMalloc(&grown, sizeof(unsigned) * kStatRecord * 4 * (size_t)D.last_blocks));
         if (D.d_stats[slot]) D.stats_retired.push_back(D.d_stats[slot]); /* a captured graph may still write to it */
         D.d_stats[slot] = grown;
-        D.stats_cap[slot] = cap_blocks;
+        D.stats_cap[slot] = (size_t)D.last_blocks;
     }
     D.last_slot = slot;
-    D.sky_rays[slot] = sky_pixels(rs, F);
     F.stats = D.d_stats[slot];
     D.last_diag = F.diag != 0;
     if (F.diag) {
@@ -908,7 +859,6 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (stream != nullptr && hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
     D.timed[ring] = cap == hipStreamCaptureStatusNone;
-    HIP_TRY(launch_sky(F, stream)); /* the sky first, outside the event pair: kernel_ms is the march kernel's own duration */
     if (D.timed[ring]) HIP_TRY(hipEventRecord(D.ev0[ring], stream));
     HIP_TRY(launch_march(F, path, single, stream));
     if (D.timed[ring]) HIP_TRY(hipEventRecord(D.ev1[ring], stream));
@@ -1468,7 +1418,6 @@ int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out) {
             HIP_TRY(hipMemcpy(rec.data(), D.d_stats[D.last_slot], rec.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
         for (size_t w = 0; w < (size_t)D.last_blocks * 4; w++)
             for (int k = 0; k < kStatWords; k++) tot[k] += rec[w * kStatRecord + k];
-        tot[0] += D.sky_rays[D.last_slot];
     }
     out->kernel_ms = kernel_ms;
     out->gather_ms = ctx->last_gather_ms;

@@ -136,10 +136,7 @@ struct DFrame {
     /* frame geometry */
     int32_t width, height;
     int32_t row0, rows;        /* this launch renders rows [row0,row0+rows) */
-    int32_t tiles_x, tiles_y;  /* size, in 16x16-pixel tiles, of the MARCH REGION of this launch: the tiles that touch the cull
-                                  rectangle below.  The march kernels run over it; every pixel outside it is sky and is written
-                                  by sky_kernel */
-    int32_t tile_x0, tile_y0;  /* origin of the march region in the launch's local tile grid */
+    int32_t tiles_x, tiles_y;  /* 16x16-pixel blocks covering width x rows */
     int32_t tile_map;          /* kMapSupertile / kMapBand / kMapLinear */
     int32_t diag;              /* 1: diagnostic kernel build that stamps per-wave timeline records */
     int32_t full;              /* 1: full closest hit needed (point/spot lights, or bounces allowed and a smooth material in the scene) */

@@ -1117,8 +1117,8 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel(const DFrame F) {
     int tile_x, tile_y;
     tile_of_block(F, b, (int)gridDim.x / kMarchGridMul, tile_x, tile_y);
     const int lane = (int)threadIdx.x & 63;
-    const int px = (tile_x + F.tile_x0) * 16 + (wave & 1) * 8 + (lane & 7);
-    const int pyl = (tile_y + F.tile_y0) * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int py = frame_row(F, pyl);
     const bool valid = tile_x < F.tiles_x && tile_y < F.tiles_y && px < F.width && pyl < F.rows && py < F.height;
 
@@ -1155,45 +1155,6 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel(const DFrame F) {
         store_pixel(F, px, pyl, color);
     }
     write_records<DIAG, true>(F, b, wave, lane, k, dg, t_start);
-}
-
-/*
- * Everything outside the march region of a launch (DFrame::tile_x0.., the tiles that touch the cull rectangle) is sky:
- * VRMiss alone (Raytracing.hlsl:444-449) — camera ray, cube-map texel, tone-map, store; the very functions the march
- * kernels use for a miss, so the pixels are the same bits.  Four bands around the march region, one pixel per lane,
- * neighbouring lanes on neighbouring pixels (1 KB of float4 per wave-store).  Four fifths of the benchmark frame: as 8x8
- * tiles of the march kernel they cost a wave slot for ~4 us each; here they are a streaming pass.
- */
-__global__ __launch_bounds__(256) void sky_kernel(const DFrame F, int mx0, int mx1, int my0, int my1) {
-    const int W = F.width;
-    const long long n_top = (long long)my0 * W, n_bot = (long long)(F.rows - my1) * W;
-    const long long n_left = (long long)(my1 - my0) * mx0;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int px, pyl;
-    if (i < n_top) {
-        pyl = (int)(i / W);
-        px = (int)(i - (long long)pyl * W);
-    } else if ((i -= n_top) < n_bot) {
-        pyl = (int)(i / W);
-        px = (int)(i - (long long)pyl * W);
-        pyl += my1;
-    } else if ((i -= n_bot) < n_left) {
-        pyl = (int)(i / mx0);
-        px = (int)(i - (long long)pyl * mx0);
-        pyl += my0;
-    } else {
-        i -= n_left;
-        const int wr = W - mx1;
-        if (wr <= 0 || i >= (long long)(my1 - my0) * wr) return;
-        pyl = (int)(i / wr);
-        px = (int)(i - (long long)pyl * wr) + mx1;
-        pyl += my0;
-    }
-    const int py = frame_row(F, pyl);
-    if (pyl >= F.rows || py >= F.height) return;
-    F3 o, d;
-    camera_ray(F, px, py, o, d);
-    store_pixel(F, px, pyl, env_lookup(F.env, F.env_size, d));
 }
 
 /* ---- tri-planar material textures (SH/Include/Textures.hlsli:16-59, Quaternion.hlsli:18-82) ----------
@@ -1300,8 +1261,8 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DFrame 
     int tile_x, tile_y;
     tile_of_block(F, b, (int)gridDim.x / kMarchGridMul, tile_x, tile_y);
     const int lane = (int)threadIdx.x & 63;
-    const int px = (tile_x + F.tile_x0) * 16 + (wave & 1) * 8 + (lane & 7);
-    const int pyl = (tile_y + F.tile_y0) * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int py = frame_row(F, pyl);
     const bool valid = tile_x < F.tiles_x && tile_y < F.tiles_y && px < F.width && pyl < F.rows && py < F.height;
 
@@ -1590,8 +1551,8 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame 
     tile_of_block(F, b, (int)gridDim.x, tile_x, tile_y);
     const int wave = (int)threadIdx.x >> 6;
     const int lane = (int)threadIdx.x & 63;
-    const int px = (tile_x + F.tile_x0) * 16 + (wave & 1) * 8 + (lane & 7);
-    const int pyl = (tile_y + F.tile_y0) * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int py = frame_row(F, pyl);
     const bool valid = tile_x < F.tiles_x && tile_y < F.tiles_y && px < F.width && pyl < F.rows && py < F.height;
 
@@ -1996,15 +1957,6 @@ static hipError_t launch_path(const DFrame& F, bool single, bool diag_build, hip
         if (diag_build) return single ? launch_t<PATH, true>(F, stream) : launch_t<PATH, false>(F, stream);
     }
     return single ? launch_nodiag_t<PATH, true>(F, stream) : launch_nodiag_t<PATH, false>(F, stream);
-}
-
-hipError_t launch_sky(const DFrame& F, hipStream_t stream) {
-    const int mx0 = std::min(F.tile_x0 * 16, F.width), mx1 = std::min((F.tile_x0 + F.tiles_x) * 16, F.width);
-    const int my0 = std::min(F.tile_y0 * 16, F.rows), my1 = std::min((F.tile_y0 + F.tiles_y) * 16, F.rows);
-    const long long n = (long long)F.width * F.rows - (long long)(mx1 - mx0) * (my1 - my0);
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sky_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, F, mx0, mx1, my0, my1);
-    return hipGetLastError();
 }
 
 hipError_t launch_march(const DFrame& F, int path, bool single, hipStream_t stream) {

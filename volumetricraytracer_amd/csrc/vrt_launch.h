@@ -11,8 +11,6 @@ namespace vrt {
 /* path: VRT_PATH_DENSE / VRT_PATH_BRICK / VRT_PATH_BRICK_LDS / kPathCube / kPathBrick16 / kPathCube16 (already resolved,
    never AUTO). */
 hipError_t launch_march(const DFrame& frame, int path, bool single_instance, hipStream_t stream);
-/* The pixels of the launch outside its march region (frame.tile_x0 / tile_y0 / tiles_x / tiles_y): sky. */
-hipError_t launch_sky(const DFrame& frame, hipStream_t stream);
 /* dense grid -> brick records of `format` (fp32: 512 B, VRT_FORMAT_TEXEL16: 256 B of int16). */
 hipError_t launch_retile(const float* dense, void* bricks, int format, int N, int nb, hipStream_t stream);
 /* VRT_PATH_CELLS: integer field -> nb^3 x 64 cell records of 8 int16. */
