@@ -25,6 +25,7 @@ Prints ONE JSON line on rank 0 (driver contract) extended with:
   latency         one frame in flight: ms per frame as an application waiting for each frame sees it
   end_to_end      vrt_render_begin/_end: march + copy of the frame to pinned host memory, pipelined
   config4         the same scene at 3840x2160 split the same N ways (BASELINE config 4)
+  reference_texel_format   the same frames with the volume kept as the reference's 16-bit texel (opt-in device format)
 """
 import argparse
 import hashlib
@@ -442,6 +443,24 @@ def main() -> None:
             del pipe4
             r.ResizeRenderOutput(W, H)
 
+    texel_leg = None
+    if not args.no_extra_legs and args.steps > 0 and world == 1 and fmt == _abi.FORMAT_F32 and args.path == "auto":
+        # the same frames with the volume kept as the reference's own 16-bit texel (RDXVoxelVolume.cpp:399-421), cell records
+        for vol in sc.volumes():
+            vol.set_device_format(_abi.FORMAT_TEXEL16)
+        r.SyncWithScene()
+        pt = params(W, H)
+        pt.path = _abi.PATH_CELLS
+        pipet = Pipeline(r, pt, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal)
+        et = timed_run(pipet, args.steps, args.warmup, world, cdev)
+        ct = job_counts(r.last_timing())
+        texel_leg = {"volume_format": "reference texel (sign + 15-bit |d|*100) as 16-byte cell records, --format texel16 --path cells",
+                     "ms_per_frame": round(et / args.steps * 1e3, 4), "value": round((ct[0] + ct[1]) * args.steps / et / 1e6, 2),
+                     "unit": "Mrays/s", "frames_in_flight": K}
+        del pipet
+        for vol in sc.volumes():
+            vol.set_device_format(fmt)
+
     if rank == 0:
         alg_bytes = v.algorithmic_bytes(t, 4 if rgba8 else 16)
         k_ms = float(np.mean(kms)) if kms else float("nan")
@@ -482,7 +501,7 @@ def main() -> None:
                                        f" x{world} + " + ("gloo gather, REHEARSAL on one GPU" if rehearsal else "RCCL gather to rank 0")),
                        "rays_per_frame": int(rays_per_frame), "samples_per_ray": round((psteps + ssteps) / max(rays_per_frame, 1), 2)},
             "roofline": roofline, "cpu_baseline": cpu,
-            "latency": latency, "end_to_end": end_to_end, "config4": config4,
+            "latency": latency, "end_to_end": end_to_end, "config4": config4, "reference_texel_format": texel_leg,
         }
         if world > 1:
             out["gather"] = "native (vrt_gather_tiles: ncclGather on the march stream)" if use_native else "torch.distributed.gather (RCCL)"
