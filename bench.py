@@ -65,8 +65,11 @@ def parse_args(argv=None):
     ap.add_argument("--tile-map", default="supertile", choices=["supertile", "band", "linear"], help="blockIdx -> tile map (speed only)")
     ap.add_argument("--gather", default="torch", choices=["torch", "native"],
                     help="N>1: the per-frame tile gather: torch.distributed.gather (RCCL under torch), or the C-ABI's own "
-                         "vrt_gather_tiles (ncclGather on the march stream); the other one is exercised once after the timed "
-                         "region and reported under native_gather_check")
+                         "vrt_gather_tiles (ncclGather on the march stream; then torch's gather is cross-checked after the "
+                         "timed region, native_gather_check)")
+    ap.add_argument("--native-check", action="store_true",
+                    help="N>1 with --gather torch: also bring up the C-ABI's own RCCL communicator and run a few frames through "
+                         "vrt_gather_tiles after the timed region (native_gather_check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the latency / end_to_end / config4 legs")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of the baseline sample")
@@ -353,8 +356,9 @@ def main() -> None:
     r.SyncWithScene()
 
     native_ready, native_error = False, None
-    if world > 1 and not rehearsal:
-        # the C-ABI's own communicator: rank 0 makes the id, torch.distributed carries it to the others
+    if world > 1 and not rehearsal and (args.gather == "native" or args.native_check):
+        # the C-ABI's own communicator (only on request: a second RCCL communicator next to torch's is not something a default
+        # benchmark run should depend on): rank 0 makes the id, torch.distributed carries it to the others
         try:
             idt = torch.zeros(_abi.VRT_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
             if rank == 0:
