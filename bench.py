@@ -61,7 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--strip-rows", type=int, default=32, help="N>1: rows per interleaved strip; 0 = contiguous row tiles")
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 8],
                     help="frames launched before the first one must have finished, each on its own HIP stream and tile "
-                         "buffer; 0 = 3, what the reference keeps in flight (FrameCount, DXConstants.cpp:23)")
+                         "buffer; 0 = 3 on one GPU, what the reference keeps in flight (FrameCount, DXConstants.cpp:23), 8 on several")
     ap.add_argument("--tile-map", default="supertile", choices=["supertile", "band", "linear"], help="blockIdx -> tile map (speed only)")
     ap.add_argument("--gather", default="torch", choices=["torch", "native"],
                     help="N>1: the per-frame tile gather: torch.distributed.gather (RCCL under torch), or the C-ABI's own "
@@ -93,6 +93,7 @@ def self_launch(n: int, argv) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")  # 8 frames in flight per rank want 8 hardware queues (default 4)
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -172,6 +173,8 @@ class Pipeline:
         self.fg = FrameGather(H, W, world, rank, torch.device("cpu") if rehearsal else dev, dtype=pix, buffers=K, strip_rows=strip_rows)
         self.march_tiles = [torch.zeros_like(x, device=dev) for x in self.fg.tiles] if rehearsal else self.fg.tiles
         self.pending = [None] * K
+        # (the current stream + K-1 pool streams: with HIP's default 4 hardware queues this arrangement lands on distinct queues;
+        # K pool streams measured 40 % slower at K = 3, profiles/r02_strong_scaling_probe.txt)
         self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(K - 1)]
         # Rank 0 un-shuffles the gathered strips on a stream of its own: the copy only has to finish before the NEXT
         # gather into the same frame buffer starts, not between two frames of a march stream.
@@ -297,6 +300,8 @@ def main() -> None:
     if args.launch_check:
         launch_check(args)
         return
+    if world > 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # read by the HIP runtime at start-up: before torch is imported
 
     import numpy as np
     import torch
@@ -334,7 +339,10 @@ def main() -> None:
         label += f" -- the same {W}x{H} frame split over {world} GPUs (strong scaling)"
     rgba8 = args.output == "rgba8" or (args.output == "auto" and world > 1)
     strip_rows = args.strip_rows if world > 1 else 0
-    K = args.frames_in_flight or 3  # FrameCount, DXConstants.cpp:23
+    # one GPU: 3 = FrameCount, DXConstants.cpp:23.  Several: every GPU gets 1/N of a frame whose march lasts as long as its longest
+    # chain whatever its size (profiles/r02_strong_scaling_probe.txt), so the pipeline is deepened to 8 frames (about one whole
+    # frame's work in flight per GPU at N = 8) over 8 HIP hardware queues
+    K = args.frames_in_flight or (3 if world == 1 else 8)
     path = {"auto": _abi.PATH_AUTO, "dense": _abi.PATH_DENSE, "brick": _abi.PATH_BRICK, "lds": _abi.PATH_BRICK_LDS, "cells": _abi.PATH_CELLS}[args.path]
     fmt = {"auto": workloads.BENCH_VOLUME_FORMAT, "f32": _abi.FORMAT_F32, "texel16": _abi.FORMAT_TEXEL16}[args.format]
     for vol in sc.volumes():
@@ -508,7 +516,8 @@ def main() -> None:
             "latency": latency, "end_to_end": end_to_end, "config4": config4, "reference_texel_format": texel_leg,
         }
         if world > 1:
-            out["gather"] = "native (vrt_gather_tiles: ncclGather on the march stream)" if use_native else "torch.distributed.gather (RCCL)"
+            out["gather"] = ("native (vrt_gather_tiles: ncclGather on the march stream)" if use_native else
+                             "torch.distributed.gather (" + ("gloo, REHEARSAL" if rehearsal else "RCCL") + ")")
             out["native_gather_check"] = native_check if native_check is not None else ({"error": native_error} if native_error else None)
         if verified is not None:
             out["gathered_frame_equals_single_gpu_frame"] = verified

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""What ONE rank of an N-way strong-scaled frame can sustain: rank 0's interleaved strips of the config-3 frame (every N-th
+32-row strip, RGBA8 tile) rendered with K frames in flight, no gather — the per-rank march rate that bounds the N-GPU job.
+Run once per GPU_MAX_HW_QUEUES setting (the HIP runtime reads it at start-up).
+Usage: [GPU_MAX_HW_QUEUES=8] python tools/strong_scaling_probe.py [workload]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import volumetricraytracer_amd as v  # noqa: E402
+from volumetricraytracer_amd import _abi, workloads  # noqa: E402
+from volumetricraytracer_amd.tiles import strip_layout  # noqa: E402
+
+workload = sys.argv[1] if len(sys.argv) > 1 else "c3"
+sc, W, H, max_steps, shadow, label = bench.build_workload(workload)
+p = v.default_params(W, H, workloads.min_cell(sc), max_steps, shadow=shadow)
+p.flags |= _abi.FLAG_OUTPUT_RGBA8
+r = v.VHipRenderer()
+assert r.Start()
+r.SetSceneToRender(sc)
+r.ResizeRenderOutput(W, H)
+r.SyncWithScene()
+print(f"{label}; GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}")
+print("ranks  K  ms/frame(rank 0 alone)  frames/s  -> whole-job Grays/s if every rank keeps that rate")
+full = None
+for n in (1, 2, 4, 8):
+    _, per = strip_layout(H, n, 32)
+    for K in (1, 2, 3, 4, 6, 8):
+        streams = [torch.cuda.Stream() for _ in range(K)]
+        tiles = [torch.zeros((per * 32, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(K)]
+
+        def run(steps):
+            for i in range(steps):
+                b = i % K
+                r.render_strips(p, 32, 0, n, per, tiles[b].data_ptr(), streams[b].cuda_stream)
+            torch.cuda.synchronize()
+
+        run(2 * K)
+        steps, dt = 300, 1e9
+        for _ in range(3):  # best of three
+            t0 = time.perf_counter()
+            run(steps)
+            dt = min(dt, (time.perf_counter() - t0) / steps)
+        if full is None:
+            t = r.last_timing()
+            full = t["primary_rays"] + t["shadow_rays"]  # n = 1: the whole frame's rays
+        print(f"  {n}    {K}   {dt * 1e3:.4f}   {1 / dt:9.0f}   {full / dt / 1e9:7.2f}")
+r.Stop()
