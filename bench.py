@@ -207,7 +207,8 @@ class Pipeline:
             with torch.cuda.stream(self.copy_stream):
                 self.pending[b].wait()  # the copy stream (not the host) waits for this gather (gloo rehearsal: the host does)
                 fg.unshuffle(b)         # gathered [rank, strip] order -> frame order, one strided device copy
-                self.unshuffled[b] = torch.cuda.Event()
+                if self.unshuffled[b] is None:
+                    self.unshuffled[b] = torch.cuda.Event()
                 self.unshuffled[b].record(self.copy_stream)
 
     def drain(self) -> None:

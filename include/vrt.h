@@ -177,7 +177,10 @@ typedef struct vrt_params {
     float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
     float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
     float step_min;       /* lower bound of one march step (ray-parameter units) */
-    float k_relax;        /* sphere-trace relaxation factor, <= 1 */
+    float k_relax;        /* sphere-trace relaxation factor.  <= 1: every distance-driven step is k_relax times the sampled distance.
+                             > 1 (typically 1.7): over-relaxation — the step is stretched by k_relax, and when the empty spheres
+                             around two successive samples then fail to overlap the ray returns to the first one's plain step
+                             (Keinert et al., "Enhanced Sphere Tracing", 2014): same surfaces, fewer positions along grazing rays */
     float cone_eps;       /* pixel-footprint termination: the hit threshold at ray parameter t is
                              eps_hit + cone_eps * t (0 = constant threshold).  Typically the angular
                              radius of a pixel, tan(fov/2)/height */

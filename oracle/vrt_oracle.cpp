@@ -737,6 +737,11 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
     const float leap_unit = (4.0f * V.cell) * inv_len; /* one brick edge in ray-parameter units */
     const float cell_unit = leap_unit * 0.25f;         /* one cell edge */
     float t_prev = t, s_prev = 0.0f;
+    /* Over-relaxation (k_relax > 1; Keinert et al., "Enhanced Sphere Tracing", 2014): a distance-driven step is stretched by
+       k_relax; at the next sample the empty spheres around the two samples must still overlap, else something may have
+       been jumped over: the ray goes back and takes the plain step from the previous sample.  relaxed: the step that led to
+       the current position was a stretched one. */
+    bool relaxed = false;
     for (int i = 0; i < P.prm.max_steps; i++) {
         if (t > t_end) return false;
         float ux = fmaf(ud.x, t, uo.x), uy = fmaf(ud.y, t, uo.y), uz = fmaf(ud.z, t, uo.z);
@@ -765,12 +770,19 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
             if (leap > 0.0f && leap >= smax && thr + thr <= smax) {
                 t_prev = t;
                 s_prev = smax;
+                relaxed = false;
                 t = t + fmaxf(fmaf(t, P.prm.cone_eps, base_min), leap);
                 continue;
             }
         }
         float s = trilinear(V, cx, cy, cz, fx, fy, fz) * ds;
         steps++;
+        if (relaxed && fmaxf(fminf(s, smax), 0.0f) + s_prev < t - t_prev) {
+            /* the spheres do not overlap: back to the previous sample's plain step (that sample stays the "previous" one) */
+            relaxed = false;
+            t = t_prev + fmaxf(s_prev, fmaf(t_prev, P.prm.cone_eps, base_min));
+            continue;
+        }
         if (s < fmaf(t, P.prm.cone_eps, P.prm.eps_hit)) {
             if (s < 0.0f && i > 0) {
                 /* the step overshot into the surface (band-edge cells of shell volumes interpolate towards the
@@ -829,7 +841,10 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
         t_prev = t;
         s_prev = fminf(s, smax); /* what a skipped sample would have recorded: the secant of an overshoot repair starts from it */
         const float adv_min = fmaxf(fmaf(t, P.prm.cone_eps, base_min), leap);
-        t = t + fmaxf(fminf(s * P.prm.k_relax, smax), adv_min);
+        const float om = P.prm.k_relax;
+        const float step = fmaxf(fminf(s * om, om > 1.0f ? smax * om : smax), adv_min);
+        relaxed = step > fmaxf(s_prev, adv_min); /* longer than the plain step from here */
+        t = t + step;
     }
     if (P.prm.max_steps > 0 && !(t > t_end)) g_exhausted++;
     return false;

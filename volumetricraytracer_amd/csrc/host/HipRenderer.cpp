@@ -441,7 +441,7 @@ void VHipRenderer::Render() {
     p.eps_hit = 0.004f * MinCell;
     p.eps_in = 0.01f; /* Raytracing.hlsl:178 */
     p.step_min = 0.004f * MinCell;
-    p.k_relax = 1.0f;
+    p.k_relax = Relaxation;
     const VObjectPtr<Scene::VCamera> cam = scene->GetActiveCamera();
     p.cone_eps = std::tan(cam->FOVAngle * (3.14159265358979323846f / 180.0f) * 0.5f) / (float)Height;
     Frame.resize((size_t)Width * Height * 4);

@@ -55,6 +55,7 @@ public:
     /* Device format of the volumes: VRT_FORMAT_F32, or VRT_FORMAT_TEXEL16 = the reference's own 16-bit volume texel
        (VDXVoxelVolume::EncodeVoxel, RDXVoxelVolume.cpp:399-421): the march then sees exactly the DXR backend's field */
     int VolumeFormat = VRT_FORMAT_F32;
+    float Relaxation = 1.7f;  /* vrt_params::k_relax: over-relaxed sphere-trace with the sphere-overlap fallback; 1 = plain */
     bool Shadows = true;      /* the reference always casts the directional shadow ray */
     int MaxBounces = 2;       /* MAX_RAY_RECURSION_DEPTH 3 = primary + 2 mirror bounces (RaytracingHlsl.h:32) */
     int DataPath = VRT_PATH_AUTO;

@@ -604,6 +604,7 @@ struct MarchState {
     float t, t_prev, s_prev, s_hit;
     int i;                 /* iterations so far: positions visited, sampled or skipped */
     bool hit;
+    bool relaxed;          /* over-relaxation (k_relax > 1): the step that led to the current position was a stretched one */
     Cell c;
 };
 
@@ -621,6 +622,7 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
     float t = st.t, t_prev = st.t_prev, s_prev = st.s_prev;
     int i = st.i;
     Cell c = st.c;
+    bool relaxed = st.relaxed;
     const bool tables = V.skip != nullptr;
     unsigned last_brick = 0xffffffffu, B = 1u, nibw = 0u;
     while (i < limit && !(t > R.t_end)) {
@@ -662,6 +664,7 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
                    condition, same advance) */
                 t_prev = t;
                 s_prev = R.smax;
+                relaxed = false;
                 t = t + __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
                 i++;
                 if constexpr (DIAG) {
@@ -683,6 +686,14 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
         for (;;) { /* samples inside this cell */
             const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
             steps++;
+            if (relaxed && __builtin_fmaxf(__builtin_fminf(s, R.smax), 0.0f) + s_prev < t - t_prev) {
+                /* over-relaxation (k_relax > 1): the empty spheres around the last two samples do not overlap — something may
+                   have been jumped over.  Back to the previous sample's plain step; that sample stays the "previous" one */
+                relaxed = false;
+                t = t_prev + __builtin_fmaxf(s_prev, __builtin_fmaf(t_prev, F.cone_eps, R.base_min));
+                i++;
+                break;
+            }
             if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
                 st.hit = true;
                 st.s_hit = s;
@@ -692,7 +703,10 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
             t_prev = t;
             s_prev = __builtin_fminf(s, R.smax);
             const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
-            t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
+            const float om = F.k_relax;
+            const float step = __builtin_fmaxf(__builtin_fminf(s * om, om > 1.0f ? R.smax * om : R.smax), adv_min);
+            relaxed = step > __builtin_fmaxf(s_prev, adv_min);
+            t = t + step;
             if (i >= limit || t > R.t_end) break;
 #ifndef VRT_AB_INCELL /* A/B build: while successive samples stay in one cell the 8 taps stay in registers.  Measured
                          (profiles/r02_ab_march_variants.txt): 12 % slower with one frame in flight — the lanes of a wave that
@@ -711,6 +725,7 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
     st.s_prev = s_prev;
     st.i = i;
     st.c = c;
+    st.relaxed = relaxed;
 }
 
 /*
@@ -738,6 +753,7 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     st.s_prev = st.s_hit = 0.0f;
     st.i = 0;
     st.hit = false;
+    st.relaxed = false;
     st.c = Cell{0, 0, 0, 0.0f, 0.0f, 0.0f};
     march_lane<DP, DIAG>(F, V, R, st, F.max_steps, steps, dg);
     if (!st.hit) {
@@ -1409,6 +1425,7 @@ __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V,
                                                float* __restrict__ slots, unsigned* __restrict__ tags, int lane, unsigned& steps) {
     float t = st.t, t_prev = st.t_prev, s_prev = st.s_prev;
     int i = st.i;
+    bool relaxed = st.relaxed;
     const int max_steps = F.max_steps;
     const unsigned nb = (unsigned)V.nb;
     for (;;) {
@@ -1425,6 +1442,7 @@ __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V,
             if (leap > 0.0f && leap >= R.smax && thr + thr <= R.smax) {
                 t_prev = t;
                 s_prev = R.smax;
+                relaxed = false;
                 t = t + __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
                 i++;
                 need = false; /* skipped: no taps this iteration */
@@ -1479,7 +1497,11 @@ __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V,
         if (sample) {
             steps++;
             st.c = c;
-            if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
+            if (relaxed && __builtin_fmaxf(__builtin_fminf(s, R.smax), 0.0f) + s_prev < t - t_prev) { /* see march_lane */
+                relaxed = false;
+                t = t_prev + __builtin_fmaxf(s_prev, __builtin_fmaf(t_prev, F.cone_eps, R.base_min));
+                i++;
+            } else if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
                 st.hit = true;
                 st.s_hit = s;
                 active = false;
@@ -1488,7 +1510,10 @@ __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V,
                 t_prev = t;
                 s_prev = __builtin_fminf(s, R.smax);
                 const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
-                t = t + __builtin_fmaxf(__builtin_fminf(s * F.k_relax, R.smax), adv_min);
+                const float om = F.k_relax;
+                const float step = __builtin_fmaxf(__builtin_fminf(s * om, om > 1.0f ? R.smax * om : R.smax), adv_min);
+                relaxed = step > __builtin_fmaxf(s_prev, adv_min);
+                t = t + step;
             }
         }
         if (active) { /* keep the lane's state current: it is read back when the lane retires */
@@ -1516,6 +1541,7 @@ __device__ __forceinline__ bool march_hybrid(const DFrame& F, const VolRef& V, c
     st.s_prev = st.s_hit = 0.0f;
     st.i = 0;
     st.hit = false;
+    st.relaxed = false;
     st.c = Cell{0, 0, 0, 0.0f, 0.0f, 0.0f};
     const int max_steps = F.max_steps;
     const int head = max_steps < kHeadSteps ? max_steps : kHeadSteps;

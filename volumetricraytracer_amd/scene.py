@@ -496,7 +496,7 @@ def march_budget(resolution: int, base: int = 255) -> int:
 
 def default_params(width: int, height: int, cell: float, max_steps: int = 128, shadow: bool = False,
                    mode: int = _abi.MODE_INTERP_NOTEX, path: int = _abi.PATH_AUTO, fov_deg: float = 60.0,
-                   cone: bool = True) -> _abi.vrt_params:
+                   cone: bool = True, k_relax: float = 1.7) -> _abi.vrt_params:
     """March contract defaults: hit threshold and minimum step are 0.4 % of a cell at
     the ray origin and grow with the pixel footprint (angular pixel radius tan(fov/2)/height)."""
     p = _abi.vrt_params()
@@ -510,6 +510,6 @@ def default_params(width: int, height: int, cell: float, max_steps: int = 128, s
     p.eps_hit = float(np.float32(0.004 * cell))
     p.eps_in = 0.01  # Raytracing.hlsl:178
     p.step_min = float(np.float32(0.004 * cell))
-    p.k_relax = 1.0
+    p.k_relax = float(k_relax)  # > 1: over-relaxed sphere-trace with the sphere-overlap fallback
     p.cone_eps = float(np.float32(math.tan(math.radians(fov_deg) * 0.5) / height)) if cone else 0.0
     return p

@@ -72,10 +72,16 @@ class FrameGather:
         self.tiles = [torch.zeros((self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
         self.frames: Optional[List] = None  # gathered tiles, rank-major
         self.final: Optional[List] = None   # strips only: frame-ordered copies
+        self._glist = None      # per buffer: the views torch.distributed.gather receives into (built once, not per frame)
+        self._unshuffle = None  # per buffer: (source view, destination view) of the strip un-shuffle
         if world > 1 and rank == 0:
             self.frames = [torch.zeros((world * self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
+            self._glist = [[f[k * self.rows_per:(k + 1) * self.rows_per] for k in range(world)] for f in self.frames]
             if self.strip_rows > 0:
                 self.final = [torch.zeros((world * self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
+                n, per, sr = world, self.strips_per, self.strip_rows
+                self._unshuffle = [(f.view(n, per, sr, width, 4).permute(1, 0, 2, 3, 4), g.view(per, n, sr, width, 4))
+                                   for f, g in zip(self.frames, self.final)]
 
     def gather(self, b: int, async_op: bool = False):
         """Gather tile buffer `b` of every rank into frame buffer `b` on rank 0."""
@@ -83,10 +89,7 @@ class FrameGather:
 
         if self.world == 1:
             return None
-        glist = None
-        if self.rank == 0:
-            glist = [self.frames[b][k * self.rows_per:(k + 1) * self.rows_per] for k in range(self.world)]
-        return dist.gather(self.tiles[b], glist, dst=0, async_op=async_op)
+        return dist.gather(self.tiles[b], self._glist[b] if self.rank == 0 else None, dst=0, async_op=async_op)
 
     def native_gather(self, renderer, b: int, stream: int = 0) -> None:
         """The same gather through the C-ABI (vrt_gather_tiles: ncclGather of the raw tile bytes), enqueued on HIP stream
@@ -103,9 +106,8 @@ class FrameGather:
         current stream (after the gather of buffer `b` has completed)."""
         if self.strip_rows == 0 or self.world == 1 or self.rank != 0:
             return
-        n, per, sr, w = self.world, self.strips_per, self.strip_rows, self.width
-        src = self.frames[b].view(n, per, sr, w, 4).permute(1, 0, 2, 3, 4)
-        self.final[b].view(per, n, sr, w, 4).copy_(src)
+        src, dst = self._unshuffle[b]
+        dst.copy_(src)
 
     def frame(self, b: int):
         """The assembled H x W x 4 frame (rank 0 only; for strips call unshuffle(b) first)."""
