@@ -62,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 8],
                     help="frames launched before the first one must have finished, each on its own HIP stream and tile "
                          "buffer; 0 = 3 on one GPU, what the reference keeps in flight (FrameCount, DXConstants.cpp:23), 8 on several")
+    ap.add_argument("--k-relax", type=float, default=0.0,
+                    help="over-relaxation factor of the sphere trace (vrt_params.k_relax); 0 = the renderer's default (1.7), 1 = plain")
     ap.add_argument("--tile-map", default="supertile", choices=["supertile", "band", "linear"], help="blockIdx -> tile map (speed only)")
     ap.add_argument("--gather", default="torch", choices=["torch", "native"],
                     help="N>1: the per-frame tile gather: torch.distributed.gather (RCCL under torch), or the C-ABI's own "
@@ -130,7 +132,7 @@ def kernel_source_hash() -> str:
 
 def traffic_key(args, world: int, K: int, rgba8: bool) -> dict:
     return {"workload": args.workload, "n_gpus": world, "path": args.path, "format": args.format, "tile_map": args.tile_map,
-            "frames_in_flight": K, "rgba8": bool(rgba8), "kernel_source_sha": kernel_source_hash()}
+            "frames_in_flight": K, "rgba8": bool(rgba8), "k_relax": args.k_relax, "kernel_source_sha": kernel_source_hash()}
 
 
 def measured_traffic(key: dict):
@@ -351,6 +353,8 @@ def main() -> None:
 
     def params(w, h):
         q = v.default_params(w, h, workloads.min_cell(sc), max_steps, shadow=shadow, path=path)
+        if args.k_relax > 0.0:
+            q.k_relax = args.k_relax
         if rgba8:
             q.flags |= _abi.FLAG_OUTPUT_RGBA8
         q.flags |= {"supertile": 0, "band": 1, "linear": 2}[args.tile_map]
@@ -506,7 +510,7 @@ def main() -> None:
             "config": {"workload": label, "width": W, "height": H, "volume": f"{sc.volumes()[0].N - 1}^3 cells",
                        "volume_format": {_abi.FORMAT_F32: "f32 bricks (512 B per 4^3 cells)",
                                          _abi.FORMAT_TEXEL16: "reference texel: sign + 15-bit |d|*100, 16-bit bricks (256 B per 4^3 cells)"}[fmt],
-                       "max_steps": max_steps, "shadow": bool(shadow), "data_path": args.path,
+                       "max_steps": max_steps, "shadow": bool(shadow), "k_relax": round(float(p.k_relax), 3), "data_path": args.path,
                        "output": "rgba8 (R8G8B8A8_UNORM tiles; march and shading in f32)" if rgba8 else "f32 (float4)",
                        "frames_in_flight": K,
                        "parallelism": ("1 GPU" if world == 1 else

@@ -174,7 +174,7 @@ struct Packed {
     float light_strength;
     const vrt_scene* scene;
     vrt_params prm;
-    uint32_t* steps_img; /* optional: per-pixel samples taken (primary+shadow), rows*width */
+    uint32_t* steps_img; /* optional debug output, rows*width: march positions of the primary ray (low 16 bits) and of the rays after it (high 16) */
 };
 
 Instance build_instance(const vrt_instance& in) {
@@ -548,6 +548,7 @@ bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env
 
 inline float lerp1(float a, float b, float w) { return fmaf(w, b - a, a); }
 
+const float kRelaxGate = 0.8f; /* over-relaxation: a step is stretched only when the sample is at least this fraction of the one before */
 const int kRefine = 3; /* secant samples spent on a hit that overshot into the surface */
 
 /* Trilinear interpolant of cell (cx,cy,cz) at fractional position (fx,fy,fz). */
@@ -572,6 +573,10 @@ struct Stats {
 };
 /* marches (ray x instance) that ran out of budget inside the volume, counted per thread and collected by vrto_render */
 thread_local uint64_t g_exhausted = 0;
+/* debug only (vrto_debug_set_steps_image): march positions visited, sampled or skipped, by the primary ray [0] and by the
+   rays that follow it [1] — what the length of a GPU lane's dependent chain is made of */
+thread_local uint64_t g_positions[2] = {0, 0};
+thread_local int g_ray_class = 0;
 
 struct HitRec {
     float t;
@@ -744,6 +749,7 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
     bool relaxed = false;
     for (int i = 0; i < P.prm.max_steps; i++) {
         if (t > t_end) return false;
+        g_positions[g_ray_class]++;
         float ux = fmaf(ud.x, t, uo.x), uy = fmaf(ud.y, t, uo.y), uz = fmaf(ud.z, t, uo.z);
         float cxf = minf(maxf(floorf(ux), 0.0f), cmax);
         float cyf = minf(maxf(floorf(uy), 0.0f), cmax);
@@ -838,13 +844,18 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
             }
             return true;
         }
+        const float s_old = s_prev;
         t_prev = t;
         s_prev = fminf(s, smax); /* what a skipped sample would have recorded: the secant of an overshoot repair starts from it */
         const float adv_min = fmaxf(fmaf(t, P.prm.cone_eps, base_min), leap);
         const float om = P.prm.k_relax;
-        const float step = fmaxf(fminf(s * om, om > 1.0f ? smax * om : smax), adv_min);
-        relaxed = step > fmaxf(s_prev, adv_min); /* longer than the plain step from here */
-        t = t + step;
+        const float plain = fmaxf(s_prev, adv_min);
+        const float stretched = fmaxf(fminf(s * om, om > 1.0f ? smax * om : smax), adv_min);
+        /* stretched only while (a) the distance is not falling fast — a ray running at a surface would only overshoot and
+           come back, it is the grazing ray whose chain the stretch shortens — and (b) the next sample stays inside the
+           interval: past its end there is no sample to check the overlap with */
+        relaxed = stretched > plain && s >= kRelaxGate * s_old && t + stretched <= t_end;
+        t = t + (relaxed ? stretched : plain);
     }
     if (P.prm.max_steps > 0 && !(t > t_end)) g_exhausted++;
     return false;
@@ -854,10 +865,14 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
 bool trace_closest(const Packed& P, V3 o, V3 d, float t_max, float t_base, HitRec& h, uint64_t& steps) {
     bool any = false;
     float best = t_max;
+    /* A sphere-trace runs over the instance's whole interval whatever has been hit before: where its stretched steps fall
+       depends on the interval's end, so cutting it at the closest hit so far would make the result depend on the order the
+       instances are visited in.  (The cell walk of the Cube modes has no such state and stops at the closest hit.) */
+    const bool cube = P.prm.mode >= VRT_MODE_CUBE;
     for (int i = 0; i < P.n_inst; i++) {
         float t;
         V3 n;
-        if (march_instance(P, i, o, d, best, t_base, true, t, n, steps)) {
+        if (march_instance(P, i, o, d, cube ? best : t_max, t_base, true, t, n, steps)) {
             if (!any || t < best) {
                 any = true;
                 best = t;
@@ -1035,6 +1050,7 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
     HitRec h;
     uint64_t steps = 0;
     bool hit = trace_closest(P, o, d, 10000.0f, t_base, h, steps);
+    g_ray_class = 1; /* everything this pixel traces from here on follows its primary ray */
     st.primary_steps += steps;
     if (!hit) {
         float rgb[3];
@@ -1179,9 +1195,13 @@ void render_rows(const Packed& P, int y0, int y1, int row0, float* out, Stats& s
             V3 o, d;
             camera_ray(P.cam, W, H, x, y, o, d);
             st.primary_rays++;
-            const uint64_t before = st.primary_steps + st.shadow_steps;
+            g_positions[0] = g_positions[1] = 0;
+            g_ray_class = 0;
             V3 c = radiance_ray(P, o, d, 1, 0.0f, st);
-            if (P.steps_img) P.steps_img[(size_t)(y - row0) * W + x] = (uint32_t)(st.primary_steps + st.shadow_steps - before);
+            if (P.steps_img) {
+                const uint64_t a = g_positions[0] < 0xffffu ? g_positions[0] : 0xffffu, b = g_positions[1] < 0xffffu ? g_positions[1] : 0xffffu;
+                P.steps_img[(size_t)(y - row0) * W + x] = (uint32_t)(a | (b << 16));
+            }
             float* px = out + ((size_t)(y - row0) * W + x) * 4;
             px[0] = tonemap(c.x);
             px[1] = tonemap(c.y);

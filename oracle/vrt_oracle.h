@@ -53,8 +53,9 @@ int vrto_render(const vrt_scene* scene, const vrto_volume* volumes,
                 const vrt_params* params, int row0, int rows,
                 float* out_rgba, vrto_stats* stats_or_null, int threads);
 
-/* Debug: when set (non-NULL), the next vrto_render calls also write the number of trilinear
- * samples each pixel took (primary + shadow) into img (rows*width).  Not thread-safe. */
+/* Debug: when set (non-NULL), the next vrto_render calls also write, per pixel, the number of march positions (sampled
+ * or skipped) its primary ray visited (low 16 bits) and the rays after it visited (high 16 bits) into img (rows*width):
+ * the length of the dependent chain a GPU lane runs for that pixel (tests/chain_lengths.py).  Not thread-safe. */
 void vrto_debug_set_steps_image(uint32_t* img);
 
 /* Single-ray probes used by the analytic pins (world-space ray, direction is normalised

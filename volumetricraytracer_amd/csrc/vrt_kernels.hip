@@ -323,6 +323,7 @@ struct RaySeg {
     float t_enter, t0, t_end;
     float ds;             /* density → ray-parameter distance: density_scale / |od| */
     float smax;           /* step_max / |od| */
+    float smax_relax;     /* the longest stretched step: smax * max(k_relax, 1) */
     float cmax;           /* N - 2 */
     float base_min;       /* step_min + cone_eps * t_base */
     float leap_unit;      /* one brick edge (4 cells) in ray-parameter units */
@@ -360,6 +361,7 @@ __device__ __forceinline__ bool setup_ray(const DFrame& F, const DInstance* __re
     const float inv_len = 1.0f / sqrtf(dot3(R.od, R.od));
     R.ds = V.dscale * inv_len;
     R.smax = V.step_max * inv_len;
+    R.smax_relax = F.k_relax > 1.0f ? R.smax * F.k_relax : R.smax;
     R.uo = f3((R.oo.x + V.extent) * V.inv_cell, (R.oo.y + V.extent) * V.inv_cell, (R.oo.z + V.extent) * V.inv_cell);
     R.ud = R.od * V.inv_cell;
     R.cmax = (float)(V.N - 2);
@@ -387,6 +389,7 @@ __device__ __forceinline__ bool setup_shadow_ray(const DFrame& F, const DInstanc
     const float inv_len = I->sh_inv_len;
     R.ds = V.dscale * inv_len;
     R.smax = V.step_max * inv_len;
+    R.smax_relax = F.k_relax > 1.0f ? R.smax * F.k_relax : R.smax;
     R.uo = f3((R.oo.x + V.extent) * V.inv_cell, (R.oo.y + V.extent) * V.inv_cell, (R.oo.z + V.extent) * V.inv_cell);
     R.ud = R.od * V.inv_cell;
     R.cmax = (float)(V.N - 2);
@@ -403,6 +406,20 @@ struct Cell {
     int cx, cy, cz;
     float fx, fy, fz;
 };
+/* v_min_f32 / v_max_f32 as they are: fminf / fmaxf make the compiler put a quieting v_max x,x in front of every operand
+ * it cannot prove free of signalling NaNs (IEEE mode), which in the march loop is most of them.  Same results as fminf /
+ * fmaxf for every input (a NaN operand loses against a number). */
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ Cell cell_at(const RaySeg& R, float t) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 uxy = __builtin_elementwise_fma((f2){R.ud.x, R.ud.y}, (f2){t, t}, (f2){R.uo.x, R.uo.y}); /* one v_pk_fma_f32 */
@@ -430,6 +447,7 @@ __device__ __forceinline__ float leap_of(const RaySeg& R, const Cell& c, unsigne
     return B > 0u ? (float)B * R.leap_unit : (float)((nibw >> (4u * k)) & 15u) * R.cell_unit;
 }
 
+constexpr float kRelaxGate = 0.8f; /* over-relaxation: a step is stretched only when the sample is at least this fraction of the one before */
 constexpr int kRefine = 3; /* secant samples spent on a hit that overshot into the surface */
 
 /*
@@ -604,7 +622,8 @@ struct MarchState {
     float t, t_prev, s_prev, s_hit;
     int i;                 /* iterations so far: positions visited, sampled or skipped */
     bool hit;
-    bool relaxed;          /* over-relaxation (k_relax > 1): the step that led to the current position was a stretched one */
+    float chk;             /* over-relaxation (k_relax > 1): s_prev when the step that led to the current position was a stretched
+                              one (the next sample checks the overlap of the two empty spheres), else +inf */
     Cell c;
 };
 
@@ -622,7 +641,7 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
     float t = st.t, t_prev = st.t_prev, s_prev = st.s_prev;
     int i = st.i;
     Cell c = st.c;
-    bool relaxed = st.relaxed;
+    float chk = st.chk;
     const bool tables = V.skip != nullptr;
     unsigned last_brick = 0xffffffffu, B = 1u, nibw = 0u;
     while (i < limit && !(t > R.t_end)) {
@@ -664,8 +683,8 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
                    condition, same advance) */
                 t_prev = t;
                 s_prev = R.smax;
-                relaxed = false;
-                t = t + __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
+                chk = __builtin_inff();
+                t = t + vmax(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
                 i++;
                 if constexpr (DIAG) {
                     dg->iters++;
@@ -683,49 +702,42 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
             dg->fetches += lat < 450 ? 1u : 0u;
             dg->iters++;
         }
-        for (;;) { /* samples inside this cell */
-            const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
-            steps++;
-            if (relaxed && __builtin_fmaxf(__builtin_fminf(s, R.smax), 0.0f) + s_prev < t - t_prev) {
-                /* over-relaxation (k_relax > 1): the empty spheres around the last two samples do not overlap — something may
-                   have been jumped over.  Back to the previous sample's plain step; that sample stays the "previous" one */
-                relaxed = false;
-                t = t_prev + __builtin_fmaxf(s_prev, __builtin_fmaf(t_prev, F.cone_eps, R.base_min));
-                i++;
-                break;
-            }
-            if (s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
-                st.hit = true;
-                st.s_hit = s;
-                break;
-            }
-            i++;
-            t_prev = t;
-            s_prev = __builtin_fminf(s, R.smax);
-            const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
-            const float om = F.k_relax;
-            const float step = __builtin_fmaxf(__builtin_fminf(s * om, om > 1.0f ? R.smax * om : R.smax), adv_min);
-            relaxed = step > __builtin_fmaxf(s_prev, adv_min);
-            t = t + step;
-            if (i >= limit || t > R.t_end) break;
-#ifndef VRT_AB_INCELL /* A/B build: while successive samples stay in one cell the 8 taps stay in registers.  Measured
-                         (profiles/r02_ab_march_variants.txt): 12 % slower with one frame in flight — the lanes of a wave that
-                         changed cell wait for the in-cell samples of the others before any of them may fetch */
+        const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
+        steps++;
+        /* Over-relaxation (k_relax > 1): when the step that led here was a stretched one (chk = the previous sample's empty
+           radius, else +inf), the empty spheres around the two samples must overlap; if they do not, something may have been
+           jumped over and the ray goes BACK to the previous sample's plain step (that sample stays the "previous" one).
+           Written with selects, not branches: the lanes of a wave that go back and those that go on run the same code. */
+        const float s_clamped = vmin(s, R.smax);
+        const bool back = vmax(s_clamped, 0.0f) + chk < t - t_prev;
+        if (!back && s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
+            st.hit = true;
+            st.s_hit = s;
+            if constexpr (DIAG) dg->loop += stamp() - st0;
             break;
-#endif
-            const Cell c2 = cell_at(R, t);
-            if (c2.cx != c.cx || c2.cy != c.cy || c2.cz != c.cz) break;
-            c = c2;
         }
+        i++;
+        const float s_gate = kRelaxGate * s_prev;
+        const float from = back ? t_prev : t;                 /* where the next step starts */
+        const float radius = back ? s_prev : s_clamped;       /* the empty radius there */
+        const float adv_min = vmax(__builtin_fmaf(from, F.cone_eps, R.base_min), back ? 0.0f : leap);
+        const float plain = vmax(radius, adv_min);
+        const float stretched = vmax(vmin(s * F.k_relax, R.smax_relax), adv_min);
+        /* stretched only while the distance is not falling fast (a ray running at a surface would overshoot and come
+           back) and the next sample stays inside the interval (beyond it nothing checks the overlap) */
+        const bool relax = !back && stretched > plain && s >= s_gate && t + stretched <= R.t_end;
+        t_prev = from;
+        s_prev = radius;
+        chk = relax ? radius : __builtin_inff();
+        t = from + (relax ? stretched : plain);
         if constexpr (DIAG) dg->loop += stamp() - st0;
-        if (st.hit) break;
     }
     st.t = t;
     st.t_prev = t_prev;
     st.s_prev = s_prev;
     st.i = i;
     st.c = c;
-    st.relaxed = relaxed;
+    st.chk = chk;
 }
 
 /*
@@ -753,7 +765,7 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     st.s_prev = st.s_hit = 0.0f;
     st.i = 0;
     st.hit = false;
-    st.relaxed = false;
+    st.chk = __builtin_inff();
     st.c = Cell{0, 0, 0, 0.0f, 0.0f, 0.0f};
     march_lane<DP, DIAG>(F, V, R, st, F.max_steps, steps, dg);
     if (!st.hit) {
@@ -798,7 +810,11 @@ __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float
                 const DInstance* I = F.inst + ii;
                 float t;
                 F3 n;
-                if (march_instance<PATH, NORMAL, DIAG>(F, I, F.vols + I->slot, o, d, best, t_base, t, n, steps, dg)) {
+                /* a sphere-trace covers the instance's whole interval whatever was hit before (where its stretched steps
+                   fall depends on the interval's end: cut at `best` the result would depend on the visiting order); the
+                   cell walk of the Cube modes has no such state and stops at the closest hit so far */
+                constexpr bool kCube = PATH == kPathCube || PATH == kPathCube16;
+                if (march_instance<PATH, NORMAL, DIAG>(F, I, F.vols + I->slot, o, d, kCube ? best : t_max, t_base, t, n, steps, dg)) {
                     if (!any || t < best || (t == best && ii < inst_best)) {
                         any = true;
                         best = t;
@@ -1425,7 +1441,7 @@ __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V,
                                                float* __restrict__ slots, unsigned* __restrict__ tags, int lane, unsigned& steps) {
     float t = st.t, t_prev = st.t_prev, s_prev = st.s_prev;
     int i = st.i;
-    bool relaxed = st.relaxed;
+    bool relaxed = st.chk < __builtin_inff(); /* the step that led to the current position was a stretched one (march_lane) */
     const int max_steps = F.max_steps;
     const unsigned nb = (unsigned)V.nb;
     for (;;) {
@@ -1507,13 +1523,15 @@ __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V,
                 active = false;
             } else {
                 i++;
+                const float s_gate = kRelaxGate * s_prev;
                 t_prev = t;
                 s_prev = __builtin_fminf(s, R.smax);
                 const float adv_min = __builtin_fmaxf(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
                 const float om = F.k_relax;
-                const float step = __builtin_fmaxf(__builtin_fminf(s * om, om > 1.0f ? R.smax * om : R.smax), adv_min);
-                relaxed = step > __builtin_fmaxf(s_prev, adv_min);
-                t = t + step;
+                const float plain = __builtin_fmaxf(s_prev, adv_min);
+                const float stretched = __builtin_fmaxf(__builtin_fminf(s * om, R.smax_relax), adv_min);
+                relaxed = stretched > plain && s >= s_gate && t + stretched <= R.t_end;
+                t = t + (relaxed ? stretched : plain);
             }
         }
         if (active) { /* keep the lane's state current: it is read back when the lane retires */
@@ -1541,7 +1559,7 @@ __device__ __forceinline__ bool march_hybrid(const DFrame& F, const VolRef& V, c
     st.s_prev = st.s_hit = 0.0f;
     st.i = 0;
     st.hit = false;
-    st.relaxed = false;
+    st.chk = __builtin_inff();
     st.c = Cell{0, 0, 0, 0.0f, 0.0f, 0.0f};
     const int max_steps = F.max_steps;
     const int head = max_steps < kHeadSteps ? max_steps : kHeadSteps;
