@@ -558,13 +558,12 @@ inline float trilinear(const Volume& v, int cx, int cy, int cz, float fx, float 
     const float* b1 = b0 + N;                                                  /* x0, z1 */
     const float* b2 = b0 + N * N;                                              /* x1, z0 */
     const float* b3 = b2 + N;                                                  /* x1, z1 */
-    float a00 = lerp1(b0[0], b0[1], fy);
-    float a01 = lerp1(b1[0], b1[1], fy);
-    float a10 = lerp1(b2[0], b2[1], fy);
-    float a11 = lerp1(b3[0], b3[1], fy);
-    float c0 = lerp1(a00, a01, fz);
-    float c1 = lerp1(a10, a11, fz);
-    return lerp1(c0, c1, fx);
+    /* z, then x, then y (the order the kernel's packed arithmetic takes: the two y values of a load travel together) */
+    float a0y0 = lerp1(b0[0], b1[0], fz), a0y1 = lerp1(b0[1], b1[1], fz); /* x0 */
+    float a1y0 = lerp1(b2[0], b3[0], fz), a1y1 = lerp1(b2[1], b3[1], fz); /* x1 */
+    float c0 = lerp1(a0y0, a1y0, fx);
+    float c1 = lerp1(a0y1, a1y1, fx);
+    return lerp1(c0, c1, fy);
 }
 
 struct Stats {
@@ -577,6 +576,15 @@ thread_local uint64_t g_exhausted = 0;
    rays that follow it [1] — what the length of a GPU lane's dependent chain is made of */
 thread_local uint64_t g_positions[2] = {0, 0};
 thread_local int g_ray_class = 0;
+/* debug only (vrto_debug_set_position_log): one record {t, s or NaN when skipped, leap, step taken} per position */
+float* g_pos_log = nullptr;
+int g_pos_log_cap = 0, g_pos_log_n = 0;
+inline void log_position(float t, float s, float leap, float step) {
+    if (g_pos_log && g_pos_log_n < g_pos_log_cap) {
+        float* r = g_pos_log + 4 * (size_t)g_pos_log_n++;
+        r[0] = t; r[1] = s; r[2] = leap; r[3] = step;
+    }
+}
 
 struct HitRec {
     float t;
@@ -777,6 +785,7 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
                 t_prev = t;
                 s_prev = smax;
                 relaxed = false;
+                log_position(t, std::numeric_limits<float>::quiet_NaN(), leap, fmaxf(fmaf(t, P.prm.cone_eps, base_min), leap));
                 t = t + fmaxf(fmaf(t, P.prm.cone_eps, base_min), leap);
                 continue;
             }
@@ -786,6 +795,7 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
         if (relaxed && fmaxf(fminf(s, smax), 0.0f) + s_prev < t - t_prev) {
             /* the spheres do not overlap: back to the previous sample's plain step (that sample stays the "previous" one) */
             relaxed = false;
+            log_position(t, s, leap, t_prev + fmaxf(s_prev, fmaf(t_prev, P.prm.cone_eps, base_min)) - t); /* negative: went back */
             t = t_prev + fmaxf(s_prev, fmaf(t_prev, P.prm.cone_eps, base_min));
             continue;
         }
@@ -855,6 +865,7 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
            come back, it is the grazing ray whose chain the stretch shortens — and (b) the next sample stays inside the
            interval: past its end there is no sample to check the overlap with */
         relaxed = stretched > plain && s >= kRelaxGate * s_old && t + stretched <= t_end;
+        log_position(t, s, leap, relaxed ? stretched : plain);
         t = t + (relaxed ? stretched : plain);
     }
     if (P.prm.max_steps > 0 && !(t > t_end)) g_exhausted++;
@@ -1220,6 +1231,13 @@ extern "C" {
 
 static uint32_t* g_steps_img = nullptr;
 void vrto_debug_set_steps_image(uint32_t* img) { g_steps_img = img; }
+int vrto_debug_set_position_log(float* records, int capacity) {
+    const int n = g_pos_log_n;
+    g_pos_log = records;
+    g_pos_log_cap = records ? capacity : 0;
+    g_pos_log_n = 0;
+    return n;
+}
 
 int vrto_render(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env_rgba8, int env_face_size,
                 const vrt_params* params, int row0, int rows, float* out_rgba, vrto_stats* stats_or_null,

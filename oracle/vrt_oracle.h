@@ -57,6 +57,10 @@ int vrto_render(const vrt_scene* scene, const vrto_volume* volumes,
  * or skipped) its primary ray visited (low 16 bits) and the rays after it visited (high 16 bits) into img (rows*width):
  * the length of the dependent chain a GPU lane runs for that pixel (tests/chain_lengths.py).  Not thread-safe. */
 void vrto_debug_set_steps_image(uint32_t* img);
+/* Debug: while set, every march position of vrto_trace (single-threaded) appends {t, sample or NaN when skipped, leap, step
+ * taken (negative: the over-relaxed march went back)} to records (4 floats each, at most capacity).  Returns the number of
+ * records written since the previous call. */
+int vrto_debug_set_position_log(float* records, int capacity);
 
 /* Single-ray probes used by the analytic pins (world-space ray, direction is normalised
  * internally; returns 1 on hit and writes t / world normal / instance index). */

@@ -29,9 +29,11 @@ r.SyncWithScene()
 print(f"{label}; GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}")
 print("ranks  K  ms/frame(rank 0 alone)  frames/s  -> whole-job Grays/s if every rank keeps that rate")
 full = None
-for n in (1, 2, 4, 8):
+NS = [int(x) for x in os.environ.get("PROBE_RANKS", "1,2,4,8").split(",")]
+KS = [int(x) for x in os.environ.get("PROBE_FRAMES_IN_FLIGHT", "1,2,3,4,6,8").split(",")]
+for n in NS:
     _, per = strip_layout(H, n, 32)
-    for K in (1, 2, 3, 4, 6, 8):
+    for K in KS:
         streams = [torch.cuda.Stream() for _ in range(K)]
         tiles = [torch.zeros((per * 32, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(K)]
 
@@ -48,6 +50,9 @@ for n in (1, 2, 4, 8):
             run(steps)
             dt = min(dt, (time.perf_counter() - t0) / steps)
         if full is None:
+            if n != 1:
+                r.render_strips(p, 32, 0, 1, strip_layout(H, 1, 32)[1], torch.zeros((strip_layout(H, 1, 32)[1] * 32, W, 4), dtype=torch.uint8, device="cuda:0").data_ptr(), 0)
+                torch.cuda.synchronize()
             t = r.last_timing()
             full = t["primary_rays"] + t["shadow_rays"]  # n = 1: the whole frame's rays
         print(f"  {n}    {K}   {dt * 1e3:.4f}   {1 / dt:9.0f}   {full / dt / 1e9:7.2f}")

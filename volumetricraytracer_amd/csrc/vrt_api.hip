@@ -60,7 +60,7 @@ RcclApi* rccl() {
     return api.ok ? &api : nullptr;
 }
 
-constexpr int kStatSlots = 8; /* streams that may have launches in flight at once without sharing a counter buffer */
+constexpr int kStatSlots = 16; /* streams that may have launches in flight at once without sharing a counter buffer */
 constexpr int kRing = 256; /* per-launch event pairs + stat slots kept for vrt_timing_history */
 
 struct HostVolume {

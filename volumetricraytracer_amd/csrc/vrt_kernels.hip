@@ -216,20 +216,18 @@ __device__ __forceinline__ Taps fetch8(const VolRef& V, int cx, int cy, int cz) 
     return fetch8_at<DP>(V, DP == VRT_PATH_DENSE ? 0u : brick_index(V, cx, cy, cz), cx, cy, cz);
 }
 
-/* Trilinear interpolant from the taps: y-lerps, z-lerps, x-lerp (each lerp is one sub + one fma, exactly as the
- * oracle does them).  A dwordx2 load delivers the two operands of ONE y-lerp, so the four y-lerps are scalar
- * ops straight on the loaded pairs; their results are placed so that the two z-lerps are one packed sub and
- * one packed fma (v_pk_*_f32 does two fp32 lanes per issue slot — the march is VALU-issue bound). */
+/* Trilinear interpolant from the taps, lerp by lerp as the oracle does them (each one sub + one fma): over z, over x, then
+ * over y.  (v_pk_*_f32 does two fp32 lanes per issue slot, and the march loop is short of issue slots.) */
 typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float lerp8(const Taps& t, float fx, float fy, float fz) {
-    float2v a0, a1; /* a0 = (z0 at x0, z0 at x1), a1 = (z1 at x0, z1 at x1) */
-    a0.x = lerp1(t.y00a, t.y00b, fy);
-    a1.x = lerp1(t.y01a, t.y01b, fy);
-    a0.y = lerp1(t.y10a, t.y10b, fy);
-    a1.y = lerp1(t.y11a, t.y11b, fy);
-    const float2v w = {fz, fz};
-    const float2v c = __builtin_elementwise_fma(w, a1 - a0, a0); /* (c0, c1) = lerp over z at x0 and x1 */
-    return lerp1(c.x, c.y, fx);
+    /* z, then x, then y: a load returns the pair (y, y+1) in adjacent registers, so the z- and x-lerps run on both y values
+       at once — three packed subs and three packed fmas (v_pk_*_f32), then one scalar lerp over y */
+    const float2v p00 = {t.y00a, t.y00b}, p01 = {t.y01a, t.y01b}, p10 = {t.y10a, t.y10b}, p11 = {t.y11a, t.y11b};
+    const float2v wz = {fz, fz}, wx = {fx, fx};
+    const float2v a0 = __builtin_elementwise_fma(wz, p01 - p00, p00); /* x0: lerp over z */
+    const float2v a1 = __builtin_elementwise_fma(wz, p11 - p10, p10); /* x1 */
+    const float2v c = __builtin_elementwise_fma(wx, a1 - a0, a0);     /* lerp over x */
+    return lerp1(c.x, c.y, fy);
 }
 
 template <int DP>
