@@ -636,13 +636,15 @@ struct MarchState {
 template <int DP, bool DIAG>
 __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, const RaySeg& R, MarchState& st, int limit, unsigned& steps,
                                            DiagAcc* dg) {
-    float t = st.t, t_prev = st.t_prev, s_prev = st.s_prev;
+    float t = st.t, t_prev = st.t_prev, s_prev = st.s_prev, chk = st.chk;
+    /* the lane's own end of the interval: -inf once it has hit, so that the loop has ONE exit test and no break (a divergent
+       break costs a handful of mask operations in every iteration of every lane) */
+    float t_end = R.t_end;
     int i = st.i;
     Cell c = st.c;
-    float chk = st.chk;
     const bool tables = V.skip != nullptr;
     unsigned last_brick = 0xffffffffu, B = 1u, nibw = 0u;
-    while (i < limit && !(t > R.t_end)) {
+    while (i < limit && !(t > t_end)) {
         unsigned long long st0 = 0, st1 = 0;
         if constexpr (DIAG) st0 = stamp();
         c = cell_at(R, t);
@@ -651,85 +653,68 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
             st1 = stamp();
         }
         const unsigned brick = brick_index(V, c.cx, c.cy, c.cz);
-        Taps taps;
-        bool have_taps = false;
         float leap = 0.0f;
+        bool skip = false;
         if (tables) {
-#ifdef VRT_AB_NO_BRICK_CACHE /* A/B build (tools/ab_lib_variants.sh): table words re-read at every position */
-            last_brick = 0xffffffffu;
-#endif
-            if (brick != last_brick) {
-#ifdef VRT_AB_SPEC /* A/B build: a ray leaving a near brick asks for the next brick's taps together with its table words.
-                      Measured (profiles/r02_ab_march_variants.txt): 7 % slower — the wasted taps cost more TA time than the
-                      saved round trip gains */
-                const bool spec = B == 0u;
-#else
-                const bool spec = false;
-#endif
+            if (brick != last_brick) { /* the two table words are re-read only when the ray changes brick */
                 B = V.skip[brick];
                 nibw = V.nib[brick];
-                if (spec) {
-                    taps = fetch8_at<DP>(V, brick, c.cx, c.cy, c.cz);
-                    have_taps = true;
-                }
                 last_brick = brick;
             }
             leap = leap_of(R, c, B, nibw);
+            /* no active cell within the leap: the sample could neither hit nor shorten the step (oracle: same condition,
+               same advance) */
             const float thr = __builtin_fmaf(t, F.cone_eps, F.eps_hit);
-            if (leap > 0.0f && leap >= R.smax && thr + thr <= R.smax) {
-                /* no active cell within the leap: the sample could neither hit nor shorten the step (oracle: same
-                   condition, same advance) */
-                t_prev = t;
-                s_prev = R.smax;
-                chk = __builtin_inff();
-                t = t + vmax(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
+            skip = leap > 0.0f && leap >= R.smax && thr + thr <= R.smax;
+        }
+        if (skip) {
+            t_prev = t;
+            s_prev = R.smax;
+            chk = __builtin_inff();
+            t = t + vmax(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
+            i++;
+            if constexpr (DIAG) dg->iters++;
+        } else {
+            const Taps taps = fetch8_at<DP>(V, brick, c.cx, c.cy, c.cz);
+            if constexpr (DIAG) {
+                asm volatile("s_waitcnt vmcnt(0)" ::"v"(taps.y00a), "v"(taps.y00b), "v"(taps.y01a), "v"(taps.y01b), "v"(taps.y10a),
+                             "v"(taps.y10b), "v"(taps.y11a), "v"(taps.y11b));
+                const unsigned long long lat = stamp() - st1;
+                dg->mem += lat; /* address arithmetic + table words + 4 loads until the data is back */
+                dg->fetches += lat < 450 ? 1u : 0u;
+                dg->iters++;
+            }
+            const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
+            steps++;
+            /* Over-relaxation (k_relax > 1): when the step that led here was a stretched one (chk = the previous sample's
+               empty radius, else +inf), the empty spheres around the two samples must overlap; if they do not, something
+               may have been jumped over and the ray goes BACK to the previous sample's plain step (that sample stays the
+               "previous" one).  Written with selects: the lanes that go back and those that go on run the same code. */
+            const float s_clamped = vmin(s, R.smax);
+            const bool back = vmax(s_clamped, 0.0f) + chk < t - t_prev;
+            if (!back && s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
+                st.s_hit = s;
+                t_end = -__builtin_inff(); /* hit: t, c, t_prev, s_prev and i stay as they are */
+            } else {
                 i++;
-                if constexpr (DIAG) {
-                    dg->iters++;
-                    dg->loop += stamp() - st0;
-                }
-                continue;
+                const float s_gate = kRelaxGate * s_prev;
+                const float from = back ? t_prev : t;           /* where the next step starts */
+                const float radius = back ? s_prev : s_clamped; /* the empty radius there */
+                const float adv_min = vmax(__builtin_fmaf(from, F.cone_eps, R.base_min), back ? 0.0f : leap);
+                const float plain = vmax(radius, adv_min);
+                const float stretched = vmax(vmin(s * F.k_relax, R.smax_relax), adv_min);
+                /* stretched only while the distance is not falling fast (a ray running at a surface would overshoot and come
+                   back) and the next sample stays inside the interval (beyond it nothing checks the overlap) */
+                const bool relax = !back && stretched > plain && s >= s_gate && t + stretched <= R.t_end;
+                t_prev = from;
+                s_prev = radius;
+                chk = relax ? radius : __builtin_inff();
+                t = from + (relax ? stretched : plain);
             }
         }
-        if (!have_taps) taps = fetch8_at<DP>(V, brick, c.cx, c.cy, c.cz);
-        if constexpr (DIAG) {
-            asm volatile("s_waitcnt vmcnt(0)" ::"v"(taps.y00a), "v"(taps.y00b), "v"(taps.y01a), "v"(taps.y01b), "v"(taps.y10a),
-                         "v"(taps.y10b), "v"(taps.y11a), "v"(taps.y11b));
-            const unsigned long long lat = stamp() - st1;
-            dg->mem += lat; /* address arithmetic + table words + 4 loads until the data is back */
-            dg->fetches += lat < 450 ? 1u : 0u;
-            dg->iters++;
-        }
-        const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
-        steps++;
-        /* Over-relaxation (k_relax > 1): when the step that led here was a stretched one (chk = the previous sample's empty
-           radius, else +inf), the empty spheres around the two samples must overlap; if they do not, something may have been
-           jumped over and the ray goes BACK to the previous sample's plain step (that sample stays the "previous" one).
-           Written with selects, not branches: the lanes of a wave that go back and those that go on run the same code. */
-        const float s_clamped = vmin(s, R.smax);
-        const bool back = vmax(s_clamped, 0.0f) + chk < t - t_prev;
-        if (!back && s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
-            st.hit = true;
-            st.s_hit = s;
-            if constexpr (DIAG) dg->loop += stamp() - st0;
-            break;
-        }
-        i++;
-        const float s_gate = kRelaxGate * s_prev;
-        const float from = back ? t_prev : t;                 /* where the next step starts */
-        const float radius = back ? s_prev : s_clamped;       /* the empty radius there */
-        const float adv_min = vmax(__builtin_fmaf(from, F.cone_eps, R.base_min), back ? 0.0f : leap);
-        const float plain = vmax(radius, adv_min);
-        const float stretched = vmax(vmin(s * F.k_relax, R.smax_relax), adv_min);
-        /* stretched only while the distance is not falling fast (a ray running at a surface would overshoot and come
-           back) and the next sample stays inside the interval (beyond it nothing checks the overlap) */
-        const bool relax = !back && stretched > plain && s >= s_gate && t + stretched <= R.t_end;
-        t_prev = from;
-        s_prev = radius;
-        chk = relax ? radius : __builtin_inff();
-        t = from + (relax ? stretched : plain);
         if constexpr (DIAG) dg->loop += stamp() - st0;
     }
+    st.hit = t_end < R.t_end;
     st.t = t;
     st.t_prev = t_prev;
     st.s_prev = s_prev;
