@@ -747,6 +747,10 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
     /* smallest step: one pixel-footprint radius at the total path length t_base + t (t_base = length of
        the path that led to this ray's origin: 0 for camera rays, the hit distance for shadow rays) */
     const float base_min = fmaf(t_base, P.prm.cone_eps, P.prm.step_min);
+    /* up to here the hit threshold eps_hit + cone_eps*t is at most smax/2 (the margin covers rounding) */
+    const float t_skip_end = P.prm.cone_eps > 0.0f ? (0.5f * smax - P.prm.eps_hit) / P.prm.cone_eps
+                                                   : (P.prm.eps_hit + P.prm.eps_hit <= smax ? std::numeric_limits<float>::infinity()
+                                                                                             : -std::numeric_limits<float>::infinity());
     const float leap_unit = (4.0f * V.cell) * inv_len; /* one brick edge in ray-parameter units */
     const float cell_unit = leap_unit * 0.25f;         /* one cell edge */
     float t_prev = t, s_prev = 0.0f;
@@ -780,8 +784,7 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
             /* No active cell here: a sample would be >= smax, so it cannot be a hit while the threshold is below smax
                (factor 2: rounding margin), and max(min(s*k, smax), footprint, leap) = max(footprint, leap) once
                leap >= smax.  The ray advances without sampling (no tap is read, no sample is counted). */
-            const float thr = fmaf(t, P.prm.cone_eps, P.prm.eps_hit);
-            if (leap > 0.0f && leap >= smax && thr + thr <= smax) {
+            if (leap > 0.0f && leap >= smax && t <= t_skip_end) {
                 t_prev = t;
                 s_prev = smax;
                 relaxed = false;

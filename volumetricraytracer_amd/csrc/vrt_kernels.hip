@@ -322,6 +322,7 @@ struct RaySeg {
     float ds;             /* density → ray-parameter distance: density_scale / |od| */
     float smax;           /* step_max / |od| */
     float smax_relax;     /* the longest stretched step: smax * max(k_relax, 1) */
+    float t_skip_end;     /* up to this t the hit threshold is at most smax / 2: a position without an active cell in reach may be skipped */
     float cmax;           /* N - 2 */
     float base_min;       /* step_min + cone_eps * t_base */
     float leap_unit;      /* one brick edge (4 cells) in ray-parameter units */
@@ -360,6 +361,8 @@ __device__ __forceinline__ bool setup_ray(const DFrame& F, const DInstance* __re
     R.ds = V.dscale * inv_len;
     R.smax = V.step_max * inv_len;
     R.smax_relax = F.k_relax > 1.0f ? R.smax * F.k_relax : R.smax;
+    R.t_skip_end = F.cone_eps > 0.0f ? (0.5f * R.smax - F.eps_hit) / F.cone_eps
+                                     : (F.eps_hit + F.eps_hit <= R.smax ? __builtin_inff() : -__builtin_inff());
     R.uo = f3((R.oo.x + V.extent) * V.inv_cell, (R.oo.y + V.extent) * V.inv_cell, (R.oo.z + V.extent) * V.inv_cell);
     R.ud = R.od * V.inv_cell;
     R.cmax = (float)(V.N - 2);
@@ -388,6 +391,8 @@ __device__ __forceinline__ bool setup_shadow_ray(const DFrame& F, const DInstanc
     R.ds = V.dscale * inv_len;
     R.smax = V.step_max * inv_len;
     R.smax_relax = F.k_relax > 1.0f ? R.smax * F.k_relax : R.smax;
+    R.t_skip_end = F.cone_eps > 0.0f ? (0.5f * R.smax - F.eps_hit) / F.cone_eps
+                                     : (F.eps_hit + F.eps_hit <= R.smax ? __builtin_inff() : -__builtin_inff());
     R.uo = f3((R.oo.x + V.extent) * V.inv_cell, (R.oo.y + V.extent) * V.inv_cell, (R.oo.z + V.extent) * V.inv_cell);
     R.ud = R.od * V.inv_cell;
     R.cmax = (float)(V.N - 2);
@@ -662,10 +667,9 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
                 last_brick = brick;
             }
             leap = leap_of(R, c, B, nibw);
-            /* no active cell within the leap: the sample could neither hit nor shorten the step (oracle: same condition,
-               same advance) */
-            const float thr = __builtin_fmaf(t, F.cone_eps, F.eps_hit);
-            skip = leap > 0.0f && leap >= R.smax && thr + thr <= R.smax;
+            /* no active cell within the leap, and the hit threshold still below half the clamp: the sample could neither hit
+               nor shorten the step (oracle: same condition, same advance; smax > 0 wherever there are tables) */
+            skip = leap >= R.smax && t <= R.t_skip_end;
         }
         if (skip) {
             t_prev = t;
@@ -1437,8 +1441,7 @@ __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V,
         if (V.skip != nullptr && active) {
             const unsigned brick = (bx * nb + bz) * nb + by;
             leap = leap_of(R, c, (unsigned)V.skip[brick], V.nib[brick]);
-            const float thr = __builtin_fmaf(t, F.cone_eps, F.eps_hit);
-            if (leap > 0.0f && leap >= R.smax && thr + thr <= R.smax) {
+            if (leap >= R.smax && t <= R.t_skip_end) {
                 t_prev = t;
                 s_prev = R.smax;
                 relaxed = false;
