@@ -868,8 +868,9 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
            come back, it is the grazing ray whose chain the stretch shortens — and (b) the next sample stays inside the
            interval: past its end there is no sample to check the overlap with */
         relaxed = stretched > plain && s >= kRelaxGate * s_old && t + stretched <= t_end;
-        log_position(t, s, leap, relaxed ? stretched : plain);
-        t = t + (relaxed ? stretched : plain);
+        log_position(t, s, leap, (relaxed || om < 1.0f) ? stretched : plain);
+        /* k_relax < 1: every distance-driven step is scaled down (a field steeper than a distance), never stretched */
+        t = t + ((relaxed || om < 1.0f) ? stretched : plain);
     }
     if (P.prm.max_steps > 0 && !(t > t_end)) g_exhausted++;
     return false;

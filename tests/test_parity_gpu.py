@@ -279,6 +279,39 @@ def test_shell_volume_paths_and_formats_parity(renderer, oracle_lib, path, fmt):
     assert_parity(renderer, full, p, check_stats=False)
 
 
+@pytest.mark.parametrize("k_relax", [0.6, 1.0, 1.3, 1.7, 2.0])
+def test_over_relaxation_factors_parity(renderer, oracle_lib, k_relax):
+    """vrt_params.k_relax: below 1 every step is scaled down, 1 is plain sphere tracing, above 1 steps are stretched and
+    checked by the overlap of successive empty spheres (the march goes back where they do not overlap).  Every factor, on the
+    Voxelizer shell (tables, clamp), a metric SDF (no clamp, no tables), an instanced scene through the BVH (the stretched
+    steps depend on the interval's end: the result must not depend on the visiting order) and a one-cell-thick shell (the
+    worst case for a stretched step): pixels <= 1e-4 and counters exact against the oracle on the per-lane and the LDS paths;
+    for the thin shell also the same hit mask as plain sphere tracing."""
+    shell = scenes.config3_voxelized(6, 16)
+    for path in (_abi.PATH_BRICK, _abi.PATH_BRICK_LDS, _abi.PATH_DENSE):
+        p = v.default_params(256, 144, scenes.min_cell(shell), 255, shadow=True, path=path, k_relax=k_relax)
+        assert_parity(renderer, shell, p)
+    sdf = scenes.config3_torus(6, 16)
+    assert_parity(renderer, sdf, v.default_params(256, 144, scenes.min_cell(sdf), 255, shadow=True, k_relax=k_relax))
+    inst = scenes.config5_instances(5, 16)
+    assert_parity(renderer, inst, v.default_params(240, 136, scenes.min_cell(inst), 255, shadow=True, k_relax=k_relax), check_stats=False)
+    vol = v.VVoxelVolume(6, 100.0)
+    half = 0.5 * float(vol.GetCellSize())
+    vol.fill(lambda X, Y, Z: np.abs(np.sqrt(X * X + Y * Y + Z * Z) - 60.0) - half)
+    thin = v.VScene(Camera=sdf.Camera, DirectionalLight=sdf.DirectionalLight, Objects=[v.VVoxelObject(Volume=vol)])
+
+    def unlit(k):
+        q = v.default_params(256, 144, vol.GetCellSize(), 255, shadow=False, k_relax=k)
+        q.mode = _abi.MODE_INTERP_NOTEX_UNLIT  # a hit pixel is the tint, a miss is black (no sky box)
+        return q
+
+    img, t = assert_parity(renderer, thin, unlit(k_relax))
+    plain, t1 = gpu_render(renderer, thin, unlit(1.0))
+    hit, hit1 = img[..., :3].sum(axis=2) > 0, plain[..., :3].sum(axis=2) > 0
+    assert hit1.mean() > 0.05 and (hit != hit1).mean() < 0.002  # silhouette pixels may differ, nothing inside the disc may
+    assert abs(t["hits"] - t1["hits"]) <= 0.002 * img.shape[0] * img.shape[1]
+
+
 def test_reference_texel_upload_is_the_texel16_format(renderer, oracle_lib):
     """R6: vrt_volume_upload_texels takes the reference's own RGBA8 volume texture (UpdateVolumeTexture,
     RDXVoxelVolume.cpp:294-327).  Same frame, bit for bit, as the fp32 upload in VRT_FORMAT_TEXEL16 (which quantises on the

@@ -713,7 +713,8 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
                 t_prev = from;
                 s_prev = radius;
                 chk = relax ? radius : __builtin_inff();
-                t = from + (relax ? stretched : plain);
+                /* k_relax < 1 (wave-uniform): every distance-driven step is scaled down, never stretched */
+                t = from + ((relax || F.k_relax < 1.0f) ? stretched : plain);
             }
         }
         if constexpr (DIAG) dg->loop += stamp() - st0;
@@ -1517,7 +1518,7 @@ __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V,
                 const float plain = __builtin_fmaxf(s_prev, adv_min);
                 const float stretched = __builtin_fmaxf(__builtin_fminf(s * om, R.smax_relax), adv_min);
                 relaxed = stretched > plain && s >= s_gate && t + stretched <= R.t_end;
-                t = t + (relaxed ? stretched : plain);
+                t = t + ((relaxed || om < 1.0f) ? stretched : plain);
             }
         }
         if (active) { /* keep the lane's state current: it is read back when the lane retires */
