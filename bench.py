@@ -62,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 8],
                     help="frames launched before the first one must have finished, each on its own HIP stream and tile "
                          "buffer; 0 = 3 on one GPU, what the reference keeps in flight (FrameCount, DXConstants.cpp:23), 8 on several")
+    ap.add_argument("--block-frames", type=int, default=0,
+                    help="frames issued per vrt_render_block call on one stream (one event pair per block); 0 = default")
     ap.add_argument("--k-relax", type=float, default=0.0,
                     help="over-relaxation factor of the sphere trace (vrt_params.k_relax); 0 = the renderer's default (1.7), 1 = plain")
     ap.add_argument("--tile-map", default="supertile", choices=["supertile", "band", "linear"], help="blockIdx -> tile map (speed only)")
@@ -162,56 +164,79 @@ class _StreamEvent:
 
 
 class Pipeline:
-    """K frames in flight: K tile buffers, K HIP streams; the gather of frame i overlaps the march of i+1.."""
+    """K streams, each marching one frame at a time: K frames in flight.  Frames are issued in BLOCKS of up to G frames per
+    call on one stream (vrt_render_block: G launches back to back, one event pair per block instead of one per frame), blocks
+    round-robin over the streams.  N > 1: one gather per block (G tiles per rank in one collective, enqueued behind the
+    block's marches and overlapping the other streams' marches); rank 0 un-shuffles a gathered block of strips into frame
+    order with one strided copy on a stream of its own.  No cross-stream dependency on the march path: on this runtime
+    an event wait between streams costs several microseconds of queue time (profiles/r02_launch_overhead.txt)."""
 
-    def __init__(self, r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=False):
+    def __init__(self, r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=False, block_frames=8):
         import torch
 
         from volumetricraytracer_amd.tiles import FrameGather
 
         self.torch, self.r, self.p, self.world, self.rank, self.K = torch, r, p, world, rank, K
+        self.G = G = max(int(block_frames), 1)
         self.strip_rows, self.rehearsal, self.native = strip_rows, rehearsal, native and not rehearsal and world > 1
         pix = torch.uint8 if rgba8 else torch.float32
-        self.fg = FrameGather(H, W, world, rank, torch.device("cpu") if rehearsal else dev, dtype=pix, buffers=K, strip_rows=strip_rows)
+        self.fg = FrameGather(H, W, world, rank, torch.device("cpu") if rehearsal else dev, dtype=pix, buffers=K, strip_rows=strip_rows,
+                              frames_per_gather=G)
         self.march_tiles = [torch.zeros_like(x, device=dev) for x in self.fg.tiles] if rehearsal else self.fg.tiles
-        self.pending = [None] * K
+        self.frame_bytes = self.fg.rows_per * W * (4 if rgba8 else 16)
         # (the current stream + K-1 pool streams: with HIP's default 4 hardware queues this arrangement lands on distinct queues;
         # K pool streams measured 40 % slower at K = 3, profiles/r02_strong_scaling_probe.txt)
         self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(K - 1)]
-        # Rank 0 un-shuffles the gathered strips on a stream of its own: the copy only has to finish before the NEXT
-        # gather into the same frame buffer starts, not between two frames of a march stream.
+        self.pending = [None] * K
         self.unshuffle = world > 1 and rank == 0 and strip_rows > 0
         self.copy_stream = torch.cuda.Stream(device=dev) if self.unshuffle else None
         self.unshuffled = [None] * K
+        self.blocks = 0
+        self.last = (0, 0)  # (buffer, frame within the block) of the last frame issued
 
-    def step(self, i: int) -> None:
-        torch, fg, b = self.torch, self.fg, i % self.K
-        with torch.cuda.stream(self.streams[b]):
-            if self.pending[b] is not None:
-                self.pending[b].wait()  # tile buffer b is free again (its gather finished); stream b waits, not the host
-                self.pending[b] = None
-            if self.strip_rows > 0:
-                self.r.render_strips(self.p, self.strip_rows, self.rank, self.world, fg.strips_per, self.march_tiles[b].data_ptr(),
-                                     self.streams[b].cuda_stream)
-            else:
-                self.r.render_rows(self.p, fg.row0, fg.rows, self.march_tiles[b].data_ptr(), self.streams[b].cuda_stream)
-            if self.rehearsal:
-                fg.tiles[b].copy_(self.march_tiles[b])
-            if self.world > 1:
+    def run(self, steps: int) -> None:
+        """Issue exactly `steps` frames: blocks of G on stream 0, 1, ... K-1, 0, ...; the last round is dealt evenly."""
+        torch, fg, r = self.torch, self.fg, self.r
+        issued = 0
+        while issued < steps:
+            left = steps - issued
+            # the last K blocks share what is left evenly, so that no stream ends with a long queue while the others idle
+            n = min(self.G, max(1, -(-left // self.K)) if left < self.G * self.K else self.G)
+            b = self.blocks % self.K
+            st = self.streams[b]
+            with torch.cuda.stream(st):
+                if self.pending[b] is not None:
+                    self.pending[b].wait()  # this buffer's previous block has been gathered: stream b waits, not the host
+                    self.pending[b] = None
                 if self.unshuffled[b] is not None:
-                    self.streams[b].wait_event(self.unshuffled[b])
-                if self.native:  # ncclGather right behind the march on the same stream; "pending" = an event after it
-                    fg.native_gather(self.r, b, self.streams[b].cuda_stream)
-                    self.pending[b] = _StreamEvent(torch, self.streams[b])
+                    st.wait_event(self.unshuffled[b])
+                if self.strip_rows > 0:
+                    r.render_block(self.p, n, self.march_tiles[b].data_ptr(), self.frame_bytes, st.cuda_stream,
+                                   strips=(self.strip_rows, self.rank, self.world, fg.strips_per))
                 else:
-                    self.pending[b] = fg.gather(b, async_op=True)  # RCCL gather over xGMI, overlaps the following frames' march
-        if self.unshuffle:
-            with torch.cuda.stream(self.copy_stream):
-                self.pending[b].wait()  # the copy stream (not the host) waits for this gather (gloo rehearsal: the host does)
-                fg.unshuffle(b)         # gathered [rank, strip] order -> frame order, one strided device copy
-                if self.unshuffled[b] is None:
-                    self.unshuffled[b] = torch.cuda.Event()
-                self.unshuffled[b].record(self.copy_stream)
+                    r.render_block(self.p, n, self.march_tiles[b].data_ptr(), self.frame_bytes, st.cuda_stream, rows=(fg.row0, fg.rows))
+                if self.rehearsal:
+                    fg.tiles[b].copy_(self.march_tiles[b])
+                if self.world > 1:
+                    if self.native:  # ncclGather right behind the block's marches on the same stream; "pending" = an event after it
+                        fg.native_gather(r, b, st.cuda_stream)
+                        self.pending[b] = _StreamEvent(torch, st)
+                    else:
+                        self.pending[b] = fg.gather(b, async_op=True)  # RCCL gather over xGMI, overlaps the other streams' marches
+            if self.unshuffle:
+                with torch.cuda.stream(self.copy_stream):
+                    self.pending[b].wait()  # the copy stream (not the host) waits for this gather (gloo rehearsal: the host does)
+                    fg.unshuffle(b)         # gathered [rank, frame, strip] order -> frame order, one strided device copy
+                    if self.unshuffled[b] is None:
+                        self.unshuffled[b] = torch.cuda.Event()
+                    self.unshuffled[b].record(self.copy_stream)
+            self.last = (b, n - 1)
+            self.blocks += 1
+            issued += n
+
+    def last_frame(self):
+        """Rank 0: the assembled last frame issued."""
+        return self.fg.frame(*self.last)
 
     def drain(self) -> None:
         torch = self.torch
@@ -234,13 +259,11 @@ def timed_run(pipe: Pipeline, steps: int, warmup: int, world: int, cdev) -> floa
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(warmup):
-        pipe.step(i)
+    pipe.run(warmup)
     pipe.drain()
     barrier()
     t0 = time.perf_counter()
-    for i in range(steps):
-        pipe.step(i)
+    pipe.run(steps)
     pipe.drain()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -263,23 +286,30 @@ def launch_check(args) -> None:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    H, W, sr = 77, 16, 8
-    fg = FrameGather(H, W, world, rank, torch.device("cpu"), dtype=torch.uint8, buffers=1, strip_rows=sr if world > 1 else 0)
+    H, W, sr, G = 77, 16, 8, 3  # a block of G frames per gather, like the GPU pipeline
+    fg = FrameGather(H, W, world, rank, torch.device("cpu"), dtype=torch.uint8, buffers=1, strip_rows=sr if world > 1 else 0,
+                     frames_per_gather=G)
+
+    def tag(rows0, rows, g):  # a pixel value that names its frame row and its frame of the block
+        return ((torch.arange(rows0, rows0 + rows, dtype=torch.int32) + 7 * g) % 251).to(torch.uint8)[:, None, None]
+
     t0 = time.perf_counter()
     for _ in range(max(args.steps, 1)):
-        if world == 1:
-            fg.tiles[0][:H] = (torch.arange(H, dtype=torch.int32) % 251).to(torch.uint8)[:, None, None]
-            continue
-        for local0, frame0, rows in strip_frame_rows(H, world, rank, sr):
-            fg.tiles[0][local0:local0 + rows] = (torch.arange(frame0, frame0 + rows, dtype=torch.int32) % 251).to(torch.uint8)[:, None, None]
-        fg.gather(0, async_op=True).wait()
-        fg.unshuffle(0)
+        for g in range(G):
+            if world == 1:
+                fg.tile(0, g)[:H] = tag(0, H, g)
+                continue
+            for local0, frame0, rows in strip_frame_rows(H, world, rank, sr):
+                fg.tile(0, g)[local0:local0 + rows] = tag(frame0, rows, g)
+        if world > 1:
+            fg.gather(0, async_op=True).wait()
+            fg.unshuffle(0)
     te = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.barrier()
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
     if rank == 0:
-        ok = bool(np.array_equal(fg.frame(0)[:, 0, 0].numpy(), (np.arange(H) % 251).astype(np.uint8)))
+        ok = all(bool(np.array_equal(fg.frame(0, g)[:, 0, 0].numpy(), ((np.arange(H) + 7 * g) % 251).astype(np.uint8))) for g in range(G))
         print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_joined": world, "gathered_frame_ok": ok,
                           "elapsed_s": round(float(te.item()), 4)}), flush=True)
         if not ok:
@@ -388,18 +418,20 @@ def main() -> None:
     if args.gather == "native" and world > 1 and not native_ready and not rehearsal:
         raise SystemExit(f"[bench] --gather native: vrt_comm_init failed on some rank ({native_error})")
 
-    pipe = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=use_native)
+    # frames per vrt_render_block call: one GPU 2 (measured best at K = 3); several GPUs 8, gathered as ONE block per collective
+    G = args.block_frames or (2 if world == 1 else 8)
+    pipe = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=use_native, block_frames=G)
     elapsed = timed_run(pipe, args.steps, args.warmup, world, cdev)
 
     t = r.last_timing()  # this rank's tile, last frame (every frame is identical)
-    kms = r.timing_history(min(args.steps, 200))
+    kms = [x for x in r.timing_history(min(args.steps, 200)) if x > 0.0]  # the event-timed launches: the first frame of every block
     verified = None
     if os.environ.get("VRT_BENCH_VERIFY") and rank == 0 and args.steps > 0:
         # the gathered (and un-shuffled) frame must be the frame one GPU renders alone, bit for bit
         whole = torch.empty((H, W, 4), dtype=torch.uint8 if rgba8 else torch.float32, device=dev)
         r.render_rows(p, 0, H, whole.data_ptr(), pipe.streams[0].cuda_stream)
         torch.cuda.synchronize()
-        got = pipe.fg.frame((args.steps - 1) % K)
+        got = pipe.last_frame()
         verified = bool(torch.equal(got.cpu(), whole.cpu()))
         if not verified:
             raise SystemExit("[bench] gathered frame differs from the single-GPU frame")
@@ -422,12 +454,12 @@ def main() -> None:
     if world > 1 and native_ready and not args.no_extra_legs and args.steps > 0:
         # the other gather implementation, a few frames: same pixels on rank 0, and its frame time
         try:
-            other = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=not use_native)
+            other = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=not use_native, block_frames=G)
             osteps = max(min(args.steps, 30), 3)
             eo = timed_run(other, osteps, 2, world, cdev)
             same = True
             if rank == 0:
-                same = bool(torch.equal(other.fg.frame((osteps - 1) % K), pipe.fg.frame((args.steps - 1) % K)))
+                same = bool(torch.equal(other.last_frame(), pipe.last_frame()))
             native_check = {"gather": "torch" if use_native else "native (vrt_gather_tiles: ncclGather on the march stream)",
                             "ms_per_frame": round(eo / osteps * 1e3, 4), "same_frame_as_timed_run": same}
             del other
@@ -437,9 +469,9 @@ def main() -> None:
     if not args.no_extra_legs and args.steps > 0:
         lsteps = max(min(args.steps, 50), 5)
         # one frame in flight: what an application that waits for every frame sees
-        p1 = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, 1, rehearsal, native=use_native)
+        p1 = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, 1, rehearsal, native=use_native, block_frames=G)
         e1 = timed_run(p1, lsteps, 3, world, cdev)
-        k1 = r.timing_history(lsteps)
+        k1 = [x for x in r.timing_history(lsteps) if x > 0.0]
         latency = {"frames_in_flight": 1, "ms_per_frame": round(e1 / lsteps * 1e3, 4), "value": round(rays_per_frame * lsteps / e1 / 1e6, 2),
                    "unit": "Mrays/s", "kernel_ms": round(float(np.mean(k1)), 4) if k1 else None}
         del p1
@@ -449,7 +481,7 @@ def main() -> None:
             W4, H4 = 3840, 2160
             p4 = params(W4, H4)
             r.ResizeRenderOutput(W4, H4)
-            pipe4 = Pipeline(r, p4, W4, H4, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=use_native)
+            pipe4 = Pipeline(r, p4, W4, H4, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=use_native, block_frames=G)
             s4 = max(lsteps // 2, 5)
             e4 = timed_run(pipe4, s4, 3, world, cdev)
             c4 = job_counts(r.last_timing())
@@ -468,7 +500,7 @@ def main() -> None:
         r.SyncWithScene()
         pt = params(W, H)
         pt.path = _abi.PATH_CELLS
-        pipet = Pipeline(r, pt, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal)
+        pipet = Pipeline(r, pt, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, block_frames=G)
         et = timed_run(pipet, args.steps, args.warmup, world, cdev)
         ct = job_counts(r.last_timing())
         texel_leg = {"volume_format": "reference texel (sign + 15-bit |d|*100) as 16-byte cell records, --format texel16 --path cells",
@@ -512,10 +544,10 @@ def main() -> None:
                                          _abi.FORMAT_TEXEL16: "reference texel: sign + 15-bit |d|*100, 16-bit bricks (256 B per 4^3 cells)"}[fmt],
                        "max_steps": max_steps, "shadow": bool(shadow), "k_relax": round(float(p.k_relax), 3), "data_path": args.path,
                        "output": "rgba8 (R8G8B8A8_UNORM tiles; march and shading in f32)" if rgba8 else "f32 (float4)",
-                       "frames_in_flight": K,
+                       "frames_in_flight": K, "frames_per_call": G,
                        "parallelism": ("1 GPU" if world == 1 else
                                        (f"{strip_rows}-row interleaved strips" if strip_rows else "contiguous row tiles") +
-                                       f" x{world} + " + ("gloo gather, REHEARSAL on one GPU" if rehearsal else "RCCL gather to rank 0")),
+                                       f" x{world} + " + ("gloo gather, REHEARSAL on one GPU" if rehearsal else f"one RCCL gather to rank 0 per block of {G} frames")),
                        "rays_per_frame": int(rays_per_frame), "samples_per_ray": round((psteps + ssteps) / max(rays_per_frame, 1), 2)},
             "roofline": roofline, "cpu_baseline": cpu,
             "latency": latency, "end_to_end": end_to_end, "config4": config4, "reference_texel_format": texel_leg,

@@ -55,6 +55,10 @@ extern "C" {
                                    the reference's back-buffer precision (B8G8R8A8_UNORM, DXConstants.cpp:21);
                                    value = (uint)(min(c,1)*255 + 0.5) of the float channel the float4 path stores */
 
+#define VRT_FLAG_NO_TIMING 16    /* the launch records no event pair: vrt_last_timing / vrt_timing_history report 0 ms for it.
+                                   An event pair costs 5-7 us of queue time per launch (profiles/r02_launch_overhead.txt);
+                                   callers that keep many small launches in flight time a sample of them */
+
 enum vrt_status {
     VRT_OK = 0,
     VRT_ERR_INVALID = -1,     /* bad argument */
@@ -173,7 +177,7 @@ typedef struct vrt_params {
     int32_t max_bounces;  /* mirror-reflection depth, 0..2 (MAX_RAY_RECURSION_DEPTH 3 = primary + 2) */
     int32_t flags;        /* bits 0-1: blockIdx→tile map, 0 supertile (default) / 1 XCD band / 2 linear
                              (speed only, never results); bit 2: VRT_FLAG_DIAG_TIMELINE; bit 3:
-                             VRT_FLAG_OUTPUT_RGBA8.  Others 0 */
+                             VRT_FLAG_OUTPUT_RGBA8; bit 4: VRT_FLAG_NO_TIMING.  Others 0 */
     float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
     float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
     float step_min;       /* lower bound of one march step (ray-parameter units) */
@@ -293,6 +297,34 @@ int vrt_render_rows(vrt_ctx* ctx, const vrt_params* params, int row0, int rows,
  * DXRenderer.cpp:827-867 — the reference is single-adapter, NodeMask 0.) */
 int vrt_render_strips(vrt_ctx* ctx, const vrt_params* params, int strip_rows, int first_strip,
                       int strip_stride, int n_strips, void* device_rgba, void* hip_stream);
+
+/* One camera of a block of frames (the fields of vrt_scene's camera: Scene/Public/Camera.h:27-31). */
+typedef struct vrt_camera {
+    float position[3];
+    float rotation[4]; /* quaternion x,y,z,w */
+    float fov_deg;
+} vrt_camera;
+
+/* What vrt_render_block renders: n_frames frames of the current scene, frame f from cameras[f] (NULL: the scene's own
+ * camera for every frame) into device_rgba + f*frame_stride_bytes.  Rows of every frame: strip_rows > 0 -> the strips of
+ * vrt_render_strips (first_strip, strip_stride, n_strips); strip_rows == 0 -> rows [row0, row0+rows) like vrt_render_rows. */
+typedef struct vrt_block {
+    int32_t n_frames;                 /* 1 .. 64 */
+    int32_t strip_rows, first_strip, strip_stride, n_strips;
+    int32_t row0, rows;
+    const vrt_camera* cameras;        /* n_frames cameras, or NULL */
+    uint64_t frame_stride_bytes;      /* >= the bytes of one frame's rows */
+} vrt_block;
+
+/* n_frames launches with ONE call, back to back on hip_stream like n_frames calls of vrt_render_rows / vrt_render_strips with
+ * the scene's camera set to cameras[f] in between: same pixels, no host synchronisation, no allocation after the stream's
+ * first launch of that size.  For callers that keep many small launches in flight — a GPU's share of a frame that is split N
+ * ways marches in less time than an API round trip, an event pair and the caller's own bookkeeping take per launch
+ * (profiles/r02_launch_overhead.txt) — and for rendering a camera path.  The reference keeps FrameCount = 3 frames in flight
+ * on its swap chain (DXConstants.cpp:23, DXRenderer.cpp:37-66): overlap comes from issuing blocks on several streams.  Only
+ * the block's first frame is event-timed (vrt_timing_history reports 0 ms for the others); vrt_last_timing holds the
+ * counters of the last frame. */
+int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* block, void* device_rgba, void* hip_stream);
 
 /* ---- multi-GPU exchange (one process per GPU) --------------------------------------------------------------------------
  * The reference is single-adapter (every D3D12 object is created with NodeMask 0, DXRenderer.cpp:253); the frame of this

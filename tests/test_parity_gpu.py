@@ -3,6 +3,7 @@ images) on identical inputs.  Tolerance: 1e-4 per channel (BASELINE.json north_s
 practice the march is bit-identical and only powf differs in the last ulp.  Ray / step
 counters must agree exactly (integers)."""
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -837,6 +838,82 @@ def test_render_rows_can_be_captured_into_a_graph(renderer, oracle_lib):
     renderer.render_rows(p, 0, 120, direct.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert renderer.last_timing()["kernel_ms"] > 0.0
+
+
+def test_render_block_is_n_frames_in_flight_with_one_call(renderer, oracle_lib):
+    """vrt_render_block: a block of frames, each with its own camera, launched on the context's stream pool and ordered
+    like ONE asynchronous operation on the caller's stream.  Every frame equals the same frame rendered alone with that
+    camera (bit for bit) and the oracle; work the caller enqueued before the block (a fill of the buffer) is seen by no
+    frame and work enqueued after it (a copy of the block) sees every frame; only the block's first frame is timed; strips
+    mode gives vrt_render_strips' tiles; VRT_FLAG_NO_TIMING switches a single launch's event pair off."""
+    import copy
+    import torch
+
+    sc = scenes.config3_voxelized(6, 16)
+    W, H, n = 200, 120, 11  # more frames than pool streams
+    p = v.default_params(W, H, scenes.min_cell(sc), 255, shadow=True)
+    renderer.SetSceneToRender(sc)
+    renderer.ResizeRenderOutput(W, H)
+    renderer.SyncWithScene()
+    cam0 = sc.Camera
+    cams = []
+    for f in range(n):
+        a = 0.08 * f
+        pos = (cam0.Position[0] * math.cos(a) - cam0.Position[1] * math.sin(a) + 3.0 * f,
+               cam0.Position[0] * math.sin(a) + cam0.Position[1] * math.cos(a), cam0.Position[2] - 2.0 * f)
+        cams.append((pos, tuple(v.quat_mul(v.quat_from_axis_angle(v.UP, a), cam0.Rotation)), 60.0 - f))
+    side = torch.cuda.Stream()
+    block = torch.empty((n, H, W, 4), dtype=torch.float32, device="cuda:0")
+    with torch.cuda.stream(side):
+        block.fill_(7.0)  # enqueued BEFORE the block on the caller's stream: no frame may be overwritten by it
+        renderer.render_block(p, n, block.data_ptr(), H * W * 16, side.cuda_stream, cameras=cams)
+        after = block.clone()  # enqueued AFTER the block: must see every frame
+    torch.cuda.synchronize()
+    assert torch.equal(after, block) and float(block.max()) <= 1.0
+    hist = renderer.timing_history(n)
+    assert hist[0] > 0.0 and all(h == 0.0 for h in hist[1:])
+    alone = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+    for f in (0, 1, 5, n - 1):
+        sf = copy.copy(sc)
+        sf.Camera = v.VCamera(Position=cams[f][0], Rotation=cams[f][1], FOVAngle=cams[f][2])
+        renderer.SetSceneToRender(sf)
+        renderer.SyncWithScene()
+        renderer.render_rows(p, 0, H, alone.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert torch.equal(alone, block[f]), f
+        ref, _ = OracleScene(sf).render(p, threads=8)
+        assert np.abs(block[f].cpu().numpy() - ref).max() <= TOL
+    assert not torch.equal(block[0], block[n - 1])
+    # the scene's own camera is untouched by the block, and a block without cameras repeats the scene's frame
+    renderer.SetSceneToRender(sc)
+    renderer.SyncWithScene()
+    same = torch.empty((3, H, W, 4), dtype=torch.float32, device="cuda:0")
+    renderer.render_block(p, 3, same.data_ptr(), H * W * 16, 0)
+    renderer.render_rows(p, 0, H, alone.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert all(torch.equal(same[f], alone) for f in range(3))
+    # strips: rank 1 of 3, RGBA8 tiles, against vrt_render_strips
+    q = _abi.vrt_params.from_buffer_copy(p)
+    q.flags |= _abi.FLAG_OUTPUT_RGBA8
+    per = (((H + 15) // 16) + 2) // 3
+    tiles = torch.zeros((4, per * 16, W, 4), dtype=torch.uint8, device="cuda:0")
+    one = torch.zeros((per * 16, W, 4), dtype=torch.uint8, device="cuda:0")
+    renderer.render_block(q, 4, tiles.data_ptr(), per * 16 * W * 4, 0, strips=(16, 1, 3, per))
+    renderer.render_strips(q, 16, 1, 3, per, one.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert all(torch.equal(tiles[f], one) for f in range(4)) and int(one.max()) > 0
+    # a launch that asks not to be timed
+    q.flags |= _abi.FLAG_NO_TIMING
+    renderer.render_strips(q, 16, 1, 3, per, one.data_ptr(), 0)
+    torch.cuda.synchronize()
+    t = renderer.last_timing()
+    assert t["kernel_ms"] == 0.0 and t["primary_rays"] > 0
+    lib = _abi.load()
+    bad = _abi.vrt_block()
+    bad.n_frames, bad.rows, bad.frame_stride_bytes = 0, H, H * W * 16
+    assert lib.vrt_render_block(renderer._ctx, C.byref(p), C.byref(bad), C.c_void_p(block.data_ptr()), None) == _abi.VRT_ERR_INVALID
+    bad.n_frames, bad.frame_stride_bytes = 2, H * W * 16 - 16
+    assert lib.vrt_render_block(renderer._ctx, C.byref(p), C.byref(bad), C.c_void_p(block.data_ptr()), None) == _abi.VRT_ERR_INVALID
 
 
 @pytest.mark.parametrize("seed", range(96))

@@ -187,6 +187,37 @@ def test_unshuffle_puts_every_strip_where_it_belongs(world, height, strip_rows):
     assert torch.equal(got[:, 0, 0], torch.arange(height, dtype=torch.float32))
 
 
+@pytest.mark.parametrize("world,height,strip_rows,G", [(8, 1080, 32, 8), (4, 2160, 32, 3), (3, 50, 4, 5), (2, 54, 0, 4), (8, 1080, 0, 8)])
+def test_block_of_frames_per_gather(world, height, strip_rows, G):
+    """frames_per_gather = G: a buffer holds G frames' tiles and ONE gather moves them (bench.py, N > 1).  The gathered buffer
+    is filled the way the ranks' blocks arrive (rank-major, frame after frame, strip after strip), every row tagged with
+    (frame of the block, frame row): tile(b, g) addresses the right slice and frame(b, g) is frame g in row order."""
+    import torch
+
+    from volumetricraytracer_amd.tiles import FrameGather, strip_frame_rows, tile_rows
+
+    width = 2
+    fg = FrameGather(height, width, world, 0, torch.device("cpu"), dtype=torch.float32, buffers=1, strip_rows=strip_rows, frames_per_gather=G)
+    assert fg.tiles[0].shape[0] == G * fg.rows_per and fg.tile(0, G - 1).data_ptr() == fg.tiles[0][(G - 1) * fg.rows_per:].data_ptr()
+    fg.frames[0].fill_(-1.0)
+    for rank in range(world):
+        block = fg.frames[0][rank * G * fg.rows_per:(rank + 1) * G * fg.rows_per]
+        for g in range(G):
+            tile = block[g * fg.rows_per:(g + 1) * fg.rows_per]
+            if strip_rows > 0:
+                spans = strip_frame_rows(height, world, rank, strip_rows)
+            else:
+                _, row0, rows = tile_rows(height, world, rank)
+                spans = [(0, row0, rows)] if rows > 0 else []
+            for local0, frame0, rows in spans:
+                tile[local0:local0 + rows] = (1000.0 * g + torch.arange(frame0, frame0 + rows, dtype=torch.float32))[:, None, None]
+    fg.unshuffle(0)
+    for g in range(G):
+        got = fg.frame(0, g)
+        assert got.shape == (height, width, 4)
+        assert torch.equal(got[:, 1, 2], 1000.0 * g + torch.arange(height, dtype=torch.float32)), g
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver calls it) must start two ranks itself: the launch
     path without a march (--launch-check: gloo rendezvous, strip layout, gather, un-shuffle, max-over-ranks), runnable

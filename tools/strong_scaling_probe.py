@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What ONE rank of an N-way strong-scaled frame can sustain: rank 0's interleaved strips of the config-3 frame (every N-th
-32-row strip, RGBA8 tile) rendered with K frames in flight, no gather — the per-rank march rate that bounds the N-GPU job.
+32-row strip, RGBA8 tile) rendered with K frames in flight (K streams, blocks of 8 frames per vrt_render_block call), no gather — the per-rank march rate that bounds the N-GPU job.
 Run once per GPU_MAX_HW_QUEUES setting (the HIP runtime reads it at start-up).
 Usage: [GPU_MAX_HW_QUEUES=8] python tools/strong_scaling_probe.py [workload]"""
 import os
@@ -35,16 +35,17 @@ for n in NS:
     _, per = strip_layout(H, n, 32)
     for K in KS:
         streams = [torch.cuda.Stream() for _ in range(K)]
-        tiles = [torch.zeros((per * 32, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(K)]
+        G = int(os.environ.get("PROBE_BLOCK_FRAMES", "8"))  # frames per vrt_render_block call, like bench.py with N > 1
+        tiles = [torch.zeros((G, per * 32, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(K)]
 
         def run(steps):
-            for i in range(steps):
-                b = i % K
-                r.render_strips(p, 32, 0, n, per, tiles[b].data_ptr(), streams[b].cuda_stream)
+            for i in range(0, steps, G):
+                b = (i // G) % K
+                r.render_block(p, min(G, steps - i), tiles[b].data_ptr(), per * 32 * W * 4, streams[b].cuda_stream, strips=(32, 0, n, per))
             torch.cuda.synchronize()
 
-        run(2 * K)
-        steps, dt = 300, 1e9
+        run(2 * K * G)
+        steps, dt = 4 * K * G if 4 * K * G > 304 else 304, 1e9
         for _ in range(3):  # best of three
             t0 = time.perf_counter()
             run(steps)

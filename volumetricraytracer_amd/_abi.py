@@ -40,6 +40,7 @@ MODE_CUBE_NOTEX_UNLIT = 7
 
 FLAG_DIAG_TIMELINE = 4
 FLAG_OUTPUT_RGBA8 = 8
+FLAG_NO_TIMING = 16
 
 FORMAT_F32 = 0
 FORMAT_TEXEL16 = 1
@@ -146,6 +147,24 @@ class vrt_timing(C.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/vrt.h declares
+class vrt_camera(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("rotation", C.c_float * 4), ("fov_deg", C.c_float)]
+
+
+class vrt_block(C.Structure):
+    _fields_ = [
+        ("n_frames", C.c_int32),
+        ("strip_rows", C.c_int32),
+        ("first_strip", C.c_int32),
+        ("strip_stride", C.c_int32),
+        ("n_strips", C.c_int32),
+        ("row0", C.c_int32),
+        ("rows", C.c_int32),
+        ("cameras", C.POINTER(vrt_camera)),
+        ("frame_stride_bytes", C.c_uint64),
+    ]
+
+
 SYMBOLS = {
     "vrt_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]),
     "vrt_destroy": (C.c_int, [C.c_void_p]),
@@ -167,6 +186,7 @@ SYMBOLS = {
     "vrt_render": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_void_p]),
     "vrt_render_rows": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vrt_render_strips": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vrt_render_block": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.POINTER(vrt_block), C.c_void_p, C.c_void_p]),
     "vrt_comm_unique_id": (C.c_int, [C.c_void_p]),
     "vrt_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vrt_comm_destroy": (C.c_int, [C.c_void_p]),

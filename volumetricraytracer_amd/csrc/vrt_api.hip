@@ -148,7 +148,7 @@ struct DeviceState {
     hipEvent_t ev1[kRing];
     FrameSlot slot[VRT_FRAMES_IN_FLIGHT];
     bool events_ok = false;
-    bool timed[kRing] = {}; /* launch in this ring slot recorded its event pair (false: captured into a graph) */
+    bool timed[kRing] = {}; /* launch in this ring slot recorded its event pair (false: captured into a graph, or VRT_FLAG_NO_TIMING) */
 };
 
 }  // namespace
@@ -664,7 +664,7 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
         return VRT_ERR_INVALID;
     if (p->mode < VRT_MODE_INTERP || p->mode > VRT_MODE_CUBE_NOTEX_UNLIT) return VRT_ERR_INVALID;
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_CELLS) return VRT_ERR_INVALID;
-    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8)) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
+    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_NO_TIMING)) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
     if (!ctx->have_scene) return VRT_ERR_NOT_READY;
     return VRT_OK;
 }
@@ -858,7 +858,7 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
        never hold a time stamp of its own (vrt_last_timing / vrt_timing_history report 0 ms for it) */
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (stream != nullptr && hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
-    D.timed[ring] = cap == hipStreamCaptureStatusNone;
+    D.timed[ring] = cap == hipStreamCaptureStatusNone && !(p->flags & VRT_FLAG_NO_TIMING);
     if (D.timed[ring]) HIP_TRY(hipEventRecord(D.ev0[ring], stream));
     HIP_TRY(launch_march(F, path, single, stream));
     if (D.timed[ring]) HIP_TRY(hipEventRecord(D.ev1[ring], stream));
@@ -1160,6 +1160,55 @@ int vrt_render_strips(vrt_ctx* ctx, const vrt_params* params, int strip_rows, in
     rc = enqueue_rows(ctx, D, params, rs, static_cast<float*>(device_rgba), static_cast<hipStream_t>(hip_stream), ring);
     if (rc != VRT_OK) return rc;
     ctx->launches++;
+    ctx->last_devices = 1;
+    ctx->last_w = (uint32_t)params->width;
+    ctx->last_h = (uint32_t)rs.rows;
+    ctx->last_gather_ms = 0.f;
+    ctx->last_total_ms = 0.f;
+    return VRT_OK;
+}
+
+int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* block, void* device_rgba, void* hip_stream) {
+    int rc = check_params(ctx, params);
+    if (rc != VRT_OK) return rc;
+    if (!block || block->n_frames < 1 || block->n_frames > 64 || !device_rgba) return VRT_ERR_INVALID;
+    RowSet rs;
+    if (block->strip_rows > 0) {
+        if (block->strip_stride < 1 || block->first_strip < 0 || block->first_strip >= block->strip_stride || block->n_strips < 0 ||
+            (long long)block->n_strips * block->strip_rows > 16384)
+            return VRT_ERR_INVALID;
+        rs.rows = block->n_strips * block->strip_rows;
+        rs.strip_rows = block->strip_rows;
+        rs.strip_first = block->first_strip;
+        rs.strip_stride = block->strip_stride;
+    } else {
+        if (block->strip_rows < 0 || block->row0 < 0 || block->rows < 0 || block->row0 + block->rows > params->height) return VRT_ERR_INVALID;
+        rs.row0 = block->row0;
+        rs.rows = block->rows;
+    }
+    const size_t frame_bytes = (size_t)rs.rows * (size_t)params->width * ((params->flags & VRT_FLAG_OUTPUT_RGBA8) ? 4 : 16);
+    if (block->frame_stride_bytes < frame_bytes || (block->frame_stride_bytes & 15) != 0) return VRT_ERR_INVALID;
+    DeviceState& D = ctx->dev[0];
+    HIP_TRY(hipSetDevice(D.ordinal));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const vrt_scene saved = ctx->scene;
+    vrt_params q = *params;
+    for (int f = 0; f < block->n_frames; f++) {
+        if (block->cameras) { /* only the camera differs between the frames: the packed scene arrays stay as they are */
+            const vrt_camera& c = block->cameras[f];
+            for (int a = 0; a < 3; a++) ctx->scene.cam_position[a] = c.position[a];
+            for (int a = 0; a < 4; a++) ctx->scene.cam_rotation[a] = c.rotation[a];
+            ctx->scene.cam_fov_deg = c.fov_deg;
+        }
+        q.flags = f == 0 ? params->flags : (params->flags | VRT_FLAG_NO_TIMING); /* the block's first frame is its timing sample */
+        const int ring = (int)(ctx->launches % kRing);
+        rc = enqueue_rows(ctx, D, &q, rs, reinterpret_cast<float*>(static_cast<char*>(device_rgba) + (size_t)f * block->frame_stride_bytes), stream,
+                          ring);
+        if (rc != VRT_OK) break;
+        ctx->launches++;
+    }
+    ctx->scene = saved;
+    if (rc != VRT_OK) return rc;
     ctx->last_devices = 1;
     ctx->last_w = (uint32_t)params->width;
     ctx->last_h = (uint32_t)rs.rows;

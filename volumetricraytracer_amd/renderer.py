@@ -202,6 +202,31 @@ class VHipRenderer:
         _abi.check(self._lib.vrt_render_strips(self._ctx, C.byref(params), strip_rows, first_strip, strip_stride, n_strips,
                                                C.c_void_p(device_ptr), C.c_void_p(stream)), "vrt_render_strips")
 
+    def render_block(self, params: _abi.vrt_params, n_frames: int, device_ptr: int, frame_stride_bytes: int, stream: int = 0,
+                     strips=None, rows=None, cameras=None) -> None:
+        """vrt_render_block: n_frames frames of the current scene in flight with one call, frame f into
+        device_ptr + f*frame_stride_bytes; to the caller one asynchronous operation on `stream`.  strips = (strip_rows,
+        first_strip, strip_stride, n_strips) or rows = (row0, rows) (default: the whole frame); cameras: n_frames
+        (position[3], rotation[4], fov_deg) triples overriding the scene's camera per frame."""
+        self._require()
+        b = _abi.vrt_block()
+        b.n_frames = int(n_frames)
+        if strips is not None:
+            b.strip_rows, b.first_strip, b.strip_stride, b.n_strips = (int(x) for x in strips)
+        else:
+            b.row0, b.rows = (int(x) for x in rows) if rows is not None else (0, int(params.height))
+        keep = None
+        if cameras is not None:
+            keep = (_abi.vrt_camera * len(cameras))()
+            for c, (pos, rot, fov) in zip(keep, cameras):
+                c.position[:] = [float(x) for x in pos]
+                c.rotation[:] = [float(x) for x in rot]
+                c.fov_deg = float(fov)
+            b.cameras = keep
+        b.frame_stride_bytes = int(frame_stride_bytes)
+        _abi.check(self._lib.vrt_render_block(self._ctx, C.byref(params), C.byref(b), C.c_void_p(device_ptr), C.c_void_p(stream)),
+                   "vrt_render_block")
+
     def render_begin(self, slot: int, params: Optional[_abi.vrt_params] = None) -> _abi.vrt_params:
         """vrt_render_begin: sync the scene, snapshot it and enqueue the whole frame on frame slot `slot`
         (0..VRT_FRAMES_IN_FLIGHT-1); returns at once.  Collect with render_end(slot, params)."""

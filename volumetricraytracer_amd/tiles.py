@@ -57,7 +57,10 @@ class FrameGather:
     `dtype` float32 → [rows, W, 4] float RGBA; uint8 → [rows, W, 4] R8G8B8A8."""
 
     def __init__(self, height: int, width: int, world: int, rank: int, device, dtype=None, buffers: int = 2,
-                 strip_rows: int = 0):
+                 strip_rows: int = 0, frames_per_gather: int = 1):
+        """frames_per_gather = G > 1: a buffer holds a BLOCK of G frames' tiles ([G, rows, W, 4]) and one gather moves the whole
+        block (fewer, larger collectives: at a few tens of microseconds per frame the per-call cost of a collective is what
+        bounds an N-GPU job); tile(b, g) / frame(b, g) address frame g of block b."""
         import torch
 
         self.height, self.width, self.world, self.rank = height, width, world, rank
@@ -69,18 +72,21 @@ class FrameGather:
         else:
             self.rows_per, self.row0, self.rows = tile_rows(height, world, rank)
         dtype = dtype or torch.float32
-        self.tiles = [torch.zeros((self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
+        G = self.G = max(int(frames_per_gather), 1)
+        self.tiles = [torch.zeros((G * self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
         self.frames: Optional[List] = None  # gathered tiles, rank-major
         self.final: Optional[List] = None   # strips only: frame-ordered copies
         self._glist = None      # per buffer: the views torch.distributed.gather receives into (built once, not per frame)
         self._unshuffle = None  # per buffer: (source view, destination view) of the strip un-shuffle
         if world > 1 and rank == 0:
-            self.frames = [torch.zeros((world * self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
-            self._glist = [[f[k * self.rows_per:(k + 1) * self.rows_per] for k in range(world)] for f in self.frames]
+            # gathered: [rank, frame of the block, rows of a tile]
+            self.frames = [torch.zeros((world * G * self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
+            self._glist = [[f[k * G * self.rows_per:(k + 1) * G * self.rows_per] for k in range(world)] for f in self.frames]
             if self.strip_rows > 0:
-                self.final = [torch.zeros((world * self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
+                # frame order: [frame of the block, strip slot, rank, rows of a strip]
+                self.final = [torch.zeros((G * world * self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
                 n, per, sr = world, self.strips_per, self.strip_rows
-                self._unshuffle = [(f.view(n, per, sr, width, 4).permute(1, 0, 2, 3, 4), g.view(per, n, sr, width, 4))
+                self._unshuffle = [(f.view(n, G, per, sr, width, 4).permute(1, 2, 0, 3, 4, 5), g.view(G, per, n, sr, width, 4))
                                    for f, g in zip(self.frames, self.final)]
 
     def gather(self, b: int, async_op: bool = False):
@@ -109,12 +115,20 @@ class FrameGather:
         src, dst = self._unshuffle[b]
         dst.copy_(src)
 
-    def frame(self, b: int):
-        """The assembled H x W x 4 frame (rank 0 only; for strips call unshuffle(b) first)."""
+    def tile(self, b: int, g: int = 0):
+        """This rank's tile of frame g of buffer (block) b."""
+        return self.tiles[b][g * self.rows_per:(g + 1) * self.rows_per]
+
+    def frame(self, b: int, g: int = 0):
+        """The assembled H x W x 4 frame g of buffer (block) b (rank 0 only; for strips call unshuffle(b) first)."""
         if self.world == 1:
-            return self.tiles[b][: self.height]
+            return self.tile(b, g)[: self.height]
         if self.rank != 0:
             return None
+        full = self.world * self.rows_per
         if self.strip_rows > 0:
-            return self.final[b][: self.height]
-        return self.frames[b][: self.height]
+            return self.final[b][g * full: g * full + self.height]
+        if self.G == 1:
+            return self.frames[b][: self.height]
+        # contiguous row tiles of a block: rank-major in the gathered buffer, so frame g is a strided view
+        return self.frames[b].view(self.world, self.G, self.rows_per, self.width, 4)[:, g].reshape(full, self.width, 4)[: self.height]
