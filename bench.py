@@ -4,12 +4,13 @@
 
 A "step" is one full frame of the workload (default: BASELINE config 3 — 1920x1080, 256^3 voxelized mesh,
 shadow ray on).  With N ranks (one process per GPU) the SAME frame is split N ways — strong scaling, as the
-metric and config 4 define it: the frame is cut into 32-row strips dealt round-robin to the ranks
+metric and config 4 define it: the frame is cut into 8-row strips dealt round-robin to the ranks
 (contiguous tiles would put every object row on the middle GPUs); every rank marches its strips into a
-compact device tile with ONE launch and the tiles are gathered onto rank 0 with one RCCL gather
-(torch.distributed backend "nccl") that overlaps with the following frames' march; rank 0 un-shuffles the
-gathered strips into frame order.  The exchange format is R8G8B8A8_UNORM, the reference's own back-buffer
-precision (DXConstants.cpp:21).  `--scaling weak` (frame grows with N, fixed rays per GPU) is kept as an
+compact device tile with ONE launch per frame.  Frames are issued in blocks (vrt_render_block: several
+launches per call, one event pair per block) on K streams, and the tiles are gathered onto rank 0 with ONE
+RCCL gather per BLOCK of frames (torch.distributed backend "nccl") that overlaps with the other streams'
+march; rank 0 un-shuffles the gathered strips into frame order.  The exchange format is R8G8B8A8_UNORM, the
+reference's own back-buffer precision (DXConstants.cpp:21).  `--scaling weak` (frame grows with N, fixed rays per GPU) is kept as an
 option; it is never the default.
 
 Launching: `python bench.py --gpus N` starts the N ranks itself (a child `python -m torch.distributed.run`,
@@ -58,7 +59,8 @@ def parse_args(argv=None):
                     help="N>1: strong = the workload's own frame split N ways (the metric); weak = frame grows with N")
     ap.add_argument("--output", default="auto", choices=["auto", "f32", "rgba8"],
                     help="tile pixel format; auto = float4 on one GPU, RGBA8 (the exchange format) on several")
-    ap.add_argument("--strip-rows", type=int, default=32, help="N>1: rows per interleaved strip; 0 = contiguous row tiles")
+    ap.add_argument("--strip-rows", type=int, default=8,
+                    help="N>1: rows per interleaved strip (8: one wave row; 1080 rows deal out with 0.7 % padding at N = 8, 15 % with 32); 0 = contiguous row tiles")
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 8],
                     help="frames launched before the first one must have finished, each on its own HIP stream and tile "
                          "buffer; 0 = 3 on one GPU, what the reference keeps in flight (FrameCount, DXConstants.cpp:23), 8 on several")
@@ -486,7 +488,7 @@ def main() -> None:
             e4 = timed_run(pipe4, s4, 3, world, cdev)
             c4 = job_counts(r.last_timing())
             config4 = {"workload": f"config4: 256^3 voxelized mesh, 3840x2160 split over {world} GPU(s)" +
-                                   (", 32-row interleaved strips + RCCL gather to rank 0" if world > 1 else ""),
+                                   (f", {strip_rows}-row interleaved strips + RCCL gather to rank 0" if world > 1 else ""),
                        "ms_per_frame": round(e4 / s4 * 1e3, 4), "value": round((c4[0] + c4[1]) * s4 / e4 / 1e6, 2), "unit": "Mrays/s",
                        "steps": s4, "frames_in_flight": K}
             del pipe4

@@ -26,22 +26,23 @@ assert r.Start()
 r.SetSceneToRender(sc)
 r.ResizeRenderOutput(W, H)
 r.SyncWithScene()
-print(f"{label}; GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}")
+print(f"{label}; GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}; strips of {os.environ.get('PROBE_STRIP_ROWS', '32')} rows")
 print("ranks  K  ms/frame(rank 0 alone)  frames/s  -> whole-job Grays/s if every rank keeps that rate")
 full = None
+SR = int(os.environ.get("PROBE_STRIP_ROWS", "32"))  # rows per interleaved strip
 NS = [int(x) for x in os.environ.get("PROBE_RANKS", "1,2,4,8").split(",")]
 KS = [int(x) for x in os.environ.get("PROBE_FRAMES_IN_FLIGHT", "1,2,3,4,6,8").split(",")]
 for n in NS:
-    _, per = strip_layout(H, n, 32)
+    _, per = strip_layout(H, n, SR)
     for K in KS:
         streams = [torch.cuda.Stream() for _ in range(K)]
         G = int(os.environ.get("PROBE_BLOCK_FRAMES", "8"))  # frames per vrt_render_block call, like bench.py with N > 1
-        tiles = [torch.zeros((G, per * 32, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(K)]
+        tiles = [torch.zeros((G, per * SR, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(K)]
 
         def run(steps):
             for i in range(0, steps, G):
                 b = (i // G) % K
-                r.render_block(p, min(G, steps - i), tiles[b].data_ptr(), per * 32 * W * 4, streams[b].cuda_stream, strips=(32, 0, n, per))
+                r.render_block(p, min(G, steps - i), tiles[b].data_ptr(), per * SR * W * 4, streams[b].cuda_stream, strips=(SR, 0, n, per))
             torch.cuda.synchronize()
 
         run(2 * K * G)
