@@ -199,11 +199,13 @@ class Pipeline:
     def run(self, steps: int) -> None:
         """Issue exactly `steps` frames: blocks of G on stream 0, 1, ... K-1, 0, ...; the last round is dealt evenly."""
         torch, fg, r = self.torch, self.fg, self.r
-        issued = 0
-        while issued < steps:
-            left = steps - issued
-            # the last K blocks share what is left evenly, so that no stream ends with a long queue while the others idle
-            n = min(self.G, max(1, -(-left // self.K)) if left < self.G * self.K else self.G)
+        # whole rounds of K blocks of G frames; the last (partial) round is dealt evenly over the K streams, so that no stream
+        # ends with a long queue while the others idle
+        rounds, rest = divmod(steps, self.G * self.K)
+        plan = [self.G] * (rounds * self.K) + [rest // self.K + (1 if k < rest % self.K else 0) for k in range(self.K)]
+        for n in plan:
+            if n == 0:
+                continue
             b = self.blocks % self.K
             st = self.streams[b]
             with torch.cuda.stream(st):
@@ -234,7 +236,6 @@ class Pipeline:
                     self.unshuffled[b].record(self.copy_stream)
             self.last = (b, n - 1)
             self.blocks += 1
-            issued += n
 
     def last_frame(self):
         """Rank 0: the assembled last frame issued."""
