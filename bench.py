@@ -2,8 +2,11 @@
 """Benchmark of the ray-march hot path (BASELINE.json metric: Mrays/s + ms/frame at 1080p over a
 256^3 SDF volume, 1/2/4/8 MI355X).
 
-A "step" is one full frame of the workload (default: BASELINE config 3 — 1920x1080, 256^3 voxelized mesh,
-shadow ray on).  With N ranks (one process per GPU) the SAME frame is split N ways — strong scaling, as the
+A "step" is one pass of the hot path over one batch of input: a batch of 32 full frames of the workload (default: BASELINE
+config 3 — 1920x1080, 256^3 voxelized mesh, shadow ray on), consecutive views of a camera on a short orbit through the
+workload's own view (0.25 degrees apart) — frames of a moving camera, not copies of one frame; `ms_per_frame` =
+`ms_per_step` / 32 is in the line too.  (A single 1080p frame marches in 0.04 ms: K steps of ONE frame each would time the
+pipeline's fill and drain and the GPU's clock ramp, not the march — profiles/r02_launch_overhead.txt.)  With N ranks (one process per GPU) the SAME frame is split N ways — strong scaling, as the
 metric and config 4 define it: the frame is cut into 8-row strips dealt round-robin to the ranks
 (contiguous tiles would put every object row on the middle GPUs); every rank marches its strips into a
 compact device tile with ONE launch per frame.  Frames are issued in blocks (vrt_render_block: several
@@ -64,6 +67,8 @@ def parse_args(argv=None):
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 8],
                     help="frames launched before the first one must have finished, each on its own HIP stream and tile "
                          "buffer; 0 = 3 on one GPU, what the reference keeps in flight (FrameCount, DXConstants.cpp:23), 8 on several")
+    ap.add_argument("--frames-per-step", type=int, default=32,
+                    help="frames in the batch ONE step renders: consecutive views of a camera on a short orbit (0.25 degrees apart)")
     ap.add_argument("--block-frames", type=int, default=0,
                     help="frames issued per vrt_render_block call on one stream (one event pair per block); 0 = default")
     ap.add_argument("--k-relax", type=float, default=0.0,
@@ -136,7 +141,8 @@ def kernel_source_hash() -> str:
 
 def traffic_key(args, world: int, K: int, rgba8: bool) -> dict:
     return {"workload": args.workload, "n_gpus": world, "path": args.path, "format": args.format, "tile_map": args.tile_map,
-            "frames_in_flight": K, "rgba8": bool(rgba8), "k_relax": args.k_relax, "kernel_source_sha": kernel_source_hash()}
+            "frames_in_flight": K, "rgba8": bool(rgba8), "k_relax": args.k_relax, "frames_per_step": args.frames_per_step,
+            "kernel_source_sha": kernel_source_hash()}
 
 
 def measured_traffic(key: dict):
@@ -173,7 +179,8 @@ class Pipeline:
     order with one strided copy on a stream of its own.  No cross-stream dependency on the march path: on this runtime
     an event wait between streams costs several microseconds of queue time (profiles/r02_launch_overhead.txt)."""
 
-    def __init__(self, r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=False, block_frames=8):
+    def __init__(self, r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=False, block_frames=8, cameras=None,
+                 n_cameras=0):
         import torch
 
         from volumetricraytracer_amd.tiles import FrameGather
@@ -195,9 +202,11 @@ class Pipeline:
         self.unshuffled = [None] * K
         self.blocks = 0
         self.last = (0, 0)  # (buffer, frame within the block) of the last frame issued
+        # the batch's cameras, twice over (a block may wrap around the end of the batch): frame i uses camera i % n_cameras
+        self.cameras, self.n_cameras, self.frame_no = cameras, n_cameras, 0
 
     def run(self, steps: int) -> None:
-        """Issue exactly `steps` frames: blocks of G on stream 0, 1, ... K-1, 0, ...; the last round is dealt evenly."""
+        """Issue exactly `steps` FRAMES: blocks of G on stream 0, 1, ... K-1, 0, ...; the last round is dealt evenly."""
         torch, fg, r = self.torch, self.fg, self.r
         # whole rounds of K blocks of G frames; the last (partial) round is dealt evenly over the K streams, so that no stream
         # ends with a long queue while the others idle
@@ -214,11 +223,14 @@ class Pipeline:
                     self.pending[b] = None
                 if self.unshuffled[b] is not None:
                     st.wait_event(self.unshuffled[b])
+                cams = (self.cameras, self.frame_no % self.n_cameras) if self.cameras is not None else None
                 if self.strip_rows > 0:
                     r.render_block(self.p, n, self.march_tiles[b].data_ptr(), self.frame_bytes, st.cuda_stream,
-                                   strips=(self.strip_rows, self.rank, self.world, fg.strips_per))
+                                   strips=(self.strip_rows, self.rank, self.world, fg.strips_per), cameras=cams)
                 else:
-                    r.render_block(self.p, n, self.march_tiles[b].data_ptr(), self.frame_bytes, st.cuda_stream, rows=(fg.row0, fg.rows))
+                    r.render_block(self.p, n, self.march_tiles[b].data_ptr(), self.frame_bytes, st.cuda_stream, rows=(fg.row0, fg.rows),
+                                   cameras=cams)
+                self.frame_no += n
                 if self.rehearsal:
                     fg.tiles[b].copy_(self.march_tiles[b])
                 if self.world > 1:
@@ -251,8 +263,9 @@ class Pipeline:
         torch.cuda.synchronize()
 
 
-def timed_run(pipe: Pipeline, steps: int, warmup: int, world: int, cdev) -> float:
-    """W untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; MAX over ranks (seconds)."""
+def timed_run(pipe: Pipeline, steps: int, warmup: int, world: int, cdev, frames_per_step: int = 1) -> float:
+    """W untimed steps, then exactly `steps` steps (of frames_per_step frames each) bracketed by barrier + synchronize; MAX over
+    ranks (seconds).  Every timed run starts at the first camera of the batch."""
     import torch
     import torch.distributed as dist
 
@@ -262,11 +275,11 @@ def timed_run(pipe: Pipeline, steps: int, warmup: int, world: int, cdev) -> floa
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipe.run(warmup)
+    pipe.run(warmup * frames_per_step)
     pipe.drain()
     barrier()
     t0 = time.perf_counter()
-    pipe.run(steps)
+    pipe.run(steps * frames_per_step)
     pipe.drain()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -421,77 +434,107 @@ def main() -> None:
     if args.gather == "native" and world > 1 and not native_ready and not rehearsal:
         raise SystemExit(f"[bench] --gather native: vrt_comm_init failed on some rank ({native_error})")
 
+    # One STEP = one batch of B frames: consecutive views of a camera on a short orbit through the workload's own view
+    # (frames of a moving camera, not B copies of one frame, so a frame does not find its predecessor's lines in L2).
+    B = max(args.frames_per_step, 1)
     # frames per vrt_render_block call: one GPU 2 (measured best at K = 3); several GPUs 8, gathered as ONE block per collective
-    G = args.block_frames or (2 if world == 1 else 8)
-    pipe = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=use_native, block_frames=G)
-    elapsed = timed_run(pipe, args.steps, args.warmup, world, cdev)
+    G = min(args.block_frames or (2 if world == 1 else 8), B)
+    cams = workloads.orbit_cameras(sc, B)
+    cam_arr = r.camera_array(cams + cams)
+    KEYS = ("primary_rays", "shadow_rays", "bounce_rays", "primary_steps", "shadow_steps", "hits", "exhausted_rays")
 
-    t = r.last_timing()  # this rank's tile, last frame (every frame is identical)
-    kms = [x for x in r.timing_history(min(args.steps, 200)) if x > 0.0]  # the event-timed launches: the first frame of every block
-    verified = None
-    if os.environ.get("VRT_BENCH_VERIFY") and rank == 0 and args.steps > 0:
-        # the gathered (and un-shuffled) frame must be the frame one GPU renders alone, bit for bit
-        whole = torch.empty((H, W, 4), dtype=torch.uint8 if rgba8 else torch.float32, device=dev)
-        r.render_rows(p, 0, H, whole.data_ptr(), pipe.streams[0].cuda_stream)
-        torch.cuda.synchronize()
-        got = pipe.last_frame()
-        verified = bool(torch.equal(got.cpu(), whole.cpu()))
-        if not verified:
-            raise SystemExit("[bench] gathered frame differs from the single-GPU frame")
-        t = dict(t)  # keep the tile's counters (the verification launch overwrote last_timing)
-
-    def job_counts(tt):
-        c = torch.tensor([tt["primary_rays"], tt["shadow_rays"], tt["primary_steps"], tt["shadow_steps"], tt["hits"]],
-                         dtype=torch.float64, device=cdev)
+    def batch_counts(pp, w, h):
+        """The counters of one batch (every camera once, this rank's rows, untimed), summed over the ranks."""
+        from volumetricraytracer_amd.tiles import strip_layout, tile_rows
+        tot = {k: 0.0 for k in KEYS}
+        if strip_rows > 0:
+            per = strip_layout(h, world, strip_rows)[1]
+            rows_here, kw = per * strip_rows, {"strips": (strip_rows, rank, world, per)}
+        else:
+            _, row0, rows_here = tile_rows(h, world, rank)
+            kw = {"rows": (row0, rows_here)}
+        scratch = torch.empty((max(rows_here, 1), w, 4), dtype=torch.uint8 if rgba8 else torch.float32, device=dev)
+        for f in range(B):
+            r.render_block(pp, 1, scratch.data_ptr(), scratch.numel() * scratch.element_size(), 0, cameras=(cam_arr, f), **kw)
+            torch.cuda.synchronize()
+            tt = r.last_timing()
+            for k in KEYS:
+                tot[k] += tt[k]
+        c = torch.tensor([tot[k] for k in KEYS], dtype=torch.float64, device=cdev)
         if world > 1:
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        return [float(x) for x in c.tolist()]
+        return dict(zip(KEYS, (float(x) for x in c.tolist())))
 
-    primary, shadow_rays, psteps, ssteps, hits = job_counts(t)
-    rays_per_frame = primary + shadow_rays
+    def pipeline(pp, w, h, k, native):
+        return Pipeline(r, pp, w, h, world, rank, dev, rgba8, strip_rows, k, rehearsal, native=native, block_frames=G, cameras=cam_arr,
+                        n_cameras=B)
+
+    pipe = pipeline(p, W, H, K, use_native)
+    elapsed = timed_run(pipe, args.steps, args.warmup, world, cdev, B)
+    kms = [x for x in r.timing_history(min(args.steps * B, 200)) if x > 0.0]  # the event-timed launches: the first frame of every block
+
+    def single_gpu_frame(pp, w, h, cam_index):
+        whole = torch.empty((h, w, 4), dtype=torch.uint8 if rgba8 else torch.float32, device=dev)
+        r.render_block(pp, 1, whole.data_ptr(), whole.numel() * whole.element_size(), 0, cameras=(cam_arr, cam_index), rows=(0, h))
+        torch.cuda.synchronize()
+        return whole
+
+    verified = None
+    if os.environ.get("VRT_BENCH_VERIFY") and rank == 0 and args.steps > 0:
+        # the gathered (and un-shuffled) last frame must be the frame one GPU renders alone from that camera, bit for bit
+        verified = bool(torch.equal(pipe.last_frame().cpu(), single_gpu_frame(p, W, H, (pipe.frame_no - 1) % B).cpu()))
+        if not verified:
+            raise SystemExit("[bench] gathered frame differs from the single-GPU frame")
+
+    cnt = batch_counts(p, W, H)  # whole job, one batch
+    rays_per_step = cnt["primary_rays"] + cnt["shadow_rays"]
+    rays_per_frame = rays_per_step / B
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
-    value = rays_per_frame * args.steps / elapsed / 1e6 if args.steps > 0 else 0.0
+    value = rays_per_step * args.steps / elapsed / 1e6 if args.steps > 0 else 0.0
+    # mean frame of the batch as this rank's launch sees it (algorithmic bytes of ONE launch)
+    t = {k: cnt[k] / B / world for k in KEYS}
 
     # ---- extra legs (outside the timed region) ------------------------------------------------------------------
     native_check = None
     if world > 1 and native_ready and not args.no_extra_legs and args.steps > 0:
         # the other gather implementation, a few frames: same pixels on rank 0, and its frame time
         try:
-            other = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=not use_native, block_frames=G)
-            osteps = max(min(args.steps, 30), 3)
-            eo = timed_run(other, osteps, 2, world, cdev)
+            other = pipeline(p, W, H, K, not use_native)
+            osteps = max(min(args.steps, 3), 1)
+            eo = timed_run(other, osteps, 1, world, cdev, B)
             same = True
             if rank == 0:
-                same = bool(torch.equal(other.last_frame(), pipe.last_frame()))
+                same = bool(torch.equal(other.last_frame(), single_gpu_frame(p, W, H, (other.frame_no - 1) % B)))
             native_check = {"gather": "torch" if use_native else "native (vrt_gather_tiles: ncclGather on the march stream)",
-                            "ms_per_frame": round(eo / osteps * 1e3, 4), "same_frame_as_timed_run": same}
+                            "ms_per_frame": round(eo / (osteps * B) * 1e3, 4), "last_frame_equals_single_gpu_frame": same}
             del other
         except Exception as e:
             native_check = {"error": repr(e)}
     latency = end_to_end = config4 = None
     if not args.no_extra_legs and args.steps > 0:
-        lsteps = max(min(args.steps, 50), 5)
+        lsteps = max(min(args.steps, 4), 1)  # batches
         # one frame in flight: what an application that waits for every frame sees
-        p1 = Pipeline(r, p, W, H, world, rank, dev, rgba8, strip_rows, 1, rehearsal, native=use_native, block_frames=G)
-        e1 = timed_run(p1, lsteps, 3, world, cdev)
-        k1 = [x for x in r.timing_history(lsteps) if x > 0.0]
-        latency = {"frames_in_flight": 1, "ms_per_frame": round(e1 / lsteps * 1e3, 4), "value": round(rays_per_frame * lsteps / e1 / 1e6, 2),
+        p1 = pipeline(p, W, H, 1, use_native)
+        e1 = timed_run(p1, lsteps, 1, world, cdev, B)
+        k1 = [x for x in r.timing_history(min(lsteps * B, 200)) if x > 0.0]
+        latency = {"frames_in_flight": 1, "ms_per_frame": round(e1 / (lsteps * B) * 1e3, 4), "value": round(rays_per_step * lsteps / e1 / 1e6, 2),
                    "unit": "Mrays/s", "kernel_ms": round(float(np.mean(k1)), 4) if k1 else None}
         del p1
         if world == 1:
-            end_to_end = end_to_end_leg(r, p, rays_per_frame, lsteps)
+            end_to_end = end_to_end_leg(r, p, rays_per_frame, 50)
         if args.workload in ("c3", "c4") and args.scaling == "strong":
             W4, H4 = 3840, 2160
             p4 = params(W4, H4)
             r.ResizeRenderOutput(W4, H4)
-            pipe4 = Pipeline(r, p4, W4, H4, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=use_native, block_frames=G)
-            s4 = max(lsteps // 2, 5)
-            e4 = timed_run(pipe4, s4, 3, world, cdev)
-            c4 = job_counts(r.last_timing())
+            pipe4 = pipeline(p4, W4, H4, K, use_native)
+            s4 = max(min(args.steps, 4), 1)
+            e4 = timed_run(pipe4, s4, 1, world, cdev, B)
+            c4 = batch_counts(p4, W4, H4)
             config4 = {"workload": f"config4: 256^3 voxelized mesh, 3840x2160 split over {world} GPU(s)" +
                                    (f", {strip_rows}-row interleaved strips + RCCL gather to rank 0" if world > 1 else ""),
-                       "ms_per_frame": round(e4 / s4 * 1e3, 4), "value": round((c4[0] + c4[1]) * s4 / e4 / 1e6, 2), "unit": "Mrays/s",
-                       "steps": s4, "frames_in_flight": K}
+                       "ms_per_frame": round(e4 / (s4 * B) * 1e3, 4),
+                       "value": round((c4["primary_rays"] + c4["shadow_rays"]) * s4 / e4 / 1e6, 2), "unit": "Mrays/s",
+                       "steps": s4, "frames_per_step": B, "frames_in_flight": K}
             del pipe4
             r.ResizeRenderOutput(W, H)
 
@@ -503,12 +546,13 @@ def main() -> None:
         r.SyncWithScene()
         pt = params(W, H)
         pt.path = _abi.PATH_CELLS
-        pipet = Pipeline(r, pt, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, block_frames=G)
-        et = timed_run(pipet, args.steps, args.warmup, world, cdev)
-        ct = job_counts(r.last_timing())
+        pipet = pipeline(pt, W, H, K, False)
+        st_ = max(min(args.steps, 20), 1)
+        et = timed_run(pipet, st_, min(args.warmup, 5), world, cdev, B)
+        ct = batch_counts(pt, W, H)
         texel_leg = {"volume_format": "reference texel (sign + 15-bit |d|*100) as 16-byte cell records, --format texel16 --path cells",
-                     "ms_per_frame": round(et / args.steps * 1e3, 4), "value": round((ct[0] + ct[1]) * args.steps / et / 1e6, 2),
-                     "unit": "Mrays/s", "frames_in_flight": K}
+                     "ms_per_frame": round(et / (st_ * B) * 1e3, 4),
+                     "value": round((ct["primary_rays"] + ct["shadow_rays"]) * st_ / et / 1e6, 2), "unit": "Mrays/s", "frames_in_flight": K}
         del pipet
         for vol in sc.volumes():
             vol.set_device_format(fmt)
@@ -518,6 +562,7 @@ def main() -> None:
         k_ms = float(np.mean(kms)) if kms else float("nan")
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if kms else 0.0
         samples = int(t["primary_steps"] + t["shadow_steps"])
+        psteps, ssteps = cnt["primary_steps"], cnt["shadow_steps"]
         traffic = measured_traffic(traffic_key(args, world, K, rgba8))
         roofline = {
             # contract fields: ALGORITHMIC bytes (32 B per trilinear sample + 192 B per hit + the pixel store)
@@ -529,7 +574,7 @@ def main() -> None:
             # physical picture: what really crosses the HBM interface, and what the kernel really waits for
             "hbm_measured_GBps": round(traffic / (k_ms * 1e-3) / 1e9, 2) if traffic and kms else None,
             "hbm_measured_frac": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and kms else None,
-            "hbm_measured_frac_of_ms_per_step": round(traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and world == 1 else None,
+            "hbm_measured_frac_of_ms_per_frame": round(traffic / (ms_per_step / B * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and world == 1 else None,
             "limiter": "latency of dependent sample chains (tail) / texture-addresser gather rate (busy phase); not HBM bandwidth",
             "gsamples_per_s": round(samples / (k_ms * 1e-3) / 1e9, 2) if kms else None,
             "gather_ceiling_gsamples_per_s": GATHER_CEILING_GSAMPLES,
@@ -540,18 +585,20 @@ def main() -> None:
         out = {
             "metric": "Mrays/sec at 1080p, 256^3 SDF volume" if args.workload in ("c3", "c3sdf") else "Mrays/sec",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step / B, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": W, "height": H, "volume": f"{sc.volumes()[0].N - 1}^3 cells",
                        "volume_format": {_abi.FORMAT_F32: "f32 bricks (512 B per 4^3 cells)",
                                          _abi.FORMAT_TEXEL16: "reference texel: sign + 15-bit |d|*100, 16-bit bricks (256 B per 4^3 cells)"}[fmt],
                        "max_steps": max_steps, "shadow": bool(shadow), "k_relax": round(float(p.k_relax), 3), "data_path": args.path,
                        "output": "rgba8 (R8G8B8A8_UNORM tiles; march and shading in f32)" if rgba8 else "f32 (float4)",
-                       "frames_in_flight": K, "frames_per_call": G,
+                       "step": f"one batch of {B} frames: consecutive views of a camera orbiting the workload's view, 0.25 degrees apart",
+                       "frames_per_step": B, "frames_in_flight": K, "frames_per_call": G,
                        "parallelism": ("1 GPU" if world == 1 else
                                        (f"{strip_rows}-row interleaved strips" if strip_rows else "contiguous row tiles") +
                                        f" x{world} + " + ("gloo gather, REHEARSAL on one GPU" if rehearsal else f"one RCCL gather to rank 0 per block of {G} frames")),
-                       "rays_per_frame": int(rays_per_frame), "samples_per_ray": round((psteps + ssteps) / max(rays_per_frame, 1), 2)},
+                       "rays_per_step": int(rays_per_step), "rays_per_frame": int(rays_per_frame),
+                       "samples_per_ray": round((psteps + ssteps) / max(rays_per_step, 1), 2)},
             "roofline": roofline, "cpu_baseline": cpu,
             "latency": latency, "end_to_end": end_to_end, "config4": config4, "reference_texel_format": texel_leg,
         }

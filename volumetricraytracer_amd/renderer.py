@@ -215,17 +215,26 @@ class VHipRenderer:
             b.strip_rows, b.first_strip, b.strip_stride, b.n_strips = (int(x) for x in strips)
         else:
             b.row0, b.rows = (int(x) for x in rows) if rows is not None else (0, int(params.height))
-        keep = None
         if cameras is not None:
-            keep = (_abi.vrt_camera * len(cameras))()
-            for c, (pos, rot, fov) in zip(keep, cameras):
-                c.position[:] = [float(x) for x in pos]
-                c.rotation[:] = [float(x) for x in rot]
-                c.fov_deg = float(fov)
-            b.cameras = keep
+            # a list of (position, rotation, fov) triples, or (a ctypes array from camera_array(), index of the first camera)
+            arr, start = cameras if isinstance(cameras, tuple) and isinstance(cameras[0], C.Array) else (self.camera_array(cameras), 0)
+            if start < 0 or start + b.n_frames > len(arr):
+                raise ValueError("camera range outside the array")
+            b.cameras = C.cast(C.byref(arr, start * C.sizeof(_abi.vrt_camera)), C.POINTER(_abi.vrt_camera))
         b.frame_stride_bytes = int(frame_stride_bytes)
         _abi.check(self._lib.vrt_render_block(self._ctx, C.byref(params), C.byref(b), C.c_void_p(device_ptr), C.c_void_p(stream)),
                    "vrt_render_block")
+
+    @staticmethod
+    def camera_array(cameras):
+        """A ctypes vrt_camera array from (position[3], rotation[4], fov_deg) triples, to be passed (with a start index) to
+        render_block many times without rebuilding it."""
+        arr = (_abi.vrt_camera * len(cameras))()
+        for c, (pos, rot, fov) in zip(arr, cameras):
+            c.position[:] = [float(x) for x in pos]
+            c.rotation[:] = [float(x) for x in rot]
+            c.fov_deg = float(fov)
+        return arr
 
     def render_begin(self, slot: int, params: Optional[_abi.vrt_params] = None) -> _abi.vrt_params:
         """vrt_render_begin: sync the scene, snapshot it and enqueue the whole frame on frame slot `slot`

@@ -92,6 +92,20 @@ def bench_config3() -> v.VScene:
     return _bench_c3
 
 
+def orbit_cameras(scene: v.VScene, n: int, step_deg: float = 0.25):
+    """n cameras on a short orbit about the world's up axis through the scene's own camera (frame n/2 is the scene's
+    view): the batch of views one bench step renders — consecutive frames of a moving camera, not n copies of one frame.
+    Returns (position, rotation, fov) triples as vrt_render_block takes them."""
+    cam = scene.Camera
+    out = []
+    for f in range(n):
+        a = math.radians((f - n // 2) * step_deg)
+        c, s_ = math.cos(a), math.sin(a)
+        pos = (cam.Position[0] * c - cam.Position[1] * s_, cam.Position[0] * s_ + cam.Position[1] * c, cam.Position[2])
+        out.append((pos, tuple(v.quat_mul(v.quat_from_axis_angle(v.UP, a), cam.Rotation)), float(cam.FOVAngle)))
+    return out
+
+
 def full_closest_hit_scene(resolution: int = 6, env: int = 32) -> v.VScene:
     """Exercises the whole closest-hit shader: smooth metallic spheres that mirror each
     other (roughness 0.1 < 0.3 → bounce, as in the reference's demo materials,
