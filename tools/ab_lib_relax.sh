@@ -8,12 +8,12 @@ for round in 1 2; do
   for spec in $1; do
     lib="${spec%%:*}"; k="${spec#*:}"
     for K in 1 3; do
-      VRT_LIB="$root/volumetricraytracer_amd/lib/$lib.so" python3 "$root/bench.py" --no-cpu-baseline --no-extra-legs --steps 60 --k-relax $k --frames-in-flight $K 2>/dev/null | python3 -c "
+      VRT_LIB="$root/volumetricraytracer_amd/lib/$lib.so" python3 "$root/bench.py" --no-cpu-baseline --no-extra-legs --steps 10 --k-relax $k --frames-in-flight $K 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         o = json.loads(l); r = o['roofline']
-        print('round $round $lib k_relax $k K=$K: %.1f us/frame %.2f Grays/s (kernel %.1f us) samples/ray %.2f' % (o['ms_per_step'] * 1e3, o['value'] / 1e3, r['kernel_ms'] * 1e3, o['config']['samples_per_ray']))
+        print('round $round $lib k_relax $k K=$K: %.1f us/frame %.2f Grays/s (kernel %.1f us) samples/ray %.2f' % (o['ms_per_frame'] * 1e3, o['value'] / 1e3, r['kernel_ms'] * 1e3, o['config']['samples_per_ray']))
 " >> "$out"
     done
   done

@@ -18,13 +18,13 @@ out="$root/gpurun_out/ab"; mkdir -p "$out"; : > "$out/ab.txt"
 for round in 1 2; do
   for v in "${variants[@]}"; do
     name="${v%%:*}"
-    VRT_LIB="$root/volumetricraytracer_amd/lib/ab_$name.so" python3 "$root/bench.py" --no-cpu-baseline --steps 60 "$@" > "$out/$name.$round.json" 2> "$out/$name.$round.err" || echo "$name failed"
+    VRT_LIB="$root/volumetricraytracer_amd/lib/ab_$name.so" python3 "$root/bench.py" --no-cpu-baseline --steps 10 "$@" > "$out/$name.$round.json" 2> "$out/$name.$round.err" || echo "$name failed"
     python3 - "$name" "$round" "$out/$name.$round.json" >> "$out/ab.txt" <<'PY'
 import json, sys
 name, rnd, path = sys.argv[1:4]
 try:
     j = json.loads(open(path).read().strip().splitlines()[-1])
-    print(f"{name:16s} round {rnd}: K=2 {j['ms_per_step']*1e3:7.1f} us/frame {j['value']/1e3:6.2f} Grays/s (kernel {j['roofline']['kernel_ms']*1e3:6.1f} us) | K=1 {j['latency']['ms_per_frame']*1e3:7.1f} us/frame (kernel {j['latency']['kernel_ms']*1e3:6.1f} us) | 4K {j['config4']['ms_per_frame']*1e3:7.1f} us/frame")
+    print(f"{name:16s} round {rnd}: K=2 {j['ms_per_frame']*1e3:7.1f} us/frame {j['value']/1e3:6.2f} Grays/s (kernel {j['roofline']['kernel_ms']*1e3:6.1f} us) | K=1 {j['latency']['ms_per_frame']*1e3:7.1f} us/frame (kernel {j['latency']['kernel_ms']*1e3:6.1f} us) | 4K {j['config4']['ms_per_frame']*1e3:7.1f} us/frame")
 except Exception as e:
     print(f"{name:16s} round {rnd}: no result ({e})")
 PY

@@ -4,5 +4,5 @@ for w in c3 c3sdf c2 c5 c4; do for k in 1 2; do python bench.py --no-cpu-baselin
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        o=json.loads(l); print('$w K=$k', 'ms/frame', o['ms_per_step'], 'kernel_us', round(o['roofline']['kernel_ms']*1e3,1), 'Grays/s', round(o['value']/1e3,2), 'frac', o['roofline']['frac'])
+        o=json.loads(l); print('$w K=$k', 'ms/frame', o['ms_per_frame'], 'kernel_us', round(o['roofline']['kernel_ms']*1e3,1), 'Grays/s', round(o['value']/1e3,2), 'frac', o['roofline']['frac'])
 "; done; done

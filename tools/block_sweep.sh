@@ -6,12 +6,12 @@ out="$root/gpurun_out/block_sweep.txt"; mkdir -p "$root/gpurun_out"; : > "$out"
 for q in default 8; do
   for K in 1 2 3 4 6 8; do
     if [ $q = default ]; then unset GPU_MAX_HW_QUEUES; else export GPU_MAX_HW_QUEUES=$q; fi
-    python3 "$root/bench.py" --no-cpu-baseline --no-extra-legs --steps 96 --frames-in-flight $K "$@" 2>/dev/null | python3 -c "
+    python3 "$root/bench.py" --no-cpu-baseline --no-extra-legs --steps 10 --frames-in-flight $K "$@" 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         o = json.loads(l); r = o['roofline']
-        print('hw queues $q K=$K: %.1f us/frame %.2f Grays/s (kernel %.1f us)' % (o['ms_per_step'] * 1e3, o['value'] / 1e3, r['kernel_ms'] * 1e3))
+        print('hw queues $q K=$K: %.1f us/frame %.2f Grays/s (kernel %.1f us)' % (o['ms_per_frame'] * 1e3, o['value'] / 1e3, r['kernel_ms'] * 1e3))
 " >> "$out"
   done
 done

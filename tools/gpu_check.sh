@@ -9,6 +9,6 @@ for args in "--frames-in-flight 1" "" "--path cells" "--workload c5" "--workload
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        o=json.loads(l); r=o['roofline']; print(o['ms_per_step'], round(o['value'],1), 'kernel_ms', r.get('kernel_ms'), 'spr', r.get('samples_per_ray'))
+        o=json.loads(l); r=o['roofline']; print(o['ms_per_frame'], round(o['value'],1), 'kernel_ms', r.get('kernel_ms'), 'spr', r.get('samples_per_ray'))
 "
 done

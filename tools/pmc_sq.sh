@@ -14,7 +14,7 @@ for set in \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TA_BUSY_avr" ; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$out/p$i" -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 "$@" > "$out/bench_p$i.json" 2> "$out/p$i.err" || echo "pass $i failed: $(tail -2 $out/p$i.err)"
+  rocprofv3 --pmc $set --output-format csv -d "$out/p$i" -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > "$out/bench_p$i.json" 2> "$out/p$i.err" || echo "pass $i failed: $(tail -2 $out/p$i.err)"
 done
 python3 - "$out" "$tag" <<'PY'
 import csv, glob, json, os, sys

@@ -29,18 +29,18 @@ def j(p):
 lines = ["frames in flight sweep (config 3, f32 bricks): K  ms/frame  Grays/s  kernel_ms(events)"]
 for k in (1, 2, 3, 4):
     r = j(f"{out}/k{k}.json")
-    if r: lines.append(f"  {k}  {r['ms_per_step']:.4f}  {r['value']/1e3:6.2f}  {r['roofline']['kernel_ms']:.4f}")
+    if r: lines.append(f"  {k}  {r['ms_per_frame']:.4f}  {r['value']/1e3:6.2f}  {r['roofline']['kernel_ms']:.4f}")
 lines.append("")
 lines.append("device formats / data paths (config 3, K=3): name  ms/frame  Grays/s | K=1 ms/frame | 4K ms/frame Grays/s")
 for p in sorted(glob.glob(f"{out}/fmt_*.json")):
     r = j(p)
     if r:
-        lines.append(f"  {os.path.basename(p)[4:-5]:16s} {r['ms_per_step']:.4f}  {r['value']/1e3:6.2f} | {r['latency']['ms_per_frame']:.4f} | {r['config4']['ms_per_frame']:.4f} {r['config4']['value']/1e3:6.2f}")
+        lines.append(f"  {os.path.basename(p)[4:-5]:16s} {r['ms_per_frame']:.4f}  {r['value']/1e3:6.2f} | {r['latency']['ms_per_frame']:.4f} | {r['config4']['ms_per_frame']:.4f} {r['config4']['value']/1e3:6.2f}")
 lines.append("")
 lines.append("other workloads (K=3): name  ms/frame  Grays/s  kernel_ms  rays/frame  samples/ray")
 for p in sorted(glob.glob(f"{out}/wl_*.json")):
     r = j(p)
-    if r: lines.append(f"  {os.path.basename(p)[3:-5]:6s} {r['ms_per_step']:.4f}  {r['value']/1e3:6.2f}  {r['roofline']['kernel_ms']:.4f}  {r['config']['rays_per_frame']}  {r['config']['samples_per_ray']}")
+    if r: lines.append(f"  {os.path.basename(p)[3:-5]:6s} {r['ms_per_frame']:.4f}  {r['value']/1e3:6.2f}  {r['roofline']['kernel_ms']:.4f}  {r['config']['rays_per_frame']}  {r['config']['samples_per_ray']}")
 open(f"{out}/sweeps.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
