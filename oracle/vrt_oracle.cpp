@@ -105,8 +105,11 @@ Camera camera_basis(const vrt_scene* s, int width, int height) {
 }
 
 inline void camera_ray(const Camera& c, int width, int height, int px, int py, V3& o, V3& d) {
-    float sx = (((float)px + 0.5f) / (float)width) * 2.0f - 1.0f;
-    float sy = (((float)py + 0.5f) / (float)height) * 2.0f - 1.0f;
+    /* pixel centre -> NDC with the reciprocal of the frame size (one rounding more than a division; the kernel takes the
+       reciprocals from the host: two exact divisions per pixel were 8 % of a sky pixel's instructions) */
+    const float inv_w = 1.0f / (float)width, inv_h = 1.0f / (float)height;
+    float sx = (((float)px + 0.5f) * inv_w) * 2.0f - 1.0f;
+    float sy = (((float)py + 0.5f) * inv_h) * 2.0f - 1.0f;
     float tx = sx * c.cx;
     float ty = (-sy) * c.cy;
     V3 dir = v3((tx * c.r0.x + ty * c.r1.x) - c.r2.x,

@@ -237,6 +237,8 @@ void pack_camera(const vrt_scene& s, int width, int height, DFrame& F) {
     float half = tanf(s.cam_fov_deg * (3.14159265358979323846f / 180.0f) * 0.5f);
     F.cx = aspect * half;
     F.cy = half;
+    F.inv_w = 1.0f / (float)width;
+    F.inv_h = 1.0f / (float)height;
 }
 
 /* object→world = S·R (+T), world→object = R^T·S^-1 (RDXLevelObject.cpp:38-47). */

@@ -124,6 +124,7 @@ struct DFrame {
     float cam_o[3];
     float r0[3], r1[3], r2[3];
     float cx, cy;
+    float inv_w, inv_h; /* 1 / width, 1 / height */
     /* directional light */
     float light_dir[3];
     float light_strength;

@@ -990,8 +990,8 @@ __device__ __forceinline__ bool wave_can_reach(const DFrame& F, bool valid, int 
 
 /* Camera ray of pixel (px,py) (Ray.hlsli:36-48, then normalised). */
 __device__ __forceinline__ void camera_ray(const DFrame& F, int px, int py, F3& o, F3& d) {
-    float sx = (((float)px + 0.5f) / (float)F.width) * 2.0f - 1.0f;
-    float sy = (((float)py + 0.5f) / (float)F.height) * 2.0f - 1.0f;
+    float sx = (((float)px + 0.5f) * F.inv_w) * 2.0f - 1.0f; /* 1/width, 1/height from the host (oracle: the same two products) */
+    float sy = (((float)py + 0.5f) * F.inv_h) * 2.0f - 1.0f;
     float tx = sx * F.cx;
     float ty = (-sy) * F.cy;
     d = normalize3(f3((tx * F.r0[0] + ty * F.r1[0]) - F.r2[0], (tx * F.r0[1] + ty * F.r1[1]) - F.r2[1],
