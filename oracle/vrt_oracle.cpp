@@ -935,8 +935,9 @@ void env_lookup(const uint8_t* env, int S, V3 dir, float rgb[3]) {
         if (vz >= 0.0f) { face = 4; sc = vx;  tc = -vy; }
         else            { face = 5; sc = -vx; tc = -vy; }
     }
-    float u = (sc / ma + 1.0f) * 0.5f;
-    float v = (tc / ma + 1.0f) * 0.5f;
+    const float inv_ma = 1.0f / ma; /* one correctly rounded division, two products (kernel and oracle alike) */
+    float u = (sc * inv_ma + 1.0f) * 0.5f;
+    float v = (tc * inv_ma + 1.0f) * 0.5f;
     int ix = (int)floorf(u * (float)S);
     int iy = (int)floorf(v * (float)S);
     ix = ix < 0 ? 0 : (ix > S - 1 ? S - 1 : ix);
