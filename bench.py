@@ -63,7 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--output", default="auto", choices=["auto", "f32", "rgba8"],
                     help="tile pixel format; auto = float4 on one GPU, RGBA8 (the exchange format) on several")
     ap.add_argument("--strip-rows", type=int, default=8,
-                    help="N>1: rows per interleaved strip (8: one wave row; 1080 rows deal out with 0.7 % padding at N = 8, 15 % with 32); 0 = contiguous row tiles")
+                    help="N>1: rows per interleaved strip (8: one wave row; 1080 rows deal out with 0.7 %% padding at N = 8, 15 %% with 32); 0 = contiguous row tiles")
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 8],
                     help="frames launched before the first one must have finished, each on its own HIP stream and tile "
                          "buffer; 0 = 3 on one GPU, what the reference keeps in flight (FrameCount, DXConstants.cpp:23), 8 on several")

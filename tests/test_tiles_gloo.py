@@ -235,3 +235,18 @@ def test_bench_launches_its_own_ranks(tmp_path):
     bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--launch-check"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert bad.returncode == 2 and "refusing" in bad.stderr
+
+
+def test_bench_cli_parses_and_prints_help():
+    """bench.py --help (a percent sign in a help string once broke it) and the defaults the driver relies on."""
+    import subprocess
+
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "--frames-per-step" in res.stdout and "--gpus" in res.stdout
+    sys.path.insert(0, ROOT)
+    import bench
+
+    a = bench.parse_args([])
+    assert (a.gpus, a.frames_per_step, a.strip_rows, a.scaling, a.workload) == (1, 32, 8, "strong", "c3")
+    a = bench.parse_args(["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Per-rank march time of the weak-scaled multi-GPU frames, measured on ONE GPU by launching every
-rank's tile in turn (the tiles are independent; only the gather is missing).  Shows the load balance
-of interleaved strips against contiguous row tiles and the kernel-time growth with resolution.
-Usage: python tools/strip_balance.py [workload] [strip_rows]"""
+"""Per-rank march time and work of the multi-GPU frames, measured on ONE GPU by launching every rank's tile in turn (the
+tiles are independent; only the gather is missing).  Shows the load balance of interleaved strips against contiguous row
+tiles: the SAME frame split N ways (strong scaling, the default) or, with a third argument "weak", the frame grown with N.
+Usage: python tools/strip_balance.py [workload] [strip_rows] [weak]"""
 import os
 import sys
 
@@ -19,16 +19,17 @@ from volumetricraytracer_amd import _abi  # noqa: E402
 from volumetricraytracer_amd.tiles import strip_layout, tile_rows  # noqa: E402
 
 workload = sys.argv[1] if len(sys.argv) > 1 else "c3"
-strip_rows = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+strip_rows = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+weak = len(sys.argv) > 3 and sys.argv[3] == "weak"
 sc, W0, H0, max_steps, shadow, label = bench.build_workload(workload)
 r = v.VHipRenderer()
 assert r.Start()
 r.SetSceneToRender(sc)
 r.SyncWithScene()
 stream = torch.cuda.current_stream().cuda_stream
-print(label)
+print(label + f"; strips of {strip_rows} rows; " + ("weak" if weak else "strong") + " scaling")
 for world in (1, 2, 4, 8):
-    W, H = int(round(W0 * world ** 0.5)), int(round(H0 * world ** 0.5))
+    W, H = (int(round(W0 * world ** 0.5)), int(round(H0 * world ** 0.5))) if weak else (W0, H0)
     p = v.default_params(W, H, scenes.min_cell(sc), max_steps, shadow=shadow)
     p.flags |= _abi.FLAG_OUTPUT_RGBA8
     _, per = strip_layout(H, world, strip_rows)
@@ -50,6 +51,6 @@ for world in (1, 2, 4, 8):
             samples.append(t["primary_steps"] + t["shadow_steps"])
         res[mode] = (ms, rays, samples)
         print(f"  N={world} {W}x{H} {mode:6s}: kernel us per rank " + " ".join(f"{m*1e3:.0f}" for m in ms) +
-              f" | max {max(ms)*1e3:.0f} | rays/rank {min(rays)}..{max(rays)} | samples/ray {sum(samples)/sum(rays):.2f}"
+              f" | max {max(ms)*1e3:.0f} | rays/rank {min(rays)}..{max(rays)} | samples/rank max/mean {max(samples)/(sum(samples)/len(samples)):.3f}"
               f" | march-bound frame rate {sum(rays)/max(ms)/1e6:.1f} Grays/s")
 r.Stop()
