@@ -495,47 +495,75 @@ def main() -> None:
     t = {k: cnt[k] / B / world for k in KEYS}
 
     # ---- extra legs (outside the timed region) ------------------------------------------------------------------
+    def all_ok(ok: bool) -> bool:
+        if world == 1:
+            return ok
+        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(f.item())
+
+    def leg(build, run):
+        """An extra leg must never cost the main line: its allocations (which differ per rank — rank 0 holds the gathered
+        frames) are agreed on by all ranks before anyone enters the leg's collectives; a failure is reported in the leg's key."""
+        obj, err = None, None
+        try:
+            obj = build()
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+        if not all_ok(err is None):
+            return {"error": err or "another rank could not set this leg up"}
+        try:
+            return run(obj)
+        except Exception as e:  # noqa: BLE001
+            return {"error": repr(e)}
+
     native_check = None
     if world > 1 and native_ready and not args.no_extra_legs and args.steps > 0:
         # the other gather implementation, a few frames: same pixels on rank 0, and its frame time
-        try:
-            other = pipeline(p, W, H, K, not use_native)
+        def run_other(other):
             osteps = max(min(args.steps, 3), 1)
             eo = timed_run(other, osteps, 1, world, cdev, B)
             same = True
             if rank == 0:
                 same = bool(torch.equal(other.last_frame(), single_gpu_frame(p, W, H, (other.frame_no - 1) % B)))
-            native_check = {"gather": "torch" if use_native else "native (vrt_gather_tiles: ncclGather on the march stream)",
-                            "ms_per_frame": round(eo / (osteps * B) * 1e3, 4), "last_frame_equals_single_gpu_frame": same}
-            del other
-        except Exception as e:
-            native_check = {"error": repr(e)}
+            return {"gather": "torch" if use_native else "native (vrt_gather_tiles: ncclGather on the march stream)",
+                    "ms_per_frame": round(eo / (osteps * B) * 1e3, 4), "last_frame_equals_single_gpu_frame": same}
+
+        native_check = leg(lambda: pipeline(p, W, H, K, not use_native), run_other)
     latency = end_to_end = config4 = None
     if not args.no_extra_legs and args.steps > 0:
         lsteps = max(min(args.steps, 4), 1)  # batches
-        # one frame in flight: what an application that waits for every frame sees
-        p1 = pipeline(p, W, H, 1, use_native)
-        e1 = timed_run(p1, lsteps, 1, world, cdev, B)
-        k1 = [x for x in r.timing_history(min(lsteps * B, 200)) if x > 0.0]
-        latency = {"frames_in_flight": 1, "ms_per_frame": round(e1 / (lsteps * B) * 1e3, 4), "value": round(rays_per_step * lsteps / e1 / 1e6, 2),
-                   "unit": "Mrays/s", "kernel_ms": round(float(np.mean(k1)), 4) if k1 else None}
-        del p1
+
+        def run_latency(p1):
+            # one frame in flight: what an application that waits for every frame sees
+            e1 = timed_run(p1, lsteps, 1, world, cdev, B)
+            k1 = [x for x in r.timing_history(min(lsteps * B, 200)) if x > 0.0]
+            return {"frames_in_flight": 1, "ms_per_frame": round(e1 / (lsteps * B) * 1e3, 4),
+                    "value": round(rays_per_step * lsteps / e1 / 1e6, 2), "unit": "Mrays/s",
+                    "kernel_ms": round(float(np.mean(k1)), 4) if k1 else None}
+
+        latency = leg(lambda: pipeline(p, W, H, 1, use_native), run_latency)
         if world == 1:
-            end_to_end = end_to_end_leg(r, p, rays_per_frame, 50)
+            end_to_end = leg(lambda: None, lambda _: end_to_end_leg(r, p, rays_per_frame, 50))
         if args.workload in ("c3", "c4") and args.scaling == "strong":
             W4, H4 = 3840, 2160
             p4 = params(W4, H4)
-            r.ResizeRenderOutput(W4, H4)
-            pipe4 = pipeline(p4, W4, H4, K, use_native)
-            s4 = max(min(args.steps, 4), 1)
-            e4 = timed_run(pipe4, s4, 1, world, cdev, B)
-            c4 = batch_counts(p4, W4, H4)
-            config4 = {"workload": f"config4: 256^3 voxelized mesh, 3840x2160 split over {world} GPU(s)" +
-                                   (f", {strip_rows}-row interleaved strips + RCCL gather to rank 0" if world > 1 else ""),
-                       "ms_per_frame": round(e4 / (s4 * B) * 1e3, 4),
-                       "value": round((c4["primary_rays"] + c4["shadow_rays"]) * s4 / e4 / 1e6, 2), "unit": "Mrays/s",
-                       "steps": s4, "frames_per_step": B, "frames_in_flight": K}
-            del pipe4
+
+            def build4():
+                r.ResizeRenderOutput(W4, H4)
+                return pipeline(p4, W4, H4, K, use_native)
+
+            def run4(pipe4):
+                s4 = max(min(args.steps, 4), 1)
+                e4 = timed_run(pipe4, s4, 1, world, cdev, B)
+                c4 = batch_counts(p4, W4, H4)
+                return {"workload": f"config4: 256^3 voxelized mesh, 3840x2160 split over {world} GPU(s)" +
+                                    (f", {strip_rows}-row interleaved strips + RCCL gather to rank 0" if world > 1 else ""),
+                        "ms_per_frame": round(e4 / (s4 * B) * 1e3, 4),
+                        "value": round((c4["primary_rays"] + c4["shadow_rays"]) * s4 / e4 / 1e6, 2), "unit": "Mrays/s",
+                        "steps": s4, "frames_per_step": B, "frames_in_flight": K}
+
+            config4 = leg(build4, run4)
             r.ResizeRenderOutput(W, H)
 
     texel_leg = None
