@@ -1,0 +1,35 @@
+"""Not collected by pytest (by hand on the GPU box: `python tests/soak_random_scenes.py 96 600`): the random-scene fuzz of
+test_parity_gpu.py::test_random_scenes_parity over a seed range of one's choosing; prints every seed whose frame or counters
+differ from the oracle's."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import volumetricraytracer_amd as v  # noqa: E402
+from oracle.binding import OracleScene  # noqa: E402
+from test_parity_gpu import STAT_KEYS, TOL, gpu_render  # noqa: E402
+from volumetricraytracer_amd import workloads as scenes  # noqa: E402
+
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+bad = []
+r = v.VHipRenderer()  # ONE renderer for all scenes: volumes, textures and tables are replaced scene after scene
+assert r.Start()
+for seed in range(lo, hi):
+    sc, p = scenes.random_scene(seed)
+    img, t = gpu_render(r, sc, p)
+    ref, st = OracleScene(sc).render(p, threads=16)
+    keys = STAT_KEYS if len(sc.Objects) == 1 else ("primary_rays", "shadow_rays", "bounce_rays", "hits")
+    err = float(np.abs(img - ref).max())
+    if np.isnan(img).any() or err > TOL or any(t[k] != st[k] for k in keys):
+        bad.append(seed)
+        print(f"seed {seed}: max err {err:.3g} mode {p.mode} objects {len(sc.Objects)}", {k: (t[k], st[k]) for k in keys if t[k] != st[k]}, flush=True)
+    if seed % 50 == 0:
+        print(f"... seed {seed}", flush=True)
+r.Stop()
+print(f"seeds {lo}..{hi - 1}: {len(bad)} mismatches {bad}")
+sys.exit(1 if bad else 0)

@@ -840,6 +840,24 @@ def test_render_rows_can_be_captured_into_a_graph(renderer, oracle_lib):
     assert renderer.last_timing()["kernel_ms"] > 0.0
 
 
+def test_renderer_releases_textures_of_scenes_it_no_longer_renders(oracle_lib):
+    """One renderer, scene after scene, each with three material textures of its own: textures no volume of the current
+    scene names leave the device (vrt_texture_free) and their ids are reused — 30 scenes are 90 textures, more than the
+    VRT_MAX_TEXTURES slots — and the last scene still renders like the oracle."""
+    r = v.VHipRenderer()
+    assert r.Start()
+    try:
+        for i in range(30):
+            sc = scenes.textured_scene()
+            p = v.default_params(96, 54, scenes.min_cell(sc), 255, shadow=True, mode=_abi.MODE_INTERP)
+            img, _ = gpu_render(r, sc, p)
+            assert len(r._tex_ids) <= 3
+        ref, _ = OracleScene(sc).render(p, threads=8)
+        assert np.abs(img - ref).max() <= TOL
+    finally:
+        r.Stop()
+
+
 def test_render_block_is_n_frames_in_flight_with_one_call(renderer, oracle_lib):
     """vrt_render_block: a block of frames, each with its own camera, launched on the context's stream pool and ordered
     like ONE asynchronous operation on the caller's stream.  Every frame equals the same frame rendered alone with that

@@ -86,6 +86,13 @@ class VHipRenderer:
         if sc is None:
             raise RuntimeError("SetSceneToRender was not called")
         vols = sc.volumes()
+        # material textures no volume of the scene names any more leave the device (their ids are handed out again): a
+        # renderer that is given scene after scene does not run out of the VRT_MAX_TEXTURES slots
+        live = {id(t) for vol in vols for t in vol.Material.textures() if t is not None}
+        for key in [k for k in self._tex_ids if k not in live]:
+            _abi.check(self._lib.vrt_texture_free(self._ctx, self._tex_ids[key]), "vrt_texture_free")
+            del self._tex_ids[key]
+            del self._tex_keep[key]
         for slot, vol in enumerate(vols):
             if self._uploaded.get(slot) != id(vol) or vol.dirty:
                 self.upload_volume(slot, vol)
@@ -164,8 +171,9 @@ class VHipRenderer:
         key = id(image)
         if key in self._tex_ids:
             return self._tex_ids[key]
-        tid = len(self._tex_ids)
-        if tid >= _abi.VRT_MAX_TEXTURES:
+        used = set(self._tex_ids.values())
+        tid = next((i for i in range(_abi.VRT_MAX_TEXTURES) if i not in used), None)
+        if tid is None:
             raise RuntimeError("too many material textures")
         img = np.ascontiguousarray(image, dtype=np.uint8)
         _abi.check(self._lib.vrt_texture_upload(self._ctx, tid, img.shape[1], img.shape[0], img.ctypes.data_as(C.c_void_p)),
