@@ -2,10 +2,10 @@
 """Benchmark of the ray-march hot path (BASELINE.json metric: Mrays/s + ms/frame at 1080p over a
 256^3 SDF volume, 1/2/4/8 MI355X).
 
-A "step" is one pass of the hot path over one batch of input: a batch of 32 full frames of the workload (default: BASELINE
+A "step" is one pass of the hot path over one batch of input: a batch of 64 full frames of the workload (default: BASELINE
 config 3 — 1920x1080, 256^3 voxelized mesh, shadow ray on), consecutive views of a camera on a short orbit through the
 workload's own view (0.25 degrees apart) — frames of a moving camera, not copies of one frame; `ms_per_frame` =
-`ms_per_step` / 32 is in the line too.  (A single 1080p frame marches in 0.04 ms: K steps of ONE frame each would time the
+`ms_per_step` / 64 is in the line too.  (A single 1080p frame marches in 0.04 ms: K steps of ONE frame each would time the
 pipeline's fill and drain and the GPU's clock ramp, not the march — profiles/r02_launch_overhead.txt.)  With N ranks (one process per GPU) the SAME frame is split N ways — strong scaling, as the
 metric and config 4 define it: the frame is cut into 8-row strips dealt round-robin to the ranks
 (contiguous tiles would put every object row on the middle GPUs); every rank marches its strips into a
@@ -67,7 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 8],
                     help="frames launched before the first one must have finished, each on its own HIP stream and tile "
                          "buffer; 0 = 3 on one GPU, what the reference keeps in flight (FrameCount, DXConstants.cpp:23), 8 on several")
-    ap.add_argument("--frames-per-step", type=int, default=32,
+    ap.add_argument("--frames-per-step", type=int, default=64,
                     help="frames in the batch ONE step renders: consecutive views of a camera on a short orbit (0.25 degrees apart)")
     ap.add_argument("--block-frames", type=int, default=0,
                     help="frames issued per vrt_render_block call on one stream (one event pair per block); 0 = default")
