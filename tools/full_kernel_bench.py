@@ -1,0 +1,28 @@
+"""GPU box: the full closest-hit kernel (lights, bounces, textures) against the lean kernel on the same scene, 1080p."""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import volumetricraytracer_amd as v
+from volumetricraytracer_amd import workloads, _abi
+for name, sc, bounces in (("full_closest_hit (lights+mirror bounce)", workloads.full_closest_hit_scene(7, 64), 2), ("textured", workloads.textured_scene(7, 64), 2), ("same scene, lean kernel (no lights/bounces)", None, 0)):
+    if sc is None:
+        sc = workloads.full_closest_hit_scene(7, 64); sc.PointLights=[]; sc.SpotLights=[]
+    W,H=1920,1080
+    mode=_abi.MODE_INTERP if name=="textured" else _abi.MODE_INTERP_NOTEX
+    p=v.default_params(W,H,workloads.min_cell(sc),255,shadow=True,mode=mode); p.max_bounces=bounces
+    r=v.VHipRenderer(); assert r.Start(); r.SetSceneToRender(sc); r.ResizeRenderOutput(W,H); r.SyncWithScene()
+    streams=[torch.cuda.Stream() for _ in range(3)]
+    bufs=[torch.empty((2,H,W,4),dtype=torch.float32,device="cuda:0") for _ in range(3)]
+    def run(n):
+        for i in range(n):
+            b=i%3
+            r.render_block(p,2,bufs[b].data_ptr(),H*W*16,streams[b].cuda_stream)
+        torch.cuda.synchronize()
+    run(30)
+    t0=time.perf_counter(); run(150); dt=(time.perf_counter()-t0)/300
+    t=r.last_timing()
+    rays=t["primary_rays"]+t["shadow_rays"]+t["bounce_rays"]
+    print(f"{name}: {dt*1e3:.4f} ms/frame, {rays/dt/1e9:.2f} Grays/s, rays/frame {rays}, samples/ray {(t['primary_steps']+t['shadow_steps'])/rays:.2f}, hits {t['hits']}")
+    r.Stop()
