@@ -72,6 +72,9 @@ def test_argument_errors_without_touching_the_gpu():
     assert lib.vrt_destroy(None) == _abi.VRT_ERR_INVALID
     assert lib.vrt_render(None, None, None) == _abi.VRT_ERR_INVALID
     assert lib.vrt_last_timing(None, None) == _abi.VRT_ERR_INVALID
+    assert lib.vrt_render_block(None, None, None, None, None) == _abi.VRT_ERR_INVALID
+    assert lib.vrt_render_rows(None, None, 0, 0, None, None) == _abi.VRT_ERR_INVALID
+    assert lib.vrt_gather_tiles(None, None, None, 0, 0, None) == _abi.VRT_ERR_NOT_READY  # no context, no communicator
 
 
 def test_no_fallback_when_library_missing(tmp_path):
