@@ -171,6 +171,15 @@ class _StreamEvent:
         self._torch.cuda.current_stream().wait_event(self._ev)
 
 
+def block_plan(frames: int, G: int, K: int):
+    """Sizes of the vrt_render_block calls that issue exactly `frames` frames over K streams: whole rounds of K blocks of G
+    frames, then the rest dealt as evenly as possible over the K streams (no stream ends with a long queue while the others
+    idle).  Block i goes to stream i % K."""
+    rounds, rest = divmod(max(frames, 0), G * K)
+    plan = [G] * (rounds * K) + [rest // K + (1 if k < rest % K else 0) for k in range(K)]
+    return [n for n in plan if n > 0]
+
+
 class Pipeline:
     """K streams, each marching one frame at a time: K frames in flight.  Frames are issued in BLOCKS of up to G frames per
     call on one stream (vrt_render_block: G launches back to back, one event pair per block instead of one per frame), blocks
@@ -210,11 +219,7 @@ class Pipeline:
         torch, fg, r = self.torch, self.fg, self.r
         # whole rounds of K blocks of G frames; the last (partial) round is dealt evenly over the K streams, so that no stream
         # ends with a long queue while the others idle
-        rounds, rest = divmod(steps, self.G * self.K)
-        plan = [self.G] * (rounds * self.K) + [rest // self.K + (1 if k < rest % self.K else 0) for k in range(self.K)]
-        for n in plan:
-            if n == 0:
-                continue
+        for n in block_plan(steps, self.G, self.K):
             b = self.blocks % self.K
             st = self.streams[b]
             with torch.cuda.stream(st):

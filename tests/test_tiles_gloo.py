@@ -250,3 +250,20 @@ def test_bench_cli_parses_and_prints_help():
     assert (a.gpus, a.frames_per_step, a.strip_rows, a.scaling, a.workload) == (1, 64, 8, "strong", "c3")
     a = bench.parse_args(["--gpus", "8", "--steps", "20", "--warmup", "5"])
     assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
+
+
+def test_bench_block_plan_issues_exactly_the_frames_asked_for():
+    """bench.py times EXACTLY K steps: the blocks of a run add up to steps x frames per step, none is larger than the block
+    size, whole rounds come first and the last round is dealt evenly."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for frames in (0, 1, 5, 63, 64, 65, 20 * 64, 100 * 64 + 7):
+        for G, K in ((2, 3), (8, 8), (1, 1), (8, 3), (64, 8)):
+            plan = bench.block_plan(frames, G, K)
+            assert sum(plan) == frames and all(1 <= n <= G for n in plan)
+            full = frames // (G * K) * K
+            assert plan[:full] == [G] * full
+            tail = plan[full:]
+            assert len(tail) <= K and (not tail or max(tail) - min(tail) <= 1)
+    assert bench.block_plan(100, 8, 8) == [8] * 8 + [5, 5, 5, 5, 4, 4, 4, 4]
