@@ -362,6 +362,39 @@ def test_bench_volume_parity(renderer, oracle_lib, path, fmt):
             vol.set_device_format(_abi.FORMAT_F32)
 
 
+def test_bench_batch_cameras_parity(renderer, oracle_lib):
+    """The frames bench.py actually renders: one step is a batch of views of a camera orbiting the config-3 view
+    (workloads.orbit_cameras) issued through vrt_render_block.  The first, a middle and the last camera of the batch at
+    1920x1080, each against the oracle on 8 bands of 16 rows, and all three bit-equal to the same view rendered alone."""
+    import copy
+    import torch
+
+    sc = scenes.bench_config3()
+    W, H, B = 1920, 1080, 64
+    p = v.default_params(W, H, scenes.min_cell(sc), 255, shadow=True)
+    cams = scenes.orbit_cameras(sc, B)
+    assert np.allclose(cams[B // 2][0], sc.Camera.Position) and np.allclose(cams[B // 2][1], sc.Camera.Rotation)  # the workload's own view
+    renderer.SetSceneToRender(sc)
+    renderer.ResizeRenderOutput(W, H)
+    renderer.SyncWithScene()
+    pick = [0, 17, B - 1]
+    block = torch.empty((len(pick), H, W, 4), dtype=torch.float32, device="cuda:0")
+    renderer.render_block(p, len(pick), block.data_ptr(), H * W * 16, 0, cameras=[cams[f] for f in pick])
+    torch.cuda.synchronize()
+    alone = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+    for j, f in enumerate(pick):
+        sf = copy.copy(sc)
+        sf.Camera = v.VCamera(Position=cams[f][0], Rotation=cams[f][1], FOVAngle=cams[f][2])
+        img = block[j].cpu().numpy()
+        assert _oracle_bands(sf, p, img) <= TOL, f
+        renderer.SetSceneToRender(sf)
+        renderer.SyncWithScene()
+        renderer.render_rows(p, 0, H, alone.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert torch.equal(alone, block[j]), f
+    assert not torch.equal(block[0], block[2])
+
+
 def _oracle_bands(sc, p, img, bands=8, rows=16):
     """Oracle comparison on `bands` bands of `rows` rows spread over the frame (the oracle renders row ranges)."""
     o = OracleScene(sc)
