@@ -11,7 +11,9 @@ Two partitions, both seamless because every rank renders from global pixel coord
 The tiles are equal-sized buffers gathered with ONE collective: `torch.distributed.gather` (backend
 "nccl" is RCCL over xGMI on MI355X, "gloo" on CPU for tests), or — `native_gather` — the C-ABI's own
 `vrt_gather_tiles` (ncclGather on the march stream, no torch in the data path).  For strips rank 0 then
-un-shuffles the gathered [rank, strip] order into frame order with one strided device copy."""
+un-shuffles the gathered [rank, strip] order into frame order with one strided device copy.  A buffer may hold
+a BLOCK of several frames' tiles (`frames_per_gather`): one collective then moves the whole block — what
+bench.py does, because at a few tens of microseconds per frame the per-call cost of a collective bounds the job."""
 from __future__ import annotations
 
 from typing import List, Optional, Tuple
