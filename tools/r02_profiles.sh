@@ -13,7 +13,7 @@ for cfg in "f32:--format f32" "texel16_bricks:--format texel16" "texel16_cells:-
   python3 bench.py --no-cpu-baseline $args > $out/fmt_$name.json 2>/dev/null
 done
 for w in c2 c3sdf c5; do python3 bench.py --no-cpu-baseline --no-extra-legs --workload $w > $out/wl_$w.json 2>/dev/null; done
-(cd tools/microbench && ./gather16 > ../../$out/gather16.txt 2>&1)
+(cd tools/microbench && { [ -x gather16 ] || hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o gather16 gather16.hip; } && ./gather16 > ../../$out/gather16.txt 2>&1)
 bash tools/relax_sweep.sh > $out/relax_sweep.log 2>&1; cp gpurun_out/relax_sweep.txt $out/relax_sweep.txt
 # libraries of earlier commits built next to the product one (volumetricraytracer_amd/lib/ab_*.so), when present
 libs=""; for l in ab_prerelax:1.0 ab_prev:1.7 ab_head:1.7 libvrt_hip:1.7; do [ -f volumetricraytracer_amd/lib/${l%%:*}.so ] && libs="$libs $l"; done
