@@ -319,7 +319,7 @@ int build_bvh(std::vector<int>& ids, int begin, int end, const std::vector<Box>&
     }
     if (end - begin == 1) {
         nd.left = -(ids[begin] + 1);
-        nd.right = 0;
+        nd.right = n_nodes; /* the next node in preorder: where the walk goes on after a leaf, or when a box is missed */
         return me;
     }
     int axis = 0;
@@ -341,10 +341,10 @@ int build_bvh(std::vector<int>& ids, int begin, int end, const std::vector<Box>&
         float cl = boxes[l].lo[axis] + boxes[l].hi[axis], cr = boxes[r].lo[axis] + boxes[r].hi[axis];
         return cl < cr || (cl == cr && l < r);
     });
-    int l = build_bvh(ids, begin, mid, boxes, nodes, n_nodes);
-    int r = build_bvh(ids, mid, end, boxes, nodes, n_nodes);
+    int l = build_bvh(ids, begin, mid, boxes, nodes, n_nodes); /* = me + 1: the kernels rely on it */
+    (void)build_bvh(ids, mid, end, boxes, nodes, n_nodes);
     nodes[me].left = l;
-    nodes[me].right = r;
+    nodes[me].right = n_nodes; /* threaded tree: the node that follows this whole subtree in preorder (n_nodes at the very end) */
     return me;
 }
 

@@ -89,7 +89,9 @@ struct DInstance {
     float pad_;
 };
 
-/* Flat AABB BVH over instance world boxes.  Leaf: left = -(instance+1). */
+/* Flat AABB BVH over instance world boxes, nodes in preorder, threaded.  Leaf: left = -(instance+1); inner: left = the node's
+ * own index + 1.  right = the node that follows this node's whole subtree in preorder (n_nodes behind the last): where the
+ * walk continues after a leaf, or when the box is missed. */
 struct DBvhNode {
     float lo[3];
     int32_t left;

@@ -787,33 +787,43 @@ __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float
     } else {
         bool any = false;
         float best = t_max;
-        int stack[16];
-        int sp = 0;
-        if (F.n_nodes > 0) stack[sp++] = 0;
-        while (sp > 0) {
-            const DBvhNode nd = F.nodes[stack[--sp]];
-            if (!slab_box(o, d, nd, best)) continue;
+        /* The WAVE walks the tree (DBvhNode::right is every node's successor when its subtree is left out, the left child of
+           an inner node is the node behind it): a node is visited while ANY lane's ray meets its box, so the node, the
+           instance and its volume are wave-uniform — scalar registers and scalar loads — and a lane marches an instance only
+           when its own ray meets the box.  Per-lane traversal kept a stack and every instance / volume field in vector
+           registers (106 instead of 62).  Same visiting order for every lane as before, and the result does not depend on it. */
+        int ni = 0;
+        while (ni < F.n_nodes) {
+            ni = __builtin_amdgcn_readfirstlane(ni);
+            const DBvhNode nd = F.nodes[ni];
+            const bool in = slab_box(o, d, nd, best);
+            if (__ballot(in) == 0ull) {
+                ni = nd.right;
+                continue;
+            }
             if (nd.left < 0) {
                 const int ii = -nd.left - 1;
                 const DInstance* I = F.inst + ii;
-                float t;
-                F3 n;
-                /* a sphere-trace covers the instance's whole interval whatever was hit before (where its stretched steps
-                   fall depends on the interval's end: cut at `best` the result would depend on the visiting order); the
-                   cell walk of the Cube modes has no such state and stops at the closest hit so far */
-                constexpr bool kCube = PATH == kPathCube || PATH == kPathCube16;
-                if (march_instance<PATH, NORMAL, DIAG>(F, I, F.vols + I->slot, o, d, kCube ? best : t_max, t_base, t, n, steps, dg)) {
-                    if (!any || t < best || (t == best && ii < inst_best)) {
-                        any = true;
-                        best = t;
-                        t_best = t;
-                        inst_best = ii;
-                        n_best = n;
+                if (in) {
+                    float t;
+                    F3 n;
+                    /* a sphere-trace covers the instance's whole interval whatever was hit before (where its stretched steps
+                       fall depends on the interval's end: cut at `best` the result would depend on the visiting order); the
+                       cell walk of the Cube modes has no such state and stops at the closest hit so far */
+                    constexpr bool kCube = PATH == kPathCube || PATH == kPathCube16;
+                    if (march_instance<PATH, NORMAL, DIAG>(F, I, F.vols + I->slot, o, d, kCube ? best : t_max, t_base, t, n, steps, dg)) {
+                        if (!any || t < best || (t == best && ii < inst_best)) {
+                            any = true;
+                            best = t;
+                            t_best = t;
+                            inst_best = ii;
+                            n_best = n;
+                        }
                     }
                 }
+                ni = nd.right;
             } else {
-                stack[sp++] = nd.right;
-                stack[sp++] = nd.left;
+                ni = ni + 1;
             }
         }
         return any;
@@ -828,21 +838,26 @@ __device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_m
     if constexpr (SINGLE) {
         return march_instance<PATH, 0, DIAG, DIR_SHADOW>(F, F.inst, F.vol0, o, d, t_max, t_base, t, n, steps, dg);
     } else {
-        int stack[16];
-        int sp = 0;
-        if (F.n_nodes > 0) stack[sp++] = 0;
-        while (sp > 0) {
-            const DBvhNode nd = F.nodes[stack[--sp]];
-            if (!slab_box(o, d, nd, t_max)) continue;
+        bool found = false; /* this lane's ray is blocked: it takes no further part, the wave goes on for the others */
+        int ni = 0;
+        while (ni < F.n_nodes) {
+            if (__ballot(!found) == 0ull) break;
+            ni = __builtin_amdgcn_readfirstlane(ni);
+            const DBvhNode nd = F.nodes[ni];
+            const bool in = !found && slab_box(o, d, nd, t_max);
+            if (__ballot(in) == 0ull) {
+                ni = nd.right;
+                continue;
+            }
             if (nd.left < 0) {
                 const DInstance* I = F.inst + (-nd.left - 1);
-                if (march_instance<PATH, 0, DIAG, DIR_SHADOW>(F, I, F.vols + I->slot, o, d, t_max, t_base, t, n, steps, dg)) return true;
+                if (in && march_instance<PATH, 0, DIAG, DIR_SHADOW>(F, I, F.vols + I->slot, o, d, t_max, t_base, t, n, steps, dg)) found = true;
+                ni = nd.right;
             } else {
-                stack[sp++] = nd.right;
-                stack[sp++] = nd.left;
+                ni = ni + 1;
             }
         }
-        return false;
+        return found;
     }
 }
 
