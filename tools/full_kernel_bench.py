@@ -6,7 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import volumetricraytracer_amd as v
 from volumetricraytracer_amd import workloads, _abi
-for name, sc, bounces in (("full_closest_hit (lights+mirror bounce)", workloads.full_closest_hit_scene(7, 64), 2), ("textured", workloads.textured_scene(7, 64), 2), ("same scene, lean kernel (no lights/bounces)", None, 0)):
+import copy
+_c3 = copy.copy(workloads.bench_config3())
+_c3.PointLights = [v.VPointLight(Position=(120.0, 60.0, 140.0), Color=(1.0, 0.9, 0.8), IlluminationStrength=40.0)]
+for name, sc, bounces in (("config 3 volume + one point light (single instance, full kernel)", _c3, 0), ("full_closest_hit (lights+mirror bounce)", workloads.full_closest_hit_scene(7, 64), 2), ("textured", workloads.textured_scene(7, 64), 2), ("same scene, lean kernel (no lights/bounces)", None, 0)):
     if sc is None:
         sc = workloads.full_closest_hit_scene(7, 64); sc.PointLights=[]; sc.SpotLights=[]
     W,H=1920,1080
@@ -20,8 +23,8 @@ for name, sc, bounces in (("full_closest_hit (lights+mirror bounce)", workloads.
             b=i%3
             r.render_block(p,2,bufs[b].data_ptr(),H*W*16,streams[b].cuda_stream)
         torch.cuda.synchronize()
-    run(30)
-    t0=time.perf_counter(); run(150); dt=(time.perf_counter()-t0)/300
+    run(600)  # the GPU's clocks take tens of milliseconds to ramp: untimed
+    t0=time.perf_counter(); run(600); dt=(time.perf_counter()-t0)/1200
     t=r.last_timing()
     rays=t["primary_rays"]+t["shadow_rays"]+t["bounce_rays"]
     print(f"{name}: {dt*1e3:.4f} ms/frame, {rays/dt/1e9:.2f} Grays/s, rays/frame {rays}, samples/ray {(t['primary_steps']+t['shadow_steps'])/rays:.2f}, hits {t['hits']}")

@@ -1999,7 +1999,10 @@ static hipError_t launch_full_t(const DFrame& F, hipStream_t stream) {
 
 template <int PATH>
 static hipError_t launch_path(const DFrame& F, bool single, bool diag_build, hipStream_t stream) {
-    if (F.full) return single ? launch_full_t<PATH, true>(F, stream) : launch_full_t<PATH, false>(F, stream);
+    /* the full closest hit always walks the (wave-uniform) BVH, a one-node tree included: its single-instance specialisation
+       kept every instance / volume field live across the whole kernel (128-153 VGPRs, 3 waves per SIMD, against 108-125 and 4)
+       and measured 7 % slower on a one-instance scene with a point light (profiles/r02_full_closest_hit_kernel.txt) */
+    if (F.full) return launch_full_t<PATH, false>(F, stream);
     if constexpr (PATH == VRT_PATH_DENSE || PATH == VRT_PATH_BRICK || PATH == kPathBrick16 || PATH == kPathCells16) {
         if (diag_build) return single ? launch_t<PATH, true>(F, stream) : launch_t<PATH, false>(F, stream);
     }
