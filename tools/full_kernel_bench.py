@@ -9,11 +9,11 @@ from volumetricraytracer_amd import workloads, _abi
 import copy
 _c3 = copy.copy(workloads.bench_config3())
 _c3.PointLights = [v.VPointLight(Position=(120.0, 60.0, 140.0), Color=(1.0, 0.9, 0.8), IlluminationStrength=40.0)]
-for name, sc, bounces in (("config 3 volume + one point light (single instance, full kernel)", _c3, 0), ("full_closest_hit (lights+mirror bounce)", workloads.full_closest_hit_scene(7, 64), 2), ("textured", workloads.textured_scene(7, 64), 2), ("same scene, lean kernel (no lights/bounces)", None, 0)):
+for name, sc, bounces in (("config 3 volume, Cube mode (exact voxel walk, lean kernel)", workloads.bench_config3(), 0), ("config 3 volume + one point light (single instance, full kernel)", _c3, 0), ("full_closest_hit (lights+mirror bounce)", workloads.full_closest_hit_scene(7, 64), 2), ("textured", workloads.textured_scene(7, 64), 2), ("same scene, lean kernel (no lights/bounces)", None, 0)):
     if sc is None:
         sc = workloads.full_closest_hit_scene(7, 64); sc.PointLights=[]; sc.SpotLights=[]
     W,H=1920,1080
-    mode=_abi.MODE_INTERP if name=="textured" else _abi.MODE_INTERP_NOTEX
+    mode=_abi.MODE_INTERP if name=="textured" else (_abi.MODE_CUBE_NOTEX if "Cube mode" in name else _abi.MODE_INTERP_NOTEX)
     p=v.default_params(W,H,workloads.min_cell(sc),255,shadow=True,mode=mode); p.max_bounces=bounces
     r=v.VHipRenderer(); assert r.Start(); r.SetSceneToRender(sc); r.ResizeRenderOutput(W,H); r.SyncWithScene()
     streams=[torch.cuda.Stream() for _ in range(3)]
