@@ -608,7 +608,7 @@ def main() -> None:
             "hbm_measured_GBps": round(traffic / (k_ms * 1e-3) / 1e9, 2) if traffic and kms else None,
             "hbm_measured_frac": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and kms else None,
             "hbm_measured_frac_of_ms_per_frame": round(traffic / (ms_per_step / B * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and world == 1 else None,
-            "limiter": "latency of dependent sample chains (tail) / texture-addresser gather rate (busy phase); not HBM bandwidth",
+            "limiter": "latency of dependent position chains (a lone frame) and vector-instruction issue (62 % of the issue slots with three frames in flight, profiles/r02_pmc_sq_tcp_tcc.txt); not HBM bandwidth",
             "gsamples_per_s": round(samples / (k_ms * 1e-3) / 1e9, 2) if kms else None,
             "gather_ceiling_gsamples_per_s": GATHER_CEILING_GSAMPLES,
         }
