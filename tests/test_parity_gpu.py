@@ -959,6 +959,12 @@ def test_render_block_is_n_frames_in_flight_with_one_call(renderer, oracle_lib):
     torch.cuda.synchronize()
     t = renderer.last_timing()
     assert t["kernel_ms"] == 0.0 and t["primary_rays"] > 0
+    # ... also through vrt_render (host frame): same pixels, no event pair
+    timed_frame, tt = gpu_render(renderer, sc, p)
+    pq = _abi.vrt_params.from_buffer_copy(p)
+    pq.flags |= _abi.FLAG_NO_TIMING
+    untimed_frame, tu = gpu_render(renderer, sc, pq)
+    assert np.array_equal(timed_frame, untimed_frame) and tt["kernel_ms"] > 0.0 and tu["kernel_ms"] == 0.0 and tu["hits"] == tt["hits"]
     lib = _abi.load()
     bad = _abi.vrt_block()
     bad.n_frames, bad.rows, bad.frame_stride_bytes = 0, H, H * W * 16
