@@ -902,7 +902,10 @@ __device__ __forceinline__ F3 brdf_eval(F3 wi, F3 wo, F3 n, F3 albedo, float rou
     const float PI_REF = 3.141592f;
     const float INV_PI_REF = 1.0f / 3.141592f;
     F3 hv = wi + wo;
-    F3 h = hv * fast_rsq(dot3(hv, hv));
+    /* the half vector's length is the correctly rounded one: n.h feeds c = (n.h)^2 (a2 - 1) + 1, which cancels to 1e-3 for smooth
+       materials near the highlight — a 1-ulp reciprocal square root there became 2e-4 of D and, through the tone map of a dark
+       channel, 4e-4 of a pixel (soak of 10 000 random scenes) */
+    F3 h = normalize3(hv);
     F3 f0 = f3(0.04f + (albedo.x - 0.04f) * metal, 0.04f + (albedo.y - 0.04f) * metal,
                0.04f + (albedo.z - 0.04f) * metal);
     float a2 = rough * rough;
