@@ -313,7 +313,7 @@ typedef struct vrt_block {
     int32_t strip_rows, first_strip, strip_stride, n_strips;
     int32_t row0, rows;
     const vrt_camera* cameras;        /* n_frames cameras, or NULL */
-    uint64_t frame_stride_bytes;      /* >= the bytes of one frame's rows */
+    uint64_t frame_stride_bytes;      /* >= the bytes of one frame's rows, a multiple of the pixel size (16, or 4 with VRT_FLAG_OUTPUT_RGBA8) */
 } vrt_block;
 
 /* n_frames launches with ONE call, back to back on hip_stream like n_frames calls of vrt_render_rows / vrt_render_strips with

@@ -1189,7 +1189,8 @@ int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* bl
         rs.rows = block->rows;
     }
     const size_t frame_bytes = (size_t)rs.rows * (size_t)params->width * ((params->flags & VRT_FLAG_OUTPUT_RGBA8) ? 4 : 16);
-    if (block->frame_stride_bytes < frame_bytes || (block->frame_stride_bytes & 15) != 0) return VRT_ERR_INVALID;
+    const size_t pixel_bytes = (params->flags & VRT_FLAG_OUTPUT_RGBA8) ? 4 : 16;
+    if (block->frame_stride_bytes < frame_bytes || block->frame_stride_bytes % pixel_bytes != 0) return VRT_ERR_INVALID;
     DeviceState& D = ctx->dev[0];
     HIP_TRY(hipSetDevice(D.ordinal));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
