@@ -172,6 +172,45 @@ def test_vox_reader_is_order_agnostic_and_rejects_garbage(tmp_path):
         vx.voxelize_file(str(tmp_path / "missing.gltf"))
 
 
+def test_vox_readers_survive_truncated_and_bit_flipped_files(tmp_path):
+    """A .vox file is length-prefixed all the way down (SerializationManager.cpp): a damaged length must not turn into a
+    crash, a hang or a multi-gigabyte allocation.  Every prefix of a small scene file and 300 single-bit flips of it go through
+    the C++ reader and the Python reader: each either loads (a flip in a payload byte) or is refused with an error."""
+    vol = v.sphere_volume(2, 10.0, 4.0, v.VMaterial((0.1, 0.2, 0.3, 1.0), 0.5, 0.25))
+    sc = v.VScene(Objects=[v.VVoxelObject(Position=(1, 2, 3), Volume=vol)], PointLights=[v.VPointLight(Position=(5, 5, 5))])
+    good = str(tmp_path / "good.vox")
+    vox_io.save_scene(sc, good)
+    raw = open(good, "rb").read()
+    out = str(tmp_path / "out.vox")
+    bad = str(tmp_path / "bad.vox")
+    rng = np.random.RandomState(3)
+    cuts = sorted(set([0, 1, 7, 8, 9, 15, 16, 17, len(raw) - 1] + [int(x) for x in rng.randint(0, len(raw), 120)]))
+    refused = 0
+    for n in cuts:  # truncations: always an error
+        open(bad, "wb").write(raw[:n])
+        with pytest.raises(RuntimeError):
+            vx.vox_rewrite(bad, out)
+        with pytest.raises(Exception):
+            vox_io.load_scene(bad)
+        refused += 1
+    loaded = 0
+    for _ in range(300):  # bit flips: an error or a scene, never anything else
+        b = bytearray(raw)
+        i = int(rng.randint(0, len(b)))
+        b[i] ^= 1 << int(rng.randint(0, 8))
+        open(bad, "wb").write(bytes(b))
+        try:
+            vx.vox_rewrite(bad, out)
+            loaded += 1
+        except RuntimeError:
+            pass
+        try:
+            vox_io.load_scene(bad)
+        except Exception:  # noqa: BLE001
+            pass
+    assert refused == len(cuts) and loaded > 50  # most flips land in voxel payload and load fine
+
+
 def test_relative_texture_paths_resolve_against_the_vox_folder(tmp_path, monkeypatch):
     """VMaterial::Deserialize(sourcePath, archive) (Core/Private/Material.cpp:72-100): a texture path that is not absolute
     is relative to the folder of the .vox file, whatever the working directory; absolute paths stay.  Both readers."""
