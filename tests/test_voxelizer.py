@@ -172,6 +172,39 @@ def test_vox_reader_is_order_agnostic_and_rejects_garbage(tmp_path):
         vx.voxelize_file(str(tmp_path / "missing.gltf"))
 
 
+def test_gltf_importer_survives_damaged_files(tmp_path):
+    """.gltf (JSON with an embedded buffer) and .glb (binary container) with 1-3 damaged bytes, some also truncated: the C++
+    importer either voxelizes the file or refuses it with an error (whose text may hold bytes of the file: the Python wrapper
+    must not choke on them) — 300 mutations, no crash, no hang."""
+    pos, nrm, idx = vx.cube_mesh()
+    node = [{"name": "cube_3", "mesh": 0}]
+    emb = str(tmp_path / "cube.gltf")
+    vx.write_gltf(emb, [("cube_3", pos, nrm, idx, None)], node, embed=True)
+    ext = str(tmp_path / "cube2.gltf")
+    vx.write_gltf(ext, [("cube_3", pos, nrm, idx, None)], node, embed=False)
+    glb = str(tmp_path / "cube.glb")
+    vx.gltf_to_glb(ext, glb)
+    sources = [(open(emb, "rb").read(), ".gltf"), (open(glb, "rb").read(), ".glb")]
+    rng = np.random.RandomState(5)
+    ok = refused = 0
+    for k in range(300):
+        raw, suffix = sources[k % 2]
+        b = bytearray(raw)
+        for _ in range(int(rng.randint(1, 4))):
+            i = int(rng.randint(0, len(b)))
+            b[i] = int(rng.randint(0, 256)) if k % 3 == 0 else b[i] ^ (1 << int(rng.randint(0, 8)))
+        if rng.randint(0, 5) == 0:
+            b = b[: int(rng.randint(0, len(b)))]
+        path = str(tmp_path / ("damaged" + suffix))
+        open(path, "wb").write(bytes(b))
+        try:
+            vx.voxelize_file(path, str(tmp_path / "o.vox"))
+            ok += 1
+        except RuntimeError:
+            refused += 1
+    assert ok > 30 and refused > 100
+
+
 def test_vox_readers_survive_truncated_and_bit_flipped_files(tmp_path):
     """A .vox file is length-prefixed all the way down (SerializationManager.cpp): a damaged length must not turn into a
     crash, a hang or a multi-gigabyte allocation.  Every prefix of a small scene file and 300 single-bit flips of it go through

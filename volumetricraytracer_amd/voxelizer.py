@@ -54,7 +54,7 @@ def convert_mesh(positions: np.ndarray, indices: np.ndarray, bounds_extends, mes
     be = (C.c_float * 3)(*[float(x) for x in bounds_extends])
     h = lib.vrh_convert_mesh(pos.ctypes.data, len(pos), idx.ctypes.data, len(idx), be, mesh_name.encode())
     if not h:
-        raise RuntimeError("vrh_convert_mesh: " + lib.vrh_last_error().decode())
+        raise RuntimeError("vrh_convert_mesh: " + lib.vrh_last_error().decode(errors="replace"))
     try:
         res, size = C.c_int(), C.c_int()
         ext, cell, scale, smax = C.c_float(), C.c_float(), C.c_float(), C.c_float()
@@ -78,14 +78,14 @@ def voxelize_file(gltf_path: str, out_path: str | None = None, texlib: str | Non
     buf = C.create_string_buffer(4096)
     rc = lib.vrh_voxelize_file(gltf_path.encode(), texlib.encode() if texlib else None, out_path.encode() if out_path else None, buf, 4096)
     if rc != 0:
-        raise RuntimeError("vrh_voxelize_file: " + lib.vrh_last_error().decode())
+        raise RuntimeError("vrh_voxelize_file: " + lib.vrh_last_error().decode(errors="replace"))
     return buf.value.decode()
 
 
 def vox_rewrite(in_path: str, out_path: str) -> None:
     lib = load_host()
     if lib.vrh_vox_rewrite(in_path.encode(), out_path.encode()) != 0:
-        raise RuntimeError("vrh_vox_rewrite: " + lib.vrh_last_error().decode())
+        raise RuntimeError("vrh_vox_rewrite: " + lib.vrh_last_error().decode(errors="replace"))
 
 
 # ---- procedural meshes --------------------------------------------------------------------------
@@ -205,10 +205,10 @@ def load_texture(path: str) -> np.ndarray:
     lib.vrh_texture_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
     w, h = C.c_int(), C.c_int()
     if lib.vrh_texture_load(path.encode(), C.byref(w), C.byref(h), None, 0) != 0:
-        raise RuntimeError("vrh_texture_load: " + lib.vrh_last_error().decode())
+        raise RuntimeError("vrh_texture_load: " + lib.vrh_last_error().decode(errors="replace"))
     out = np.zeros((h.value, w.value, 4), np.uint8)
     if lib.vrh_texture_load(path.encode(), None, None, out.ctypes.data, out.nbytes) != 0:
-        raise RuntimeError("vrh_texture_load: " + lib.vrh_last_error().decode())
+        raise RuntimeError("vrh_texture_load: " + lib.vrh_last_error().decode(errors="replace"))
     return out
 
 
@@ -221,8 +221,8 @@ def load_skybox_faces(directory: str) -> np.ndarray:
     lib.vrh_cubemap_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
     size = C.c_int()
     if lib.vrh_cubemap_load(directory.encode(), C.byref(size), None, 0) != 0:
-        raise RuntimeError("vrh_cubemap_load: " + lib.vrh_last_error().decode())
+        raise RuntimeError("vrh_cubemap_load: " + lib.vrh_last_error().decode(errors="replace"))
     out = np.zeros((6, size.value, size.value, 4), np.uint8)
     if lib.vrh_cubemap_load(directory.encode(), None, out.ctypes.data, out.nbytes) != 0:
-        raise RuntimeError("vrh_cubemap_load: " + lib.vrh_last_error().decode())
+        raise RuntimeError("vrh_cubemap_load: " + lib.vrh_last_error().decode(errors="replace"))
     return out
