@@ -172,6 +172,43 @@ def test_vox_reader_is_order_agnostic_and_rejects_garbage(tmp_path):
         vx.voxelize_file(str(tmp_path / "missing.gltf"))
 
 
+def test_png_reader_survives_damaged_files(tmp_path):
+    """The material-texture PNG reader on 300 damaged copies of a valid file (random bytes, some with the chunk CRCs recomputed
+    so that the damage reaches the inflater and the un-filter code, some truncated): a texture or an error, never a crash."""
+    import zlib
+
+    rng = np.random.RandomState(9)
+    good = str(tmp_path / "g.png")
+    _write_png(good, rng.randint(0, 256, (13, 17, 4)).astype(np.uint8), 6)
+    raw = open(good, "rb").read()
+    ok = refused = 0
+    for k in range(300):
+        b = bytearray(raw)
+        for _ in range(int(rng.randint(1, 4))):
+            b[int(rng.randint(8, len(b)))] = int(rng.randint(0, 256))
+        if k % 4 == 1:  # valid CRCs around damaged chunk data
+            out, pos = bytearray(b[:8]), 8
+            while pos + 12 <= len(b):
+                ln = struct.unpack(">I", b[pos:pos + 4])[0]
+                if pos + 12 + ln > len(b):
+                    break
+                t, dd = bytes(b[pos + 4:pos + 8]), bytes(b[pos + 8:pos + 8 + ln])
+                out += b[pos:pos + 8] + dd + struct.pack(">I", zlib.crc32(t + dd) & 0xffffffff)
+                pos += 12 + ln
+            b = out
+        if k % 4 == 2:
+            b = b[: int(rng.randint(0, len(b)))]
+        path = str(tmp_path / "f.png")
+        open(path, "wb").write(bytes(b))
+        try:
+            img = vx.load_texture(path)
+            assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 4
+            ok += 1
+        except RuntimeError:
+            refused += 1
+    assert refused > 200 and ok + refused == 300
+
+
 def test_gltf_importer_survives_damaged_files(tmp_path):
     """.gltf (JSON with an embedded buffer) and .glb (binary container) with 1-3 damaged bytes, some also truncated: the C++
     importer either voxelizes the file or refuses it with an error (whose text may hold bytes of the file: the Python wrapper
