@@ -170,7 +170,7 @@ typedef struct vrt_scene {
 typedef struct vrt_params {
     int32_t width;
     int32_t height;
-    int32_t max_steps;    /* march budget per (ray, instance); reference budget: 255 (Raytracing.hlsl:229) */
+    int32_t max_steps;    /* march budget per (ray, instance), 0 .. 65535 positions; reference budget: 255 (Raytracing.hlsl:229) */
     int32_t shadow;       /* 1 = cast the directional-light shadow ray (Raytracing.hlsl:52-59) */
     int32_t mode;         /* vrt_render_mode */
     int32_t path;         /* vrt_data_path */

@@ -660,7 +660,7 @@ int pack_scene(vrt_ctx* ctx) {
 int check_params(const vrt_ctx* ctx, const vrt_params* p) {
     if (!ctx || !p) return VRT_ERR_INVALID;
     if (p->width <= 0 || p->height <= 0 || p->width > 16384 || p->height > 16384) return VRT_ERR_INVALID;
-    if (p->max_steps < 0 || p->max_bounces < 0 || p->max_bounces > 2) return VRT_ERR_INVALID;
+    if (p->max_steps < 0 || p->max_steps > 65535 || p->max_bounces < 0 || p->max_bounces > 2) return VRT_ERR_INVALID;
     if (!(p->eps_hit == p->eps_hit) || !(p->step_min > 0.0f) || !(p->k_relax > 0.0f) || !(p->eps_in >= 0.0f) ||
         !(p->cone_eps >= 0.0f))
         return VRT_ERR_INVALID;
