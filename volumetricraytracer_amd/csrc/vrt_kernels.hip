@@ -634,9 +634,10 @@ struct MarchState {
  * The march loop of one lane on data path DP, from state `st` until a hit, the end of the interval, or `limit`
  * iterations.  One iteration = one position: either skipped (the two-level table shows no active cell within the
  * leap: the ray advances, no tap is read, no sample counted) or sampled.
- * Table words are re-read only when the ray changes brick.  (Two refinements are compiled out after measurement, see the
- * VRT_AB_* blocks: speculative taps for the next brick, and keeping a cell's taps in registers across samples.)
- * Same positions, same values, same counters as the oracle's plain loop.
+ * Table words are re-read only when the ray changes brick.  (Two refinements were measured and removed — speculative taps
+ * for the next brick, a cell's taps kept in registers across samples: profiles/r02_ab_march_variants.txt.)  The loop has ONE
+ * exit test, and the sample path is written with selects: every instruction taken out of it is ~0.4 % of the frame.
+ * Same positions, same values, same counters as the oracle's loop.
  */
 template <int DP, bool DIAG>
 __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, const RaySeg& R, MarchState& st, int limit, unsigned& steps,
