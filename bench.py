@@ -65,12 +65,15 @@ def parse_args(argv=None):
     ap.add_argument("--strip-rows", type=int, default=8,
                     help="N>1: rows per interleaved strip (8: one wave row; 1080 rows deal out with 0.7 %% padding at N = 8, 15 %% with 32); 0 = contiguous row tiles")
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 8],
-                    help="frames launched before the first one must have finished, each on its own HIP stream and tile "
-                         "buffer; 0 = 3 on one GPU, what the reference keeps in flight (FrameCount, DXConstants.cpp:23), 8 on several")
-    ap.add_argument("--frames-per-step", type=int, default=64,
+                    help="HIP streams that carry blocks of frames (each with its own tile buffer); 0 = 1 on one GPU (one march launch "
+                         "covers a whole block of frames: the launch itself keeps the frames in flight), 2 on several (a block's gather "
+                         "overlaps the next block's march)")
+    ap.add_argument("--frames-per-step", type=int, default=96,
                     help="frames in the batch ONE step renders: consecutive views of a camera on a short orbit (0.25 degrees apart)")
     ap.add_argument("--block-frames", type=int, default=0,
-                    help="frames issued per vrt_render_block call on one stream (one event pair per block); 0 = default")
+                    help="frames per vrt_render_block call = per march launch (up to 48; one event pair per launch); 0 = default")
+    ap.add_argument("--per-frame-launches", action="store_true",
+                    help="A/B: vrt_render_block issues one march launch per frame (VRT_FLAG_BLOCK_PER_FRAME) instead of one per block")
     ap.add_argument("--k-relax", type=float, default=0.0,
                     help="over-relaxation factor of the sphere trace (vrt_params.k_relax); 0 = the renderer's default (1.7), 1 = plain")
     ap.add_argument("--tile-map", default="supertile", choices=["supertile", "band", "linear"], help="blockIdx -> tile map (speed only)")
@@ -396,7 +399,7 @@ def main() -> None:
     # one GPU: 3 = FrameCount, DXConstants.cpp:23.  Several: every GPU gets 1/N of a frame whose march lasts as long as its longest
     # chain whatever its size (profiles/r02_strong_scaling_probe.txt), so the pipeline is deepened to 8 frames (about one whole
     # frame's work in flight per GPU at N = 8) over 8 HIP hardware queues
-    K = args.frames_in_flight or (3 if world == 1 else 8)
+    K = args.frames_in_flight or (1 if world == 1 else 2)
     path = {"auto": _abi.PATH_AUTO, "dense": _abi.PATH_DENSE, "brick": _abi.PATH_BRICK, "lds": _abi.PATH_BRICK_LDS, "cells": _abi.PATH_CELLS}[args.path]
     fmt = {"auto": workloads.BENCH_VOLUME_FORMAT, "f32": _abi.FORMAT_F32, "texel16": _abi.FORMAT_TEXEL16}[args.format]
     for vol in sc.volumes():
@@ -408,6 +411,8 @@ def main() -> None:
             q.k_relax = args.k_relax
         if rgba8:
             q.flags |= _abi.FLAG_OUTPUT_RGBA8
+        if args.per_frame_launches:
+            q.flags |= _abi.FLAG_BLOCK_PER_FRAME
         q.flags |= {"supertile": 0, "band": 1, "linear": 2}[args.tile_map]
         return q
 
@@ -442,8 +447,8 @@ def main() -> None:
     # One STEP = one batch of B frames: consecutive views of a camera on a short orbit through the workload's own view
     # (frames of a moving camera, not B copies of one frame, so a frame does not find its predecessor's lines in L2).
     B = max(args.frames_per_step, 1)
-    # frames per vrt_render_block call: one GPU 2 (measured best at K = 3); several GPUs 8, gathered as ONE block per collective
-    G = min(args.block_frames or (2 if world == 1 else 8), B)
+    # frames per vrt_render_block call = per march launch: one GPU 48 (the most a launch covers); several GPUs 24, gathered as ONE block per collective
+    G = min(args.block_frames or (_abi.MAX_BLOCK_FRAMES if world == 1 else 24), B)
     cams = workloads.orbit_cameras(sc, B)
     cam_arr = r.camera_array(cams + cams)
     KEYS = ("primary_rays", "shadow_rays", "bounce_rays", "primary_steps", "shadow_steps", "hits", "exhausted_rays")
@@ -470,13 +475,16 @@ def main() -> None:
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
         return dict(zip(KEYS, (float(x) for x in c.tolist())))
 
-    def pipeline(pp, w, h, k, native):
-        return Pipeline(r, pp, w, h, world, rank, dev, rgba8, strip_rows, k, rehearsal, native=native, block_frames=G, cameras=cam_arr,
+    def pipeline(pp, w, h, k, native, g=None):
+        return Pipeline(r, pp, w, h, world, rank, dev, rgba8, strip_rows, k, rehearsal, native=native, block_frames=g or G, cameras=cam_arr,
                         n_cameras=B)
 
     pipe = pipeline(p, W, H, K, use_native)
     elapsed = timed_run(pipe, args.steps, args.warmup, world, cdev, B)
-    kms = [x for x in r.timing_history(min(args.steps * B, 200)) if x > 0.0]  # the event-timed launches: the first frame of every block
+    # the event-timed march launches of the timed region: (ms, frames the launch covered); only whole blocks count
+    hist = [(ms, fr) for ms, fr in r.launch_history(200) if ms > 0.0]
+    fpl = max((fr for _, fr in hist), default=1)  # frames per launch
+    kms = [ms for ms, fr in hist if fr == fpl]
 
     def single_gpu_frame(pp, w, h, cam_index):
         whole = torch.empty((h, w, 4), dtype=torch.uint8 if rgba8 else torch.float32, device=dev)
@@ -542,12 +550,12 @@ def main() -> None:
         def run_latency(p1):
             # one frame in flight: what an application that waits for every frame sees
             e1 = timed_run(p1, lsteps, 1, world, cdev, B)
-            k1 = [x for x in r.timing_history(min(lsteps * B, 200)) if x > 0.0]
-            return {"frames_in_flight": 1, "ms_per_frame": round(e1 / (lsteps * B) * 1e3, 4),
+            k1 = [x for x, fr in r.launch_history(200) if x > 0.0 and fr == 1]
+            return {"frames_in_flight": 1, "frames_per_launch": 1, "ms_per_frame": round(e1 / (lsteps * B) * 1e3, 4),
                     "value": round(rays_per_step * lsteps / e1 / 1e6, 2), "unit": "Mrays/s",
                     "kernel_ms": round(float(np.mean(k1)), 4) if k1 else None}
 
-        latency = leg(lambda: pipeline(p, W, H, 1, use_native), run_latency)
+        latency = leg(lambda: pipeline(p, W, H, 1, use_native, 1), run_latency)
         if world == 1:
             def e2e(_):
                 # the frame as the host gets it, in the bench's pixel format and in the reference's own back-buffer precision
@@ -600,10 +608,10 @@ def main() -> None:
             vol.set_device_format(fmt)
 
     if rank == 0:
-        alg_bytes = v.algorithmic_bytes(t, 4 if rgba8 else 16)
+        alg_bytes = v.algorithmic_bytes(t, 4 if rgba8 else 16) * fpl  # of ONE launch: fpl frames
         k_ms = float(np.mean(kms)) if kms else float("nan")
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if kms else 0.0
-        samples = int(t["primary_steps"] + t["shadow_steps"])
+        samples = int(t["primary_steps"] + t["shadow_steps"]) * fpl
         psteps, ssteps = cnt["primary_steps"], cnt["shadow_steps"]
         traffic = measured_traffic(traffic_key(args, world, K, rgba8))
         roofline = {
@@ -611,7 +619,7 @@ def main() -> None:
             # of one launch / its mean event-timed duration / the HBM peak
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_key": traffic_key(args, world, K, rgba8),
-            "kernel": "march_kernel", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+            "kernel": "march_kernel", "kernel_ms": round(k_ms, 4), "frames_per_launch": fpl, "algorithmic_bytes_per_launch": int(alg_bytes),
             "samples_per_launch": samples,
             # physical picture: what really crosses the HBM interface, and what the kernel really waits for
             "hbm_measured_GBps": round(traffic / (k_ms * 1e-3) / 1e9, 2) if traffic and kms else None,

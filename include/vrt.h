@@ -55,6 +55,8 @@ extern "C" {
                                    the reference's back-buffer precision (B8G8R8A8_UNORM, DXConstants.cpp:21);
                                    value = (uint)(min(c,1)*255 + 0.5) of the float channel the float4 path stores */
 
+#define VRT_FLAG_BLOCK_PER_FRAME 64 /* vrt_render_block: one march launch per frame, back to back on the stream, instead of ONE launch
+                                      for the block's frames (A/B measurements and tests; same pixels) */
 #define VRT_FLAG_NO_TIMING 16    /* the launch records no event pair: vrt_last_timing / vrt_timing_history report 0 ms for it.
                                    An event pair costs 5-7 us of queue time per launch (profiles/r02_launch_overhead.txt);
                                    callers that keep many small launches in flight time a sample of them */
@@ -177,7 +179,8 @@ typedef struct vrt_params {
     int32_t max_bounces;  /* mirror-reflection depth, 0..2 (MAX_RAY_RECURSION_DEPTH 3 = primary + 2) */
     int32_t flags;        /* bits 0-1: blockIdx→tile map, 0 supertile (default) / 1 XCD band / 2 linear
                              (speed only, never results); bit 2: VRT_FLAG_DIAG_TIMELINE; bit 3:
-                             VRT_FLAG_OUTPUT_RGBA8; bit 4: VRT_FLAG_NO_TIMING.  Others 0 */
+                             VRT_FLAG_OUTPUT_RGBA8; bit 4: VRT_FLAG_NO_TIMING; bit 5: accepted and ignored (it was round 1's
+                             VRT_FLAG_SKIP_EMPTY: the march never samples empty cells now); bit 6: VRT_FLAG_BLOCK_PER_FRAME.  Others 0 */
     float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
     float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
     float step_min;       /* lower bound of one march step (ray-parameter units) */
@@ -316,14 +319,16 @@ typedef struct vrt_block {
     uint64_t frame_stride_bytes;      /* >= the bytes of one frame's rows, a multiple of the pixel size (16, or 4 with VRT_FLAG_OUTPUT_RGBA8) */
 } vrt_block;
 
-/* n_frames launches with ONE call, back to back on hip_stream like n_frames calls of vrt_render_rows / vrt_render_strips with
- * the scene's camera set to cameras[f] in between: same pixels, no host synchronisation, no allocation after the stream's
- * first launch of that size.  For callers that keep many small launches in flight — a GPU's share of a frame that is split N
- * ways marches in less time than an API round trip, an event pair and the caller's own bookkeeping take per launch
- * (profiles/r02_launch_overhead.txt) — and for rendering a camera path.  The reference keeps FrameCount = 3 frames in flight
- * on its swap chain (DXConstants.cpp:23, DXRenderer.cpp:37-66): overlap comes from issuing blocks on several streams.  Only
- * the block's first frame is event-timed (vrt_timing_history reports 0 ms for the others); vrt_last_timing holds the
- * counters of the last frame. */
+/* n_frames frames with ONE call and ONE march launch per 32 frames (the kernel's grid has a frame axis; the cameras travel in
+ * the kernarg segment): the same pixels as n_frames calls of vrt_render_rows / vrt_render_strips with the scene's camera set to
+ * cameras[f] in between, no host synchronisation, no allocation after the stream's first launch of that size.  The reference
+ * keeps FrameCount = 3 frames in flight on its swap chain (DXConstants.cpp:23, DXRenderer.cpp:974-989) because a frame's last
+ * third is a few latency-bound waves on an otherwise idle GPU; inside one launch the dispatcher back-fills those wave slots
+ * with the next frame's waves, so the tail is paid once per launch instead of once per frame, whatever the number of streams
+ * and hardware queues — and a GPU's eighth of a frame that is split 8 ways (11 us of march) no longer pays a launch and an
+ * event pair of its own (profiles/r02_launch_overhead.txt).  Also for rendering a camera path.  vrt_timing_history /
+ * vrt_launch_history report one duration per LAUNCH (vrt_launch_history also says how many frames it covered);
+ * vrt_last_timing holds the counters of the block's last frame and the duration of its last launch. */
 int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* block, void* device_rgba, void* hip_stream);
 
 /* ---- multi-GPU exchange (one process per GPU) --------------------------------------------------------------------------
@@ -359,7 +364,10 @@ int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out);
  * returns how many were written (<= n), or a negative status. */
 int vrt_timing_history(vrt_ctx* ctx, int n, float* kernel_ms_out);
 
-/* Diagnostics: per-wave records of the last launch on the first device, 8 words each, record
+/* The same, with the number of frames each launch covered (vrt_render_block: up to 32 per launch; everything else: 1). */
+int vrt_launch_history(vrt_ctx* ctx, int n, float* kernel_ms_out, int* frames_out);
+
+/* Diagnostics: per-wave records of the last frame of the last launch on the first device, 8 words each, record
  * index = blockIdx*4 + wave.  which = 0: counters {primary_rays, shadow_rays, bounce_rays,
  * primary_steps, shadow_steps, hits, exhausted_rays, 0}.  which = 1 (only after a VRT_FLAG_DIAG_TIMELINE launch):
  * {start, end (100 MHz ticks), iterations whose taps were back within 450 cycles, XCC_ID | HW_ID<<4, longest

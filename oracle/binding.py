@@ -74,6 +74,11 @@ def load() -> C.CDLL:
         lib.vrto_ref_hit_t.restype = C.c_int
         lib.vrto_ref_hit_t.argtypes = [C.POINTER(vrto_volume), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                        C.POINTER(C.c_double)]
+        lib.vrto_trace_batch.restype = C.c_int
+        lib.vrto_trace_batch.argtypes = [C.POINTER(_abi.vrt_scene), C.POINTER(vrto_volume), C.POINTER(_abi.vrt_params), C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        lib.vrto_ref_hit_batch.restype = C.c_int
+        lib.vrto_ref_hit_batch.argtypes = [C.POINTER(vrto_volume), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         lib.vrto_debug_tables.restype = C.c_int
         lib.vrto_debug_tables.argtypes = [C.POINTER(vrto_volume), C.c_void_p, C.c_void_p, C.c_void_p]
         lib.vrto_env_lookup.restype = None
@@ -142,6 +147,37 @@ class OracleScene:
         if hit < 0:
             raise RuntimeError(f"vrto_trace failed: {hit}")
         return bool(hit), t.value, np.array(list(n), dtype=np.float32), inst.value, steps.value
+
+    def trace_batch(self, params: _abi.vrt_params, origins, directions, t_max: float = 10000.0, threads: int = 8):
+        """vrto_trace for many world-space rays with the scene set up once: (hit [n] bool, t [n] float32, normal [n, 3])."""
+        org = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        dr = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = len(org)
+        hit, t, nrm = np.zeros(n, np.uint8), np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
+        rc = load().vrto_trace_batch(C.byref(self.abi), self.vols, C.byref(params), n, org.ctypes.data, dr.ctypes.data, t_max,
+                                     hit.ctypes.data, t.ctypes.data, nrm.ctypes.data, threads)
+        if rc != 0:
+            raise RuntimeError(f"vrto_trace_batch failed: {rc}")
+        return hit.astype(bool), t, nrm
+
+    def ref_hit_batch(self, slot: int, origins, directions, threads: int = 8):
+        """vrto_ref_hit_t (the reference's DDA + per-cell cubic, double precision) for many OBJECT-space rays of one volume."""
+        org = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        dr = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = len(org)
+        hit, t = np.zeros(n, np.uint8), np.zeros(n, np.float64)
+        rc = load().vrto_ref_hit_batch(C.byref(self.vols[slot]), n, org.ctypes.data, dr.ctypes.data, hit.ctypes.data, t.ctypes.data, threads)
+        if rc != 0:
+            raise RuntimeError(f"vrto_ref_hit_batch failed: {rc}")
+        return hit.astype(bool), t
+
+    def camera_rays(self, width: int, height: int, pixels):
+        """Camera rays of many (px, py) pixels: origins [n, 3], directions [n, 3]."""
+        o = np.zeros((len(pixels), 3), np.float32)
+        d = np.zeros((len(pixels), 3), np.float32)
+        for i, (px, py) in enumerate(pixels):
+            o[i], d[i] = self.camera_ray(width, height, int(px), int(py))
+        return o, d
 
     def camera_ray(self, width: int, height: int, px: int, py: int):
         lib = load()

@@ -1330,6 +1330,42 @@ int vrto_trace(const vrt_scene* scene, const vrto_volume* volumes, const vrt_par
     return hit ? 1 : 0;
 }
 
+/* vrto_trace for n rays with the scene packed ONCE (packing builds the empty-space tables: 45 ms for a 256^3 shell). */
+int vrto_trace_batch(const vrt_scene* scene, const vrto_volume* volumes, const vrt_params* params, int n, const float* origins,
+                     const float* dirs, float t_max, uint8_t* hit_out, float* t_out, float* normal_out_or_null, int threads) {
+    if (n < 0 || (n > 0 && (!origins || !dirs || !hit_out || !t_out))) return VRT_ERR_INVALID;
+    std::unique_ptr<Packed> P(new Packed);
+    vrt_params prm = *params;
+    if (prm.width <= 0) prm.width = 1;
+    if (prm.height <= 0) prm.height = 1;
+    if (!pack(scene, volumes, nullptr, 0, &prm, *P)) return VRT_ERR_INVALID;
+    if (threads < 1) threads = 1;
+    auto work = [&](int k) {
+        for (int i = k; i < n; i += threads) {
+            const V3 o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+            const V3 d = normalize(v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]));
+            HitRec h;
+            uint64_t steps = 0;
+            const bool hit = trace_closest(*P, o, d, t_max, 0.0f, h, steps);
+            hit_out[i] = hit ? 1 : 0;
+            t_out[i] = hit ? h.t : 0.0f;
+            if (normal_out_or_null) {
+                normal_out_or_null[3 * i] = hit ? h.n_world.x : 0.0f;
+                normal_out_or_null[3 * i + 1] = hit ? h.n_world.y : 0.0f;
+                normal_out_or_null[3 * i + 2] = hit ? h.n_world.z : 0.0f;
+            }
+        }
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int k = 0; k < threads; k++) th.emplace_back(work, k);
+        for (auto& t : th) t.join();
+    }
+    return 0;
+}
+
 void vrto_camera_ray(const vrt_scene* scene, int width, int height, int px, int py, float origin[3], float dir[3]) {
     Camera c = camera_basis(scene, width, height);
     V3 o, d;
@@ -1504,6 +1540,27 @@ int vrto_ref_hit_t(const vrto_volume* vol, const float origin[3], const float di
             }
         }
         t = t_out_cell;
+    }
+    return 0;
+}
+
+/* vrto_ref_hit_t for n object-space rays of one volume. */
+int vrto_ref_hit_batch(const vrto_volume* vol, int n, const float* origins, const float* dirs, uint8_t* hit_out, double* t_out, int threads) {
+    if (!vol || n < 0 || (n > 0 && (!origins || !dirs || !hit_out || !t_out))) return VRT_ERR_INVALID;
+    if (threads < 1) threads = 1;
+    auto work = [&](int k) {
+        for (int i = k; i < n; i += threads) {
+            double t = 0.0;
+            hit_out[i] = vrto_ref_hit_t(vol, origins + 3 * i, dirs + 3 * i, &t) ? 1 : 0;
+            t_out[i] = t;
+        }
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int k = 0; k < threads; k++) th.emplace_back(work, k);
+        for (auto& t : th) t.join();
     }
     return 0;
 }

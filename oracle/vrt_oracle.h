@@ -68,6 +68,11 @@ int vrto_trace(const vrt_scene* scene, const vrto_volume* volumes, const vrt_par
                const float origin[3], const float dir[3], float t_max,
                float* t_out, float normal_out[3], int* instance_out, int* steps_out);
 
+/* The same for n rays (origins, dirs: 3 floats each) with the scene set up once; hit_out[i] 0/1, t_out[i], normal_out (3n, may
+ * be NULL). */
+int vrto_trace_batch(const vrt_scene* scene, const vrto_volume* volumes, const vrt_params* params, int n, const float* origins,
+                     const float* dirs, float t_max, uint8_t* hit_out, float* t_out, float* normal_out_or_null, int threads);
+
 /* Camera ray of pixel (px,py): writes origin[3], dir[3] (normalised). */
 void vrto_camera_ray(const vrt_scene* scene, int width, int height, int px, int py,
                      float origin[3], float dir[3]);
@@ -81,6 +86,9 @@ float vrto_sample(const vrto_volume* vol, const float p[3]);
  * octree skip).  Double precision.  Returns 1 and the ray parameter of the first zero
  * crossing, or 0.  Used to check that the sphere-trace converges to the reference's surface. */
 int vrto_ref_hit_t(const vrto_volume* vol, const float origin[3], const float dir[3], double* t_out);
+
+/* The same for n rays. */
+int vrto_ref_hit_batch(const vrto_volume* vol, int n, const float* origins, const float* dirs, uint8_t* hit_out, double* t_out, int threads);
 
 /* Debug: the two-level empty-space table the march uses for `vol` under its metric (step_max > 0) — skip_out: nb^3
  * Chebyshev brick distances D, nib_out: nb^3 words of sub-block nibbles — and (field_out, N^3 floats) the field the march

@@ -921,8 +921,17 @@ def test_render_block_is_n_frames_in_flight_with_one_call(renderer, oracle_lib):
         after = block.clone()  # enqueued AFTER the block: must see every frame
     torch.cuda.synchronize()
     assert torch.equal(after, block) and float(block.max()) <= 1.0
-    hist = renderer.timing_history(n)
-    assert hist[0] > 0.0 and all(h == 0.0 for h in hist[1:])
+    # ONE launch covered the block's 11 frames (grid.y = frame) and was event-timed
+    assert [fr for _, fr in renderer.launch_history(1)] == [n] and renderer.launch_history(1)[0][0] > 0.0
+    # ... and with VRT_FLAG_BLOCK_PER_FRAME it is n launches of which only the first is timed: same pixels
+    pf = _abi.vrt_params.from_buffer_copy(p)
+    pf.flags |= _abi.FLAG_BLOCK_PER_FRAME
+    per_frame = torch.empty_like(block)
+    renderer.render_block(pf, n, per_frame.data_ptr(), H * W * 16, 0, cameras=cams)
+    torch.cuda.synchronize()
+    assert torch.equal(per_frame, block)
+    hist = renderer.launch_history(n)
+    assert hist[0][0] > 0.0 and all(h == 0.0 for h, _ in hist[1:]) and all(fr == 1 for _, fr in hist)
     alone = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
     for f in (0, 1, 5, n - 1):
         sf = copy.copy(sc)
@@ -976,6 +985,81 @@ def test_render_block_is_n_frames_in_flight_with_one_call(renderer, oracle_lib):
         assert lib.vrt_render_rows(renderer._ctx, C.byref(q2), 0, H, C.c_void_p(block.data_ptr()), None) == _abi.VRT_ERR_INVALID, field
     bad.n_frames, bad.frame_stride_bytes = 2, H * W * 16 - 16
     assert lib.vrt_render_block(renderer._ctx, C.byref(p), C.byref(bad), C.c_void_p(block.data_ptr()), None) == _abi.VRT_ERR_INVALID
+
+
+def _orbit(cam0, n):
+    cams = []
+    for f in range(n):
+        a = 0.05 * f
+        pos = (cam0.Position[0] * math.cos(a) - cam0.Position[1] * math.sin(a), cam0.Position[0] * math.sin(a) + cam0.Position[1] * math.cos(a),
+               cam0.Position[2] + 1.5 * f)
+        cams.append((pos, tuple(v.quat_mul(v.quat_from_axis_angle(v.UP, a), cam0.Rotation)), 60.0 - 0.25 * f))
+    return cams
+
+
+@pytest.mark.parametrize("case", ["lean", "bvh", "full", "lds", "cells16", "cube", "strips_rgba8"])
+def test_fused_block_launch_equals_per_frame_launches(renderer, oracle_lib, case):
+    """The march kernels' frame axis (vrt_render_block: ONE launch per 32 frames, blockIdx.y = frame, cameras in the kernarg)
+    on every kernel family: a block of MAX_BLOCK_FRAMES + 3 frames (two launches) is bit-equal to as many per-frame launches
+    (VRT_FLAG_BLOCK_PER_FRAME), frame by frame; the counters vrt_last_timing reports are those of the block's last frame
+    rendered alone; three of the frames against the oracle."""
+    import copy
+    import torch
+
+    M = _abi.MAX_BLOCK_FRAMES
+    n, W, H = M + 3, 136, 72
+    path, mode, strips, rgba8 = _abi.PATH_AUTO, _abi.MODE_INTERP_NOTEX, None, False
+    if case == "bvh":
+        sc = scenes.config5_instances(5, 32)
+    elif case == "full":
+        sc = scenes.config3_torus(6, 32)
+        sc.PointLights = [v.VPointLight(Position=(150.0, 40.0, 120.0), IlluminationStrength=400.0, Color=(1.0, 0.8, 0.6, 1.0),
+                                        AttenuationLinear=0.05, AttenuationExp=0.002)]
+    elif case == "cube":
+        sc = scenes.config3_torus(5, 32)
+        mode = _abi.MODE_CUBE_NOTEX
+    else:
+        sc = scenes.config3_voxelized(6, 16)
+        if case == "lds":
+            path = _abi.PATH_BRICK_LDS
+        if case == "cells16":
+            path = _abi.PATH_CELLS
+            for vol in sc.volumes():
+                vol.set_device_format(_abi.FORMAT_TEXEL16)
+        if case == "strips_rgba8":
+            strips, rgba8 = (8, 1, 3, 3), True  # rank 1 of 3: 72 rows = 9 strips of 8
+    p = v.default_params(W, H, scenes.min_cell(sc), 255, shadow=True, path=path)
+    p.mode = mode
+    if rgba8:
+        p.flags |= _abi.FLAG_OUTPUT_RGBA8
+    renderer.SetSceneToRender(sc)
+    renderer.ResizeRenderOutput(W, H)
+    renderer.SyncWithScene()
+    cams = _orbit(sc.Camera, n)
+    rows = strips[0] * strips[3] if strips else H
+    shape, dt, bpp = (n, rows, W, 4), (torch.uint8 if rgba8 else torch.float32), (4 if rgba8 else 16)
+    fused = torch.zeros(shape, dtype=dt, device="cuda:0")
+    single = torch.zeros(shape, dtype=dt, device="cuda:0")
+    kw = {"strips": strips} if strips else {"rows": (0, H)}
+    renderer.render_block(p, n, fused.data_ptr(), rows * W * bpp, 0, cameras=cams, **kw)
+    torch.cuda.synchronize()
+    t_fused = renderer.last_timing()
+    assert [fr for _, fr in renderer.launch_history(2)] == [M, 3]
+    pf = _abi.vrt_params.from_buffer_copy(p)
+    pf.flags |= _abi.FLAG_BLOCK_PER_FRAME
+    renderer.render_block(pf, n, single.data_ptr(), rows * W * bpp, 0, cameras=cams, **kw)
+    torch.cuda.synchronize()
+    t_single = renderer.last_timing()
+    for f in range(n):
+        assert torch.equal(fused[f], single[f]), (case, f)
+    assert not torch.equal(fused[0], fused[n - 1])
+    assert {k: t_fused[k] for k in STAT_KEYS} == {k: t_single[k] for k in STAT_KEYS} and t_fused["primary_rays"] == (rows if not strips else 24) * W
+    if not strips:
+        for f in (0, M - 1, n - 1):  # first launch's first and last frame, second launch's last
+            sf = copy.copy(sc)
+            sf.Camera = v.VCamera(Position=cams[f][0], Rotation=cams[f][1], FOVAngle=cams[f][2])
+            ref, _ = OracleScene(sf).render(p, threads=8)
+            assert np.abs(fused[f].cpu().numpy() - ref).max() <= TOL, (case, f)
 
 
 @pytest.mark.parametrize("seed", range(96))

@@ -41,6 +41,8 @@ MODE_CUBE_NOTEX_UNLIT = 7
 FLAG_DIAG_TIMELINE = 4
 FLAG_OUTPUT_RGBA8 = 8
 FLAG_NO_TIMING = 16
+FLAG_BLOCK_PER_FRAME = 64
+MAX_BLOCK_FRAMES = 48  # frames one march launch covers (csrc/vrt_device.h kMaxBlockFrames)
 
 FORMAT_F32 = 0
 FORMAT_TEXEL16 = 1
@@ -195,6 +197,7 @@ SYMBOLS = {
     "vrt_render_end": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "vrt_last_timing": (C.c_int, [C.c_void_p, C.POINTER(vrt_timing)]),
     "vrt_timing_history": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "vrt_launch_history": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "vrt_debug_wave_records": (C.c_longlong, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]),
     "vrt_strerror": (C.c_char_p, [C.c_int]),
     "vrt_version": (C.c_char_p, []),

@@ -142,12 +142,14 @@ struct DeviceState {
     std::vector<unsigned*> stats_retired;
     int last_slot = 0;
     unsigned* d_diag = nullptr;  /* allocated on first use of VRT_FLAG_DIAG_TIMELINE (never in a capture) */
-    int last_blocks = 0;
+    int last_blocks = 0;         /* workgroups per frame of the last launch */
+    int last_frames = 1;         /* frames of the last launch: vrt_last_timing / vrt_debug_wave_records read its LAST frame's records */
     bool last_diag = false;
     hipEvent_t ev0[kRing];
     hipEvent_t ev1[kRing];
     FrameSlot slot[VRT_FRAMES_IN_FLIGHT];
     bool events_ok = false;
+    int ring_frames[kRing] = {}; /* frames the launch in this ring slot covered (vrt_timing_history_frames) */
     bool timed[kRing] = {}; /* launch in this ring slot recorded its event pair (false: captured into a graph, or VRT_FLAG_NO_TIMING) */
 };
 
@@ -219,26 +221,33 @@ void quat_to_mat(const float q[4], float R[3][3]) {
 
 /* View basis of XMMatrixLookToRH(eye, forward, up) and the two projection scalars of
  * XMMatrixPerspectiveFovRH that survive GenerateCameraRay (RDXScene.cpp:703-724, Ray.hlsli:36-48). */
-void pack_camera(const vrt_scene& s, int width, int height, DFrame& F) {
+void pack_camera(const vrt_camera& s, int width, int height, DCam& F) {
     float R[3][3];
-    quat_to_mat(s.cam_rotation, R);
+    quat_to_mat(s.rotation, R);
     H3 fwd = h3(R[0][0], R[1][0], R[2][0]);
     H3 up = h3(R[0][2], R[1][2], R[2][2]);
     H3 r2 = hnormalize(h3(-fwd.x, -fwd.y, -fwd.z));
     H3 r0 = hnormalize(hcross(up, r2));
     H3 r1 = hcross(r2, r0);
-    F.cam_o[0] = s.cam_position[0];
-    F.cam_o[1] = s.cam_position[1];
-    F.cam_o[2] = s.cam_position[2];
+    F.cam_o[0] = s.position[0];
+    F.cam_o[1] = s.position[1];
+    F.cam_o[2] = s.position[2];
     F.r0[0] = r0.x; F.r0[1] = r0.y; F.r0[2] = r0.z;
     F.r1[0] = r1.x; F.r1[1] = r1.y; F.r1[2] = r1.z;
     F.r2[0] = r2.x; F.r2[1] = r2.y; F.r2[2] = r2.z;
     float aspect = (float)width / (float)height; /* DXRenderer.cpp:47 */
-    float half = tanf(s.cam_fov_deg * (3.14159265358979323846f / 180.0f) * 0.5f);
+    float half = tanf(s.fov_deg * (3.14159265358979323846f / 180.0f) * 0.5f);
     F.cx = aspect * half;
     F.cy = half;
-    F.inv_w = 1.0f / (float)width;
-    F.inv_h = 1.0f / (float)height;
+}
+
+/* The scene's own camera as a vrt_camera. */
+vrt_camera scene_camera(const vrt_scene& s) {
+    vrt_camera c;
+    for (int a = 0; a < 3; a++) c.position[a] = s.cam_position[a];
+    for (int a = 0; a < 4; a++) c.rotation[a] = s.cam_rotation[a];
+    c.fov_deg = s.cam_fov_deg;
+    return c;
 }
 
 /* object→world = S·R (+T), world→object = R^T·S^-1 (RDXLevelObject.cpp:38-47). */
@@ -666,7 +675,9 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
         return VRT_ERR_INVALID;
     if (p->mode < VRT_MODE_INTERP || p->mode > VRT_MODE_CUBE_NOTEX_UNLIT) return VRT_ERR_INVALID;
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_CELLS) return VRT_ERR_INVALID;
-    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_NO_TIMING)) != 0 || (p->flags & 3) == 3) return VRT_ERR_INVALID;
+    /* (bit 5 was round 1's VRT_FLAG_SKIP_EMPTY: empty-space skipping is always on now; the bit is accepted and ignored) */
+    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_NO_TIMING | 32 | VRT_FLAG_BLOCK_PER_FRAME)) != 0 || (p->flags & 3) == 3)
+        return VRT_ERR_INVALID;
     if (!ctx->have_scene) return VRT_ERR_NOT_READY;
     return VRT_OK;
 }
@@ -699,11 +710,10 @@ struct RowSet {
 /* Screen rectangle of everything a primary ray can reach (DFrame::cull_*): the corners of every instance's active box
    (object space -> world -> camera -> pixel), double precision, two pixels of margin.  Any corner at or behind the camera
    plane: the whole frame. */
-void cull_rect(const vrt_ctx* ctx, const vrt_params* p, DFrame& F) {
-    F.cull_x0 = 0;
-    F.cull_y0 = 0;
-    F.cull_x1 = p->width - 1;
-    F.cull_y1 = p->height - 1;
+void cull_rect(const vrt_ctx* ctx, const vrt_params* p, DCam& F) {
+    /* (frames are at most 16384 pixels wide and high: 16 bits per coordinate) */
+    F.cull_lo = pack_cull(0, 0);
+    F.cull_hi = pack_cull(p->width - 1, p->height - 1);
     double x0 = 1e30, y0 = 1e30, x1 = -1e30, y1 = -1e30;
     for (int i = 0; i < ctx->scene.n_instances; i++) {
         const HostVolume& h = ctx->vol[ctx->scene.instances[i].volume_slot];
@@ -738,23 +748,27 @@ void cull_rect(const vrt_ctx* ctx, const vrt_params* p, DFrame& F) {
             y1 = std::max(y1, py);
         }
     }
-    if (x1 < x0) { /* no instance can be hit: an empty rectangle */
-        F.cull_x0 = F.cull_y0 = 1;
-        F.cull_x1 = F.cull_y1 = 0;
+    const double m = 2.0;
+    const int cx0 = (int)std::max(0.0, std::min((double)p->width, floor(x0 - m)));
+    const int cy0 = (int)std::max(0.0, std::min((double)p->height, floor(y0 - m)));
+    const int cx1 = (int)std::max(-1.0, std::min((double)p->width - 1.0, ceil(x1 + m)));
+    const int cy1 = (int)std::max(-1.0, std::min((double)p->height - 1.0, ceil(y1 + m)));
+    if (x1 < x0 || cx1 < cx0 || cy1 < cy0) { /* no instance can be hit, or everything projects off the screen: an empty rectangle */
+        F.cull_lo = pack_cull(1, 1);
+        F.cull_hi = pack_cull(0, 0);
         return;
     }
-    const double m = 2.0;
-    F.cull_x0 = (int)std::max(0.0, std::min((double)p->width, floor(x0 - m)));
-    F.cull_y0 = (int)std::max(0.0, std::min((double)p->height, floor(y0 - m)));
-    F.cull_x1 = (int)std::max(-1.0, std::min((double)p->width - 1.0, ceil(x1 + m)));
-    F.cull_y1 = (int)std::max(-1.0, std::min((double)p->height - 1.0, ceil(y1 + m)));
+    F.cull_lo = pack_cull(cx0, cy0);
+    F.cull_hi = pack_cull(cx1, cy1);
 }
 
 void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, const RowSet& rs, float* out,
                  unsigned* stats, DFrame& F, const SceneArrays* snapshot = nullptr) {
     const int row0 = rs.row0, rows = rs.rows;
     memset(&F, 0, sizeof F);
-    pack_camera(ctx->scene, p->width, p->height, F);
+    F.inv_w = 1.0f / (float)p->width;
+    F.inv_h = 1.0f / (float)p->height;
+    F.n_frames = 1;
     F.light_dir[0] = ctx->scene.light_dir[0];
     F.light_dir[1] = ctx->scene.light_dir[1];
     F.light_dir[2] = ctx->scene.light_dir[2];
@@ -815,19 +829,32 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.out = out;
     F.stats = stats;
     F.vol0 = ctx->scene.n_instances == 1 ? F.vols + ctx->scene.instances[0].volume_slot : nullptr;
-    cull_rect(ctx, p, F);
 }
 
-/* Enqueue one tile on one device.  No allocation, no host sync. */
+/* Enqueue n_frames frames of one tile on one device as ONE launch (grid.y = frame): frame f from cams[f] (null: the scene's own
+   camera) into out + f * frame_stride bytes.  No allocation after the stream's first launch of that size, no host sync. */
 int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet& rs, float* out, hipStream_t stream,
-                 int ring, const SceneArrays* snapshot = nullptr) {
-    DFrame F;
+                 int ring, const SceneArrays* snapshot = nullptr, int n_frames = 1, const vrt_camera* cams = nullptr, size_t frame_stride = 0) {
+    if (n_frames < 1 || n_frames > kMaxBlockFrames) return VRT_ERR_INVALID;
+    DBlock B;
+    DFrame& F = B.f;
     build_frame(ctx, D, p, rs, out, nullptr, F, snapshot);
     if ((long long)F.tiles_x * F.tiles_y > kMaxBlocks / 2) return VRT_ERR_INVALID;
     const bool single = ctx->scene.n_instances == 1;
     const int path = resolve_path(ctx, p->path, single, p->mode);
     if (path < 0) return path;
     D.last_blocks = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
+    if ((long long)D.last_blocks * n_frames > 8LL * kMaxBlocks) return VRT_ERR_INVALID;
+    D.last_frames = n_frames;
+    F.n_frames = n_frames;
+    F.frame_stride = frame_stride;
+    F.stats_stride = (uint32_t)((size_t)D.last_blocks * 4 * kStatRecord);
+    const vrt_camera own = scene_camera(ctx->scene);
+    for (int f = 0; f < n_frames; f++) {
+        pack_camera(cams ? cams[f] : own, p->width, p->height, B.cam[f]);
+        cull_rect(ctx, p, B.cam[f]);
+    }
+    const size_t stat_blocks = (size_t)D.last_blocks * (size_t)n_frames; /* one record set per (frame, wave) */
     int slot = -1;
     for (int i = 0; i < kStatSlots; i++)
         if (D.stats_bound[i] && D.stats_stream[i] == stream) slot = i;
@@ -842,17 +869,18 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
         D.stats_stream[slot] = stream;
     }
     D.stats_used[slot] = ctx->launches;
-    if (D.stats_cap[slot] < (size_t)D.last_blocks) { /* first launch of this size on this stream: the only allocation on this path */
+    if (D.stats_cap[slot] < stat_blocks) { /* first launch of this size on this stream: the only allocation on this path */
         unsigned* grown = nullptr;
-        HIP_TRY(hipMalloc(&grown, sizeof(unsigned) * kStatRecord * 4 * (size_t)D.last_blocks));
+        HIP_TRY(hipMalloc(&grown, sizeof(unsigned) * kStatRecord * 4 * stat_blocks));
         if (D.d_stats[slot]) D.stats_retired.push_back(D.d_stats[slot]); /* a captured graph may still write to it */
         D.d_stats[slot] = grown;
-        D.stats_cap[slot] = (size_t)D.last_blocks;
+        D.stats_cap[slot] = stat_blocks;
     }
     D.last_slot = slot;
     F.stats = D.d_stats[slot];
     D.last_diag = F.diag != 0;
     if (F.diag) {
+        if (stat_blocks > (size_t)kMaxBlocks) return VRT_ERR_INVALID; /* the timeline buffer holds kMaxBlocks workgroups */
         if (!D.d_diag) HIP_TRY(hipMalloc(&D.d_diag, sizeof(unsigned) * kDiagRecord * 4 * (size_t)kMaxBlocks));
         F.diag_buf = D.d_diag;
     }
@@ -861,8 +889,9 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (stream != nullptr && hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
     D.timed[ring] = cap == hipStreamCaptureStatusNone && !(p->flags & VRT_FLAG_NO_TIMING);
+    D.ring_frames[ring] = n_frames;
     if (D.timed[ring]) HIP_TRY(hipEventRecord(D.ev0[ring], stream));
-    HIP_TRY(launch_march(F, path, single, stream));
+    HIP_TRY(launch_march(B, path, single, stream));
     if (D.timed[ring]) HIP_TRY(hipEventRecord(D.ev1[ring], stream));
     return VRT_OK;
 }
@@ -1194,24 +1223,21 @@ int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* bl
     DeviceState& D = ctx->dev[0];
     HIP_TRY(hipSetDevice(D.ordinal));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    const vrt_scene saved = ctx->scene;
+    /* ONE launch per kMaxBlockFrames frames (grid.y = frame; only the camera differs between the frames, it travels in the
+       kernarg): the dispatcher back-fills the wave slots a frame's latency-bound tail leaves empty with the next frame's waves.
+       VRT_FLAG_BLOCK_PER_FRAME: one launch per frame, back to back (what this entry point did before; A/B and tests) */
+    const int chunk = (params->flags & VRT_FLAG_BLOCK_PER_FRAME) ? 1 : kMaxBlockFrames;
     vrt_params q = *params;
-    for (int f = 0; f < block->n_frames; f++) {
-        if (block->cameras) { /* only the camera differs between the frames: the packed scene arrays stay as they are */
-            const vrt_camera& c = block->cameras[f];
-            for (int a = 0; a < 3; a++) ctx->scene.cam_position[a] = c.position[a];
-            for (int a = 0; a < 4; a++) ctx->scene.cam_rotation[a] = c.rotation[a];
-            ctx->scene.cam_fov_deg = c.fov_deg;
-        }
-        q.flags = f == 0 ? params->flags : (params->flags | VRT_FLAG_NO_TIMING); /* the block's first frame is its timing sample */
+    for (int f = 0; f < block->n_frames; f += chunk) {
+        const int n = std::min(chunk, block->n_frames - f);
+        /* per-frame launches: the block's first frame is its timing sample (an event pair costs 5-7 us of queue time) */
+        q.flags = (f == 0 || chunk > 1) ? params->flags : (params->flags | VRT_FLAG_NO_TIMING);
         const int ring = (int)(ctx->launches % kRing);
         rc = enqueue_rows(ctx, D, &q, rs, reinterpret_cast<float*>(static_cast<char*>(device_rgba) + (size_t)f * block->frame_stride_bytes), stream,
-                          ring);
-        if (rc != VRT_OK) break;
+                          ring, nullptr, n, block->cameras ? block->cameras + f : nullptr, (size_t)block->frame_stride_bytes);
+        if (rc != VRT_OK) return rc;
         ctx->launches++;
     }
-    ctx->scene = saved;
-    if (rc != VRT_OK) return rc;
     ctx->last_devices = 1;
     ctx->last_w = (uint32_t)params->width;
     ctx->last_h = (uint32_t)rs.rows;
@@ -1467,7 +1493,8 @@ int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out) {
         kernel_ms = std::max(kernel_ms, ms);
         std::vector<unsigned> rec((size_t)D.last_blocks * 4 * kStatRecord);
         if (D.last_blocks > 0)
-            HIP_TRY(hipMemcpy(rec.data(), D.d_stats[D.last_slot], rec.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(rec.data(), D.d_stats[D.last_slot] + (size_t)(D.last_frames - 1) * rec.size(), rec.size() * sizeof(unsigned),
+                              hipMemcpyDeviceToHost));
         for (size_t w = 0; w < (size_t)D.last_blocks * 4; w++)
             for (int k = 0; k < kStatWords; k++) tot[k] += rec[w * kStatRecord + k];
     }
@@ -1505,6 +1532,15 @@ int vrt_timing_history(vrt_ctx* ctx, int n, float* kernel_ms_out) {
     return m;
 }
 
+int vrt_launch_history(vrt_ctx* ctx, int n, float* kernel_ms_out, int* frames_out) {
+    if (!ctx || n < 0 || (n > 0 && (!kernel_ms_out || !frames_out))) return VRT_ERR_INVALID;
+    const int m = vrt_timing_history(ctx, n, kernel_ms_out);
+    if (m < 0) return m;
+    const DeviceState& D = ctx->dev[0];
+    for (int i = 0; i < m; i++) frames_out[i] = D.ring_frames[(int)((ctx->launches - (uint64_t)m + (uint64_t)i) % kRing)];
+    return m;
+}
+
 long long vrt_debug_wave_records(vrt_ctx* ctx, int which, uint32_t* out, long long max_words) {
     if (!ctx || max_words < 0 || (max_words > 0 && !out) || which < 0 || which > 1) return VRT_ERR_INVALID;
     if (ctx->launches == 0) return VRT_ERR_NOT_READY;
@@ -1514,8 +1550,8 @@ long long vrt_debug_wave_records(vrt_ctx* ctx, int which, uint32_t* out, long lo
     if (out && max_words > 0) {
         HIP_TRY(hipSetDevice(D.ordinal));
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(out, which == 0 ? D.d_stats[D.last_slot] : D.d_diag, sizeof(uint32_t) * (size_t)std::min(words, max_words),
-                          hipMemcpyDeviceToHost));
+        const uint32_t* src = (which == 0 ? D.d_stats[D.last_slot] : D.d_diag) + (size_t)(D.last_frames - 1) * (size_t)words;
+        HIP_TRY(hipMemcpy(out, src, sizeof(uint32_t) * (size_t)std::min(words, max_words), hipMemcpyDeviceToHost));
     }
     return words;
 }

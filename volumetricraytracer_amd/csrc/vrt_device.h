@@ -25,7 +25,11 @@ constexpr int kMaxBvhNodes = 2 * 64 - 1;
 constexpr int kStatWords = 7;
 constexpr int kStatRecord = 8;                 /* words per wave record (32 B) */
 constexpr int kDiagRecord = 8;                 /* words per wave in the diagnostic timeline buffer */
-constexpr int kMaxBlocks = 1 << 20;            /* 16x16-pixel workgroups per launch (e.g. 16384 x 16384) */
+constexpr int kMaxBlocks = 1 << 20;            /* 16x16-pixel workgroups per frame of a launch (e.g. 16384 x 16384) */
+#ifndef VRT_MAX_BLOCK_FRAMES
+#define VRT_MAX_BLOCK_FRAMES 48
+#endif
+constexpr int kMaxBlockFrames = VRT_MAX_BLOCK_FRAMES;            /* frames ONE march launch covers (grid.y): their cameras travel in the kernarg segment */
 
 /* blockIdx → tile maps of the march kernel (vrt_params.flags bits 0-1; speed only). */
 constexpr int kMapSupertile = 0;
@@ -120,12 +124,22 @@ struct DSpotLight {
     float pad_[2];
 };
 
-/* Everything a launch needs; passed by value (kernarg segment → scalar loads). */
-struct DFrame {
-    /* camera */
+/* What differs between the frames of one launch (blockIdx.y = frame): the camera and the screen rectangle its rays can
+ * reach anything in.  64 bytes: one s_load_dwordx16 at kernarg + frame * 64. */
+struct DCam {
     float cam_o[3];
     float r0[3], r1[3], r2[3];
     float cx, cy;
+    /* Primary rays outside this pixel rectangle (inclusive; x | y << 16) cannot reach any instance: it bounds the projection of
+       every instance's active box (its whole box for volumes without an empty-space table), two pixels of margin included; the
+       whole frame when a box reaches behind the camera; lo = (1,1), hi = (0,0) when nothing can be hit.  A wave whose pixels
+       all lie outside goes straight to the sky */
+    uint32_t cull_lo, cull_hi;
+};
+inline uint32_t pack_cull(int x, int y) { return (uint32_t)x | ((uint32_t)y << 16); }
+
+/* Everything the frames of a launch share; passed by value (kernarg segment → scalar loads). */
+struct DFrame {
     float inv_w, inv_h; /* 1 / width, 1 / height */
     /* directional light */
     float light_dir[3];
@@ -161,18 +175,27 @@ struct DFrame {
     const uint8_t* env;        /* 6 x S x S RGBA8 or null */
     int32_t env_size;
     int32_t pad_;
-    float* out;                /* rows x width float4 (or uint32 R8G8B8A8 when rgba8) */
+    float* out;                /* frame 0: rows x width float4 (or uint32 R8G8B8A8 when rgba8); frame f at out + f * frame_stride bytes */
     unsigned* stats;           /* one 8-word record per wave (4 per workgroup): primary_rays, shadow_rays,
-                                  bounce_rays, primary_steps, shadow_steps, hits, exhausted_rays, 0 */
+                                  bounce_rays, primary_steps, shadow_steps, hits, exhausted_rays, 0; frame f at stats + f * stats_stride words */
     unsigned* diag_buf;        /* diagnostic build only: 8 words per wave {start, end (100 MHz), fast fetches, xcc|hw_id,
-                                  longest sample chain, load+lerp cycles, loop cycles, loop iterations} */
-    /* Primary rays outside this pixel rectangle (inclusive) cannot reach any instance: it bounds the projection of every
-       instance's active box (its whole box for volumes without an empty-space table), two pixels of margin included; the
-       whole frame when a box reaches behind the camera.  A wave whose pixels all lie outside goes straight to the sky */
-    int32_t cull_x0, cull_y0, cull_x1, cull_y1;
+                                  longest sample chain, load+lerp cycles, loop cycles, loop iterations}, frames like stats */
+    uint64_t frame_stride;     /* bytes between the frames of a launch in `out` */
+    uint32_t stats_stride;     /* words between the frames of a launch in `stats` (and diag_buf) */
+    int32_t n_frames;          /* = gridDim.y, 1 .. kMaxBlockFrames */
     const DVolume* vol0;       /* single-instance scenes: vols + inst[0].slot, resolved on the host so that a wave loads its instance
                                   and its volume record side by side instead of one after the other (four out of five waves of
                                   a frame only need them to find out that their rays miss) */
 };
+
+/* The kernarg of a march launch: the shared part and one DCam per frame of the block.  The dispatcher walks blockIdx.x
+ * first, so frame f + 1's waves back-fill the wave slots frame f's latency-bound tail leaves empty — what the reference gets from
+ * three back buffers in flight (DXConstants.cpp:23, DXRenderer.cpp:974-989), inside ONE launch. */
+struct DBlock {
+    DFrame f;
+    DCam cam[kMaxBlockFrames];
+};
+static_assert(sizeof(DCam) == 64, "DCam is one s_load_dwordx16");
+static_assert(sizeof(DBlock) <= 4096, "HIP kernarg segment limit");
 
 }  // namespace vrt

@@ -1003,20 +1003,36 @@ __device__ __forceinline__ void block_and_wave(int& b, int& wave) {
 /* False for a whole wave when none of its pixels lies inside the frame's cull rectangle (DFrame::cull_*): its primary rays
  * cannot reach any instance, so the scene is never looked at — no instance / volume record loaded, no slab test.  Four out
  * of five waves of the benchmark frame.  Wave-uniform on purpose: a wave that straddles the rectangle marches all its rays. */
-__device__ __forceinline__ bool wave_can_reach(const DFrame& F, bool valid, int px, int py) {
-    const bool inside = px >= F.cull_x0 && px <= F.cull_x1 && py >= F.cull_y0 && py <= F.cull_y1;
+__device__ __forceinline__ bool wave_can_reach(const DCam& C, bool valid, int px, int py) {
+    const int x0 = (int)(C.cull_lo & 0xffffu), y0 = (int)(C.cull_lo >> 16), x1 = (int)(C.cull_hi & 0xffffu), y1 = (int)(C.cull_hi >> 16);
+    const bool inside = px >= x0 && px <= x1 && py >= y0 && py <= y1;
     return __ballot(valid && inside) != 0ull;
 }
 
+/* The frame of the launch this workgroup belongs to (blockIdx.y) and its camera record: one scalar load of 64 bytes from the
+ * kernarg segment at a wave-uniform offset. */
+__device__ __forceinline__ DCam load_cam(const DBlock& B, int frame) {
+    typedef unsigned u16v __attribute__((ext_vector_type(16)));
+    const u16v w = *reinterpret_cast<const u16v*>(&B.cam[frame]);
+    DCam C;
+    C.cam_o[0] = __uint_as_float(w[0]); C.cam_o[1] = __uint_as_float(w[1]); C.cam_o[2] = __uint_as_float(w[2]);
+    C.r0[0] = __uint_as_float(w[3]); C.r0[1] = __uint_as_float(w[4]); C.r0[2] = __uint_as_float(w[5]);
+    C.r1[0] = __uint_as_float(w[6]); C.r1[1] = __uint_as_float(w[7]); C.r1[2] = __uint_as_float(w[8]);
+    C.r2[0] = __uint_as_float(w[9]); C.r2[1] = __uint_as_float(w[10]); C.r2[2] = __uint_as_float(w[11]);
+    C.cx = __uint_as_float(w[12]); C.cy = __uint_as_float(w[13]);
+    C.cull_lo = w[14]; C.cull_hi = w[15];
+    return C;
+}
+
 /* Camera ray of pixel (px,py) (Ray.hlsli:36-48, then normalised). */
-__device__ __forceinline__ void camera_ray(const DFrame& F, int px, int py, F3& o, F3& d) {
+__device__ __forceinline__ void camera_ray(const DFrame& F, const DCam& C, int px, int py, F3& o, F3& d) {
     float sx = (((float)px + 0.5f) * F.inv_w) * 2.0f - 1.0f; /* 1/width, 1/height from the host (oracle: the same two products) */
     float sy = (((float)py + 0.5f) * F.inv_h) * 2.0f - 1.0f;
-    float tx = sx * F.cx;
-    float ty = (-sy) * F.cy;
-    d = normalize3(f3((tx * F.r0[0] + ty * F.r1[0]) - F.r2[0], (tx * F.r0[1] + ty * F.r1[1]) - F.r2[1],
-                      (tx * F.r0[2] + ty * F.r1[2]) - F.r2[2]));
-    o = f3(F.cam_o[0], F.cam_o[1], F.cam_o[2]);
+    float tx = sx * C.cx;
+    float ty = (-sy) * C.cy;
+    d = normalize3(f3((tx * C.r0[0] + ty * C.r1[0]) - C.r2[0], (tx * C.r0[1] + ty * C.r1[1]) - C.r2[1],
+                      (tx * C.r0[2] + ty * C.r1[2]) - C.r2[2]));
+    o = f3(C.cam_o[0], C.cam_o[1], C.cam_o[2]);
 }
 
 struct Counters {
@@ -1032,8 +1048,9 @@ struct Counters {
 /* UNIT: every ray / hit counter of a lane is 0 or 1 (the lean kernels): one ballot + popcount each on the scalar unit instead of
    a 12-instruction shuffle reduction. */
 template <bool DIAG, bool UNIT = false>
-__device__ __forceinline__ void write_records(const DFrame& F, int b, int wave, int lane, Counters k, const DiagAcc& dg,
+__device__ __forceinline__ void write_records(const DFrame& F, int frame, int b, int wave, int lane, Counters k, const DiagAcc& dg,
                                               unsigned long long t_start) {
+    const size_t frame_words = (size_t)(unsigned)frame * F.stats_stride; /* this frame's records within the launch's buffers */
     const unsigned ex_lane = (k.s_primary >> kExhaustedShift) + (k.s_shadow >> kExhaustedShift);
     const unsigned exhausted = __ballot(ex_lane != 0u) == 0ull ? 0u : wave_sum(ex_lane); /* practically never set */
     k.s_primary &= kExhaustedOne - 1u;
@@ -1057,7 +1074,7 @@ __device__ __forceinline__ void write_records(const DFrame& F, int b, int wave, 
     if (F.stats != nullptr && lane < 8) {
         unsigned v = lane == 0 ? k.n_primary : lane == 1 ? k.n_shadow : lane == 2 ? k.n_bounce : lane == 3 ? k.s_primary
                    : lane == 4 ? k.s_shadow : lane == 5 ? k.n_hits : lane == 6 ? exhausted : 0u;
-        F.stats[((size_t)b * 4 + wave) * kStatRecord + lane] = v;
+        F.stats[frame_words + ((size_t)b * 4 + wave) * kStatRecord + lane] = v;
     }
     if constexpr (DIAG) {
         /* diagnostic timeline record: where and when this wave ran and where its march cycles went
@@ -1094,7 +1111,7 @@ __device__ __forceinline__ void write_records(const DFrame& F, int b, int wave, 
                 case 7: v = d_iters; break;
                 default: break;
             }
-            F.diag_buf[((size_t)b * 4 + wave) * kDiagRecord + lane] = v;
+            F.diag_buf[frame_words + ((size_t)b * 4 + wave) * kDiagRecord + lane] = v;
         }
     }
 }
@@ -1126,17 +1143,24 @@ __device__ __forceinline__ unsigned unorm8(float c) {
     return (unsigned)(fminf(c, 1.0f) * 255.0f + 0.5f);
 }
 
-__device__ __forceinline__ void store_pixel(const DFrame& F, int px, int pyl, F3 color) {
+__device__ __forceinline__ void store_pixel(const DFrame& F, int frame, unsigned pix /* pyl * width + px */, F3 color) {
+    char* const out = reinterpret_cast<char*>(F.out) + (size_t)(unsigned)frame * F.frame_stride;
     const float r = tonemap(color.x), g = tonemap(color.y), b = tonemap(color.z);
     /* streaming stores: a frame writes as many bytes as an XCD's whole L2 holds; they must not push the bricks out */
     if (F.rgba8) {
         __builtin_nontemporal_store(unorm8(r) | unorm8(g) << 8 | unorm8(b) << 16 | 0xff000000u,
-                                    reinterpret_cast<unsigned*>(F.out) + ((size_t)pyl * F.width + px));
+                                    reinterpret_cast<unsigned*>(out) + pix);
     } else {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4 v = {r, g, b, 1.0f};
-        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(F.out) + ((size_t)pyl * F.width + px));
+        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out) + pix);
     }
+}
+
+/* The lane's index in its wave from the execution-mask counters (v_mbcnt), for code behind the march that would otherwise keep
+ * threadIdx.x alive across it. */
+__device__ __forceinline__ unsigned late_lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
 /* Frame row of local row pyl of this launch's tile (contiguous rows, or interleaved strips). */
@@ -1149,9 +1173,12 @@ __device__ __forceinline__ int frame_row(const DFrame& F, int pyl) {
 }
 
 template <int PATH, bool SINGLE, bool DIAG>
-__global__ __launch_bounds__(kMarchThreads) void march_kernel(const DFrame F) {
+__global__ __launch_bounds__(kMarchThreads) void march_kernel(const DBlock B) {
     unsigned long long t_start = 0;
     if constexpr (DIAG) t_start = __builtin_amdgcn_s_memrealtime(); /* 100 MHz; diagnostic build only */
+    const DFrame& F = B.f;
+    const int frame = (int)blockIdx.y;
+    const DCam C = load_cam(B, frame);
     int b, wave;
     block_and_wave(b, wave);
     int tile_x, tile_y;
@@ -1164,11 +1191,11 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel(const DFrame F) {
 
     Counters k;
     DiagAcc dg;
-    const bool reach = wave_can_reach(F, valid, px, py);
+    const bool reach = wave_can_reach(C, valid, px, py);
 
     if (valid) {
         F3 o, d;
-        camera_ray(F, px, py, o, d);
+        camera_ray(F, C, px, py, o, d);
         k.n_primary = 1;
         float t_hit = 0.0f;
         int inst = 0;
@@ -1192,9 +1219,24 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel(const DFrame F) {
         } else {
             color = env_decode(sky);
         }
-        store_pixel(F, px, pyl, color);
+        /* VRT_AB_LATE_PIX (A/B build): the pixel's offset derived again from the lane id (mbcnt) and the wave-uniform tile origin, so
+           that no register holds the pixel coordinates or threadIdx across the march: 60 instead of 64 VGPRs — and 5 % SLOWER: with
+           the tighter allocation the table-word loads of the march loop reuse their own address register and wait for vmcnt(0)
+           (profiles/r03_ab_fused_variants.txt) */
+#ifdef VRT_AB_LATE_PIX
+        const unsigned lane_late = late_lane_id();
+#else
+        const unsigned lane_late = (unsigned)lane;
+#endif
+        const unsigned pix = ((unsigned)(tile_y * 16 + (wave >> 1) * 8) + (lane_late >> 3)) * (unsigned)F.width +
+                             ((unsigned)(tile_x * 16 + (wave & 1) * 8) + (lane_late & 7u));
+        store_pixel(F, frame, pix, color);
     }
-    write_records<DIAG, true>(F, b, wave, lane, k, dg, t_start);
+#ifdef VRT_AB_LATE_PIX
+    write_records<DIAG, true>(F, frame, b, wave, (int)late_lane_id(), k, dg, t_start);
+#else
+    write_records<DIAG, true>(F, frame, b, wave, lane, k, dg, t_start);
+#endif
 }
 
 /* ---- tri-planar material textures (SH/Include/Textures.hlsli:16-59, Quaternion.hlsli:18-82) ----------
@@ -1295,7 +1337,10 @@ __device__ __forceinline__ void textured_surface(const DVolume* __restrict__ V, 
 constexpr int kMaxDepth = 3;
 
 template <int PATH, bool SINGLE>
-__global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DFrame F) {
+__global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DBlock B) {
+    const DFrame& F = B.f;
+    const int frame = (int)blockIdx.y;
+    const DCam C = load_cam(B, frame);
     int b, wave;
     block_and_wave(b, wave);
     int tile_x, tile_y;
@@ -1308,10 +1353,10 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DFrame 
 
     Counters k;
     DiagAcc dg;
-    const bool reach = wave_can_reach(F, valid, px, py);
+    const bool reach = wave_can_reach(C, valid, px, py);
     if (valid) {
         F3 o, d;
-        camera_ray(F, px, py, o, d);
+        camera_ray(F, C, px, py, o, d);
         k.n_primary = 1;
         F3 direct[kMaxDepth - 1], brdf[kMaxDepth - 1];
         float ndwi[kMaxDepth - 1], fade[kMaxDepth - 1];
@@ -1420,9 +1465,9 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DFrame 
             const F3 r = f3((brdf[j].x * rc.x) * ndwi[j], (brdf[j].y * rc.y) * ndwi[j], (brdf[j].z * rc.z) * ndwi[j]);
             color = direct[j] + r;
         }
-        store_pixel(F, px, pyl, color);
+        store_pixel(F, frame, (unsigned)pyl * (unsigned)F.width + (unsigned)px, color);
     }
-    write_records<false>(F, b, wave, lane, k, dg, 0ull);
+    write_records<false>(F, frame, b, wave, lane, k, dg, 0ull);
 }
 
 /* ---- hybrid march: per-lane head, wave-cooperative LDS tail ----------------------------------- */
@@ -1592,11 +1637,14 @@ __device__ __forceinline__ bool march_hybrid(const DFrame& F, const VolRef& V, c
  * brick fills of the LDS phase.
  */
 template <bool DIAG>
-__global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame F) {
+__global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DBlock B) {
     __shared__ float s_slots[4][kLdsSlots * kBrickFloats];
     __shared__ unsigned s_tags[4][kLdsSlots];
     unsigned long long t_start = 0;
     if constexpr (DIAG) t_start = __builtin_amdgcn_s_memrealtime();
+    const DFrame& F = B.f;
+    const int frame = (int)blockIdx.y;
+    const DCam C = load_cam(B, frame);
     const int b = (int)blockIdx.x;
     int tile_x, tile_y;
     tile_of_block(F, b, (int)gridDim.x, tile_x, tile_y);
@@ -1622,9 +1670,9 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame 
     F3 o = f3(0.0f, 0.0f, 0.0f), d = f3(1.0f, 0.0f, 0.0f);
     RaySeg R = {};
     bool act = false;
-    const bool reach = wave_can_reach(F, valid, px, py);
+    const bool reach = wave_can_reach(C, valid, px, py);
     if (valid) {
-        camera_ray(F, px, py, o, d);
+        camera_ray(F, C, px, py, o, d);
         k.n_primary = 1;
         if (reach) act = setup_ray(F, I, V, o, d, 10000.0f, 0.0f, R);
     }
@@ -1655,9 +1703,9 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DFrame 
     }
     if (valid) {
         F3 color = hit ? shade_hit(F, Vd, d, n, shadowed) : env_lookup(F.env, F.env_size, d);
-        store_pixel(F, px, pyl, color);
+        store_pixel(F, frame, (unsigned)pyl * (unsigned)F.width + (unsigned)px, color);
     }
-    write_records<DIAG, true>(F, b, wave, lane, k, dg, t_start);
+    write_records<DIAG, true>(F, frame, b, wave, lane, k, dg, t_start);
 }
 
 /* dense N^3 grid → 4^3-cell bricks with a one-sample apron (5^3 samples, padded to 128 floats). */
@@ -1964,66 +2012,73 @@ __global__ void split_voxels_kernel(const uint2* __restrict__ voxels, float* __r
 /* ---- launch wrappers (host) -------------------------------------------------------------- */
 
 template <int PATH, bool SINGLE>
-static hipError_t launch_t(const DFrame& F, hipStream_t stream) {
+static hipError_t launch_t(const DBlock& B, hipStream_t stream) {
+    const DFrame& F = B.f;
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
     if (F.diag)
-        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, true>), dim3((unsigned)(grid * kMarchGridMul)), dim3(kMarchThreads), 0, stream, F);
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, true>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), 0, stream, B);
     else
-        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul)), dim3(kMarchThreads), 0, stream, F);
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), 0, stream, B);
     return hipGetLastError();
 }
 
 /* Paths without a diagnostic instantiation. */
 template <int PATH, bool SINGLE>
-static hipError_t launch_nodiag_t(const DFrame& F, hipStream_t stream) {
+static hipError_t launch_nodiag_t(const DBlock& B, hipStream_t stream) {
+    const DFrame& F = B.f;
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul)), dim3(kMarchThreads), 0, stream, F);
+    hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), 0, stream, B);
     return hipGetLastError();
 }
 
-static hipError_t launch_coop(const DFrame& F, hipStream_t stream) {
+static hipError_t launch_coop(const DBlock& B, hipStream_t stream) {
+    const DFrame& F = B.f;
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
     if (F.diag)
-        hipLaunchKernelGGL((march_kernel_coop<true>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
+        hipLaunchKernelGGL((march_kernel_coop<true>), dim3((unsigned)grid, (unsigned)F.n_frames), dim3(kBlockThreads), 0, stream, B);
     else
-        hipLaunchKernelGGL((march_kernel_coop<false>), dim3((unsigned)grid), dim3(kBlockThreads), 0, stream, F);
+        hipLaunchKernelGGL((march_kernel_coop<false>), dim3((unsigned)grid, (unsigned)F.n_frames), dim3(kBlockThreads), 0, stream, B);
     return hipGetLastError();
 }
 
 template <int PATH, bool SINGLE>
-static hipError_t launch_full_t(const DFrame& F, hipStream_t stream) {
+static hipError_t launch_full_t(const DBlock& B, hipStream_t stream) {
+    const DFrame& F = B.f;
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE>), dim3((unsigned)(grid * kMarchGridMul)), dim3(kMarchThreads), 0, stream, F);
+    hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), 0, stream, B);
     return hipGetLastError();
 }
 
 template <int PATH>
-static hipError_t launch_path(const DFrame& F, bool single, bool diag_build, hipStream_t stream) {
+static hipError_t launch_path(const DBlock& B, bool single, bool diag_build, hipStream_t stream) {
+    const DFrame& F = B.f;
     /* the full closest hit always walks the (wave-uniform) BVH, a one-node tree included: its single-instance specialisation
        kept every instance / volume field live across the whole kernel (128-153 VGPRs, 3 waves per SIMD, against 108-125 and 4)
        and measured 7 % slower on a one-instance scene with a point light (profiles/r02_full_closest_hit_kernel.txt) */
-    if (F.full) return launch_full_t<PATH, false>(F, stream);
+    if (F.full) return launch_full_t<PATH, false>(B, stream);
     if constexpr (PATH == VRT_PATH_DENSE || PATH == VRT_PATH_BRICK || PATH == kPathBrick16 || PATH == kPathCells16) {
-        if (diag_build) return single ? launch_t<PATH, true>(F, stream) : launch_t<PATH, false>(F, stream);
+        if (diag_build) return single ? launch_t<PATH, true>(B, stream) : launch_t<PATH, false>(B, stream);
     }
-    return single ? launch_nodiag_t<PATH, true>(F, stream) : launch_nodiag_t<PATH, false>(F, stream);
+    return single ? launch_nodiag_t<PATH, true>(B, stream) : launch_nodiag_t<PATH, false>(B, stream);
 }
 
-hipError_t launch_march(const DFrame& F, int path, bool single, hipStream_t stream) {
+hipError_t launch_march(const DBlock& B, int path, bool single, hipStream_t stream) {
+    const DFrame& F = B.f;
+    if (F.n_frames < 1 || F.n_frames > kMaxBlockFrames) return hipErrorInvalidValue;
     switch (path) {
-        case kPathCube: return launch_path<kPathCube>(F, single, false, stream);
-        case kPathCube16: return launch_path<kPathCube16>(F, single, false, stream);
-        case kPathBrick16: return launch_path<kPathBrick16>(F, single, F.diag != 0, stream);
-        case kPathCells16: return launch_path<kPathCells16>(F, single, F.diag != 0, stream);
-        case VRT_PATH_DENSE: return launch_path<VRT_PATH_DENSE>(F, single, F.diag != 0, stream);
+        case kPathCube: return launch_path<kPathCube>(B, single, false, stream);
+        case kPathCube16: return launch_path<kPathCube16>(B, single, false, stream);
+        case kPathBrick16: return launch_path<kPathBrick16>(B, single, F.diag != 0, stream);
+        case kPathCells16: return launch_path<kPathCells16>(B, single, F.diag != 0, stream);
+        case VRT_PATH_DENSE: return launch_path<VRT_PATH_DENSE>(B, single, F.diag != 0, stream);
         case VRT_PATH_BRICK_LDS:
-            if (single && !F.full) return launch_coop(F, stream);
-            return launch_path<VRT_PATH_BRICK>(F, single, F.diag != 0, stream);
-        default: return launch_path<VRT_PATH_BRICK>(F, single, F.diag != 0, stream);
+            if (single && !F.full) return launch_coop(B, stream);
+            return launch_path<VRT_PATH_BRICK>(B, single, F.diag != 0, stream);
+        default: return launch_path<VRT_PATH_BRICK>(B, single, F.diag != 0, stream);
     }
 }
 

@@ -9,8 +9,9 @@
 namespace vrt {
 
 /* path: VRT_PATH_DENSE / VRT_PATH_BRICK / VRT_PATH_BRICK_LDS / kPathCube / kPathBrick16 / kPathCube16 (already resolved,
-   never AUTO). */
-hipError_t launch_march(const DFrame& frame, int path, bool single_instance, hipStream_t stream);
+   never AUTO).
+   block.f.n_frames frames (grid.y) in ONE launch, frame f with camera block.cam[f]. */
+hipError_t launch_march(const DBlock& block, int path, bool single_instance, hipStream_t stream);
 /* dense grid -> brick records of `format` (fp32: 512 B, VRT_FORMAT_TEXEL16: 256 B of int16). */
 hipError_t launch_retile(const float* dense, void* bricks, int format, int N, int nb, hipStream_t stream);
 /* VRT_PATH_CELLS: integer field -> nb^3 x 64 cell records of 8 int16. */

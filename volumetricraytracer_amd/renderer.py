@@ -303,6 +303,16 @@ class VHipRenderer:
             _abi.check(m, "vrt_timing_history")
         return [buf[i] for i in range(m)]
 
+    def launch_history(self, n: int):
+        """(kernel ms, frames covered) of the last n march launches, oldest first (vrt_launch_history); 0 ms = not event-timed."""
+        self._require()
+        ms = (C.c_float * max(n, 1))()
+        fr = (C.c_int * max(n, 1))()
+        m = self._lib.vrt_launch_history(self._ctx, n, ms, fr)
+        if m < 0:
+            _abi.check(m, "vrt_launch_history")
+        return [(ms[i], fr[i]) for i in range(m)]
+
     def wave_records(self, which: int = 0) -> np.ndarray:
         """Per-wave records of the last launch, [waves, 8] uint32 (vrt_debug_wave_records):
         which=0 counters, which=1 diagnostic timeline (after a FLAG_DIAG_TIMELINE launch)."""
