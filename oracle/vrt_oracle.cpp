@@ -726,9 +726,15 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
     float t = (t_enter > 0.0f ? t_enter : 0.0f) + P.prm.eps_in;
     float t_end = minf(t_exit, t_cur);
     bool clipped = false;
-    if (V.skip) {
+    /* up to here the hit threshold eps_hit + cone_eps*t is at most smax/2 (the margin covers rounding) */
+    const float t_skip_end = P.prm.cone_eps > 0.0f ? (0.5f * smax - P.prm.eps_hit) / P.prm.cone_eps
+                                                   : (P.prm.eps_hit + P.prm.eps_hit <= smax ? std::numeric_limits<float>::infinity()
+                                                                                             : -std::numeric_limits<float>::infinity());
+    if (V.skip && t_end <= t_skip_end) {
         /* The active box: bounding box of the bricks that can hold surface.  Outside it the table would only leap; the
-           march is clipped to it (same slab arithmetic, same reciprocals as the volume box). */
+           march is clipped to it (same slab arithmetic, same reciprocals as the volume box) — as long as the whole interval
+           lies where an inactive cell cannot produce a hit (t <= t_skip_end): a volume so far away that a pixel's footprint
+           exceeds half the step clamp is marched over its whole box. */
         const float inf = std::numeric_limits<float>::infinity();
         const float oo3[3] = {oo.x, oo.y, oo.z}, od3[3] = {od.x, od.y, od.z};
         float tmin[3], tmax[3];
@@ -750,10 +756,6 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
     /* smallest step: one pixel-footprint radius at the total path length t_base + t (t_base = length of
        the path that led to this ray's origin: 0 for camera rays, the hit distance for shadow rays) */
     const float base_min = fmaf(t_base, P.prm.cone_eps, P.prm.step_min);
-    /* up to here the hit threshold eps_hit + cone_eps*t is at most smax/2 (the margin covers rounding) */
-    const float t_skip_end = P.prm.cone_eps > 0.0f ? (0.5f * smax - P.prm.eps_hit) / P.prm.cone_eps
-                                                   : (P.prm.eps_hit + P.prm.eps_hit <= smax ? std::numeric_limits<float>::infinity()
-                                                                                             : -std::numeric_limits<float>::infinity());
     const float leap_unit = (4.0f * V.cell) * inv_len; /* one brick edge in ray-parameter units */
     const float cell_unit = leap_unit * 0.25f;         /* one cell edge */
     float t_prev = t, s_prev = 0.0f;

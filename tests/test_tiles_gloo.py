@@ -247,7 +247,7 @@ def test_bench_cli_parses_and_prints_help():
     import bench
 
     a = bench.parse_args([])
-    assert (a.gpus, a.frames_per_step, a.strip_rows, a.scaling, a.workload) == (1, 64, 8, "strong", "c3")
+    assert (a.gpus, a.frames_per_step, a.strip_rows, a.scaling, a.workload) == (1, 96, 8, "strong", "c3")
     a = bench.parse_args(["--gpus", "8", "--steps", "20", "--warmup", "5"])
     assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
 

@@ -560,6 +560,32 @@ def test_skybox_from_a_dds_cube_map(tmp_path, layout):
     open(bad, "wb").write(bc)
     with pytest.raises(RuntimeError):
         vx.load_skybox_faces(bad)
+    # a damaged header: an absurd mip count (with and without DDSD_MIPMAPCOUNT set) is refused or ignored at once — never a
+    # loop of 4e9 iterations or a shift by >= 32
+    import time
+    for flag in (0x20000, 0):
+        huge = bytearray(raw)
+        hdr_flags = struct.unpack("<I", raw[8:12])[0]
+        huge[8:12] = struct.pack("<I", (hdr_flags & ~0x20000) | flag)
+        huge[28:32] = struct.pack("<I", 0xffffffff)
+        open(bad, "wb").write(huge)
+        t0 = time.perf_counter()
+        if flag and layout != "legacy_bgra_mips":
+            with pytest.raises(RuntimeError):   # claims a full mip chain the file does not hold: truncated
+                vx.load_skybox_faces(bad)
+        elif flag:
+            assert np.array_equal(vx.load_skybox_faces(bad), want)  # the count is clamped to the chain a face of this size can have
+        elif layout == "legacy_bgra_mips":
+            # without the flag the field is undefined: one level per face is read; this file's faces are a mip chain apart, so
+            # the faces after the first come out wrong, but nothing hangs or crashes
+            assert vx.load_skybox_faces(bad).shape == (6, 8, 8, 4)
+        else:
+            assert np.array_equal(vx.load_skybox_faces(bad), want)
+        assert time.perf_counter() - t0 < 1.0
+    # the suffix rule is case-insensitive, and the same for every caller
+    upper = str(tmp_path / "SKY.DdS")
+    open(upper, "wb").write(raw)
+    assert np.array_equal(vx.load_skybox_faces(upper), want)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/VolumetricRaytracer/VolumetricRaytracer/Resources/Skybox"),

@@ -159,8 +159,10 @@ VObjectPtr<VTextureCube> VTextureCube::LoadFromDDSFile(const std::string& path) 
         return off + 4 <= file.size() ? (uint32_t)file[off] | (uint32_t)file[off + 1] << 8 | (uint32_t)file[off + 2] << 16 | (uint32_t)file[off + 3] << 24 : 0u;
     };
     if (file.size() < 128 || u32(0) != 0x20534444u /* "DDS " */ || u32(4) != 124 || u32(76) != 32) return nullptr;
-    const uint32_t height = u32(12), width = u32(16);
-    uint32_t mips = u32(28);
+    const uint32_t hdr_flags = u32(8), height = u32(12), width = u32(16);
+    /* dwMipMapCount is only defined with DDSD_MIPMAPCOUNT, and a square texture has at most 1 + floor(log2(width)) levels: a
+       damaged header must neither make the size loop below run for seconds nor shift by >= 32 */
+    uint32_t mips = (hdr_flags & 0x20000u) ? u32(28) : 1u;
     const uint32_t pf_flags = u32(80), fourcc = u32(84), bits = u32(88), rmask = u32(92), gmask = u32(96), bmask = u32(100), amask = u32(104);
     const uint32_t caps2 = u32(112);
     if (mips == 0) mips = 1;
@@ -191,6 +193,9 @@ VObjectPtr<VTextureCube> VTextureCube::LoadFromDDSFile(const std::string& path) 
         return nullptr; /* block-compressed or exotic: not supported */
     }
     if (!cube || width == 0 || width != height || width > 16384) return nullptr;
+    uint32_t max_mips = 1;
+    while ((width >> max_mips) != 0) max_mips++;
+    mips = std::min(mips, max_mips);
     size_t face_bytes = 0; /* all mip levels of one face */
     for (uint32_t m = 0; m < mips; m++) face_bytes += (size_t)std::max(1u, width >> m) * std::max(1u, height >> m) * (size_t)bpp;
     if (file.size() < data + 6 * face_bytes) return nullptr; /* truncated */

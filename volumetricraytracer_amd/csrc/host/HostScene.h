@@ -39,6 +39,13 @@ public:
        24-bit RGB, legacy or DX10 header, six faces, top mip level only.  nullptr for anything else (not a cube map,
        block-compressed, truncated, faces not square). */
     static std::shared_ptr<VTextureCube> LoadFromDDSFile(const std::string& path);
+    /* Whether a sky box argument names a .dds file (suffix, any case) rather than a folder of face images: the one rule every
+       caller uses. */
+    static bool IsDDSPath(const std::string& path) {
+        if (path.size() <= 4) return false;
+        const char* e = path.c_str() + path.size() - 4;
+        return e[0] == '.' && (e[1] | 0x20) == 'd' && (e[2] | 0x20) == 'd' && (e[3] | 0x20) == 's';
+    }
 
 private:
     size_t Width, Height;

@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
         light->IlluminationStrength = 6.f;
         scene->SetActiveDirectionalLight(light);
     }
-    const bool skyIsDDS = skyboxDir.size() > 4 && skyboxDir.compare(skyboxDir.size() - 4, 4, ".dds") == 0; /* the reference's Skybox.dds */
+    const bool skyIsDDS = VTextureCube::IsDDSPath(skyboxDir); /* the reference's Skybox.dds */
     VObjectPtr<VTextureCube> sky = skyboxDir.empty() ? nullptr : (skyIsDDS ? VTextureCube::LoadFromDDSFile(skyboxDir) : VTextureCube::LoadFromFaceDirectory(skyboxDir));
     if (!skyboxDir.empty() && !sky) fprintf(stderr, "cannot load a sky box from %s; using the procedural one\n", skyboxDir.c_str());
     scene->SetEnvironmentTexture(sky ? sky : ProceduralSky(256));

@@ -127,7 +127,7 @@ int vrh_texture_load(const char* path, int* width, int* height, uint8_t* out, si
    non-null and cap suffices.  0 / -1. */
 int vrh_cubemap_load(const char* dir, int* face_size, uint8_t* out, size_t cap) {
     const std::string where = dir ? dir : "";
-    const bool dds = where.size() > 4 && (where.compare(where.size() - 4, 4, ".dds") == 0 || where.compare(where.size() - 4, 4, ".DDS") == 0);
+    const bool dds = VTextureCube::IsDDSPath(where);
     VObjectPtr<VTextureCube> t = dds ? VTextureCube::LoadFromDDSFile(where) : VTextureCube::LoadFromFaceDirectory(where);
     if (!t) {
         g_error = (dds ? std::string("cannot read an uncompressed cube map from ") : std::string("cannot load six equal square faces from ")) + where;

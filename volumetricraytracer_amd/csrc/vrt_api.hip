@@ -720,11 +720,34 @@ void cull_rect(const vrt_ctx* ctx, const vrt_params* p, DCam& F) {
         const DInstance& I = ctx->inst[i];
         double lo[3], hi[3];
         const double cell = ((double)h.extent * 2.0) / (double)(h.N - 1);
+        /* The kernel clips a ray to the active box only when its whole interval ends before t_skip_end = (smax/2 - eps_hit) /
+           cone_eps, smax = step_max / |w2o d| >= step_max * min|scale| (clip_to_active_box).  The rectangle may rely on the clip
+           only if that holds for EVERY primary ray: the farthest corner of the volume box is nearer than the smallest t_skip_end */
+        bool clip_everywhere = true;
+        if (h.step_max > 0.0f) {
+            const vrt_instance& in = ctx->scene.instances[i];
+            const double min_scale = std::min(std::min(fabs((double)in.scale[0]), fabs((double)in.scale[1])), fabs((double)in.scale[2]));
+            const double smax_min = (double)h.step_max * min_scale;
+            double far2 = 0.0;
+            for (int k = 0; k < 8; k++) {
+                const double c[3] = {(k & 1) ? (double)h.extent : -(double)h.extent, (k & 2) ? (double)h.extent : -(double)h.extent,
+                                     (k & 4) ? (double)h.extent : -(double)h.extent};
+                double d2 = 0.0;
+                for (int a = 0; a < 3; a++) {
+                    const double w = (double)I.o2w[a * 3 + 0] * c[0] + (double)I.o2w[a * 3 + 1] * c[1] + (double)I.o2w[a * 3 + 2] * c[2] + (double)I.pos[a] - (double)F.cam_o[a];
+                    d2 += w * w;
+                }
+                far2 = std::max(far2, d2);
+            }
+            const double t_far = sqrt(far2) * 1.001;
+            clip_everywhere = p->cone_eps > 0.0f ? t_far <= (0.5 * smax_min * 0.999 - (double)p->eps_hit) / (double)p->cone_eps
+                                                 : 2.0 * (double)p->eps_hit <= smax_min * 0.999;
+        }
         for (int a = 0; a < 3; a++) {
             lo[a] = -(double)h.extent;
             hi[a] = (double)h.extent;
-            if (h.step_max > 0.0f && p->mode < VRT_MODE_CUBE) { /* the sphere-trace is clipped to the active box (a little slack for
-                                                                   its float rounding); the Cube modes visit the whole volume box */
+            if (h.step_max > 0.0f && p->mode < VRT_MODE_CUBE && clip_everywhere) { /* the sphere-trace is clipped to the active box (a little
+                                                                   slack for its float rounding); the Cube modes visit the whole volume box */
                 const int ax = a == 0 ? 0 : (a == 1 ? 2 : 1);
                 lo[a] = std::max(lo[a], (double)(h.abox[ax] * kBrickCells) * cell - (double)h.extent - 0.01 * cell);
                 hi[a] = std::min(hi[a], (double)std::min((h.abox[3 + ax] + 1) * kBrickCells, h.N - 1) * cell - (double)h.extent + 0.01 * cell);

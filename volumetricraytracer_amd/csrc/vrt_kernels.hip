@@ -296,9 +296,12 @@ __device__ __forceinline__ bool slab_box(F3 o, F3 d, const DBvhNode& n, float t_
     return !(tx < te) && !(tx < 0.0f) && !(te > t_cur);
 }
 
-/* A lane's sample counter also carries, above bit kExhaustedShift, how many of its marches ran out of budget (max_steps
- * positions visited with the ray still inside the volume): < 2^20 samples and < 2^12 marches per lane and counter. */
-constexpr unsigned kExhaustedShift = 20;
+/* A lane's hit counter (at most 3: one per level of the closest-hit loop) also carries, above bit kExhaustedShift, how many of the
+ * lane's marches ran out of budget (max_steps positions visited with the ray still inside the volume): at most 3 levels x 11 rays
+ * x 64 instances of them, in the 24 bits above.  The sample counters count samples only: 65535 positions x 33 rays x 64 instances
+ * stay below 2^32 (round 2 packed this count into the sample counters' upper 12 bits, which long budgets over many instances
+ * could carry into). */
+constexpr unsigned kExhaustedShift = 8;
 constexpr unsigned kExhaustedOne = 1u << kExhaustedShift;
 
 /* Diagnostic-build accumulators (wave-uniform, shader-clock cycles); unused otherwise. */
@@ -331,10 +334,12 @@ struct RaySeg {
 };
 
 /* Clip the march interval [t0, t_end] of a ray set up against the volume box to the volume's active box.  False: the ray
- * misses the active box (nothing to march). */
+ * misses the active box (nothing to march).  Only while the whole interval lies where an inactive cell cannot produce a hit
+ * (t <= t_skip_end: the hit threshold stays below half the step clamp); a volume so far away that a pixel's footprint exceeds
+ * that is marched over its whole box, like the oracle does. */
 __device__ __forceinline__ bool clip_to_active_box(const VolRef& V, F3 inv, RaySeg& R) {
     R.clipped = false;
-    if (V.skip == nullptr) return true;
+    if (V.skip == nullptr || !(R.t_end <= R.t_skip_end)) return true;
     float ta, tb;
     slab_interval(R.oo, R.od, inv, V.alo, V.ahi, ta, tb);
     if (!(tb > ta) || !(tb >= 0.0f)) return false;
@@ -529,7 +534,7 @@ __device__ __forceinline__ F3 hit_normal(const DInstance* __restrict__ I, const 
  */
 template <int NORMAL, bool B16>
 __device__ __forceinline__ bool march_cube(const DFrame& F, const DInstance* __restrict__ I, const DVolume* __restrict__ Vd, F3 o,
-                                           F3 d, float t_cur, float& t_hit, F3& n_world, unsigned& steps) {
+                                           F3 d, float t_cur, float& t_hit, F3& n_world, unsigned& steps, unsigned& ex) {
     const VolRef V = load_vol<VRT_PATH_BRICK>(Vd);
     RaySeg R;
     if (!setup_ray<false>(F, I, V, o, d, t_cur, 0.0f, R)) return false;
@@ -615,7 +620,7 @@ __device__ __forceinline__ bool march_cube(const DFrame& F, const DInstance* __r
         t = maxf_(t_new, t);
         axis_in = axis;
     }
-    if (max_steps > 0 && !(t > R.t_end)) steps += kExhaustedOne;
+    if (max_steps > 0 && !(t > R.t_end)) ex += kExhaustedOne;
     return false;
 }
 
@@ -737,9 +742,9 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
 template <int PATH, int NORMAL /* 0 none, 1 fast length, 2 exact length */, bool DIAG = false, bool DIR_SHADOW = false>
 __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance* __restrict__ I,
                                                const DVolume* __restrict__ Vd, F3 o, F3 d, float t_cur, float t_base,
-                                               float& t_hit, F3& n_world, unsigned& steps, DiagAcc* dg = nullptr) {
+                                               float& t_hit, F3& n_world, unsigned& steps, unsigned& ex, DiagAcc* dg = nullptr) {
     if constexpr (PATH == kPathCube || PATH == kPathCube16) {
-        return march_cube<NORMAL, PATH == kPathCube16>(F, I, Vd, o, d, t_cur, t_hit, n_world, steps);
+        return march_cube<NORMAL, PATH == kPathCube16>(F, I, Vd, o, d, t_cur, t_hit, n_world, steps, ex);
     } else {
     constexpr int DP = data_path<PATH>(); /* where the taps come from */
     const VolRef V = load_vol<DP>(Vd);
@@ -758,7 +763,7 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     st.c = Cell{0, 0, 0, 0.0f, 0.0f, 0.0f};
     march_lane<DP, DIAG>(F, V, R, st, F.max_steps, steps, dg);
     if (!st.hit) {
-        if (F.max_steps > 0 && st.i >= F.max_steps && !(st.t > R.t_end)) steps += kExhaustedOne; /* budget ran out inside the volume: reported, treated as a miss */
+        if (F.max_steps > 0 && st.i >= F.max_steps && !(st.t > R.t_end)) ex += kExhaustedOne; /* budget ran out inside the volume: reported, treated as a miss */
         return false;
     }
     float t = st.t;
@@ -774,11 +779,11 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
 /* Closest hit over the scene.  SINGLE: exactly one instance, no BVH, all scene data wave-uniform. */
 template <int PATH, bool SINGLE, bool DIAG = false, int NORMAL = 1>
 __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float t_max, float t_base, float& t_best,
-                                              int& inst_best, F3& n_best, unsigned& steps, DiagAcc* dg = nullptr) {
+                                              int& inst_best, F3& n_best, unsigned& steps, unsigned& ex, DiagAcc* dg = nullptr) {
     if constexpr (SINGLE) {
         float t;
         F3 n;
-        if (march_instance<PATH, NORMAL, DIAG>(F, F.inst, F.vol0, o, d, t_max, t_base, t, n, steps, dg)) {
+        if (march_instance<PATH, NORMAL, DIAG>(F, F.inst, F.vol0, o, d, t_max, t_base, t, n, steps, ex, dg)) {
             t_best = t;
             inst_best = 0;
             n_best = n;
@@ -812,7 +817,7 @@ __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float
                        fall depends on the interval's end: cut at `best` the result would depend on the visiting order); the
                        cell walk of the Cube modes has no such state and stops at the closest hit so far */
                     constexpr bool kCube = PATH == kPathCube || PATH == kPathCube16;
-                    if (march_instance<PATH, NORMAL, DIAG>(F, I, F.vols + I->slot, o, d, kCube ? best : t_max, t_base, t, n, steps, dg)) {
+                    if (march_instance<PATH, NORMAL, DIAG>(F, I, F.vols + I->slot, o, d, kCube ? best : t_max, t_base, t, n, steps, ex, dg)) {
                         if (!any || t < best || (t == best && ii < inst_best)) {
                             any = true;
                             best = t;
@@ -832,12 +837,12 @@ __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float
 }
 
 template <int PATH, bool SINGLE, bool DIAG = false, bool DIR_SHADOW = false>
-__device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_max, float t_base, unsigned& steps,
+__device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_max, float t_base, unsigned& steps, unsigned& ex,
                                           DiagAcc* dg = nullptr) {
     float t;
     F3 n;
     if constexpr (SINGLE) {
-        return march_instance<PATH, 0, DIAG, DIR_SHADOW>(F, F.inst, F.vol0, o, d, t_max, t_base, t, n, steps, dg);
+        return march_instance<PATH, 0, DIAG, DIR_SHADOW>(F, F.inst, F.vol0, o, d, t_max, t_base, t, n, steps, ex, dg);
     } else {
         bool found = false; /* this lane's ray is blocked: it takes no further part, the wave goes on for the others */
         int ni = 0;
@@ -852,7 +857,7 @@ __device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_m
             }
             if (nd.left < 0) {
                 const DInstance* I = F.inst + (-nd.left - 1);
-                if (in && march_instance<PATH, 0, DIAG, DIR_SHADOW>(F, I, F.vols + I->slot, o, d, t_max, t_base, t, n, steps, dg)) found = true;
+                if (in && march_instance<PATH, 0, DIAG, DIR_SHADOW>(F, I, F.vols + I->slot, o, d, t_max, t_base, t, n, steps, ex, dg)) found = true;
                 ni = nd.right;
             } else {
                 ni = ni + 1;
@@ -1051,10 +1056,9 @@ template <bool DIAG, bool UNIT = false>
 __device__ __forceinline__ void write_records(const DFrame& F, int frame, int b, int wave, int lane, Counters k, const DiagAcc& dg,
                                               unsigned long long t_start) {
     const size_t frame_words = (size_t)(unsigned)frame * F.stats_stride; /* this frame's records within the launch's buffers */
-    const unsigned ex_lane = (k.s_primary >> kExhaustedShift) + (k.s_shadow >> kExhaustedShift);
+    const unsigned ex_lane = k.n_hits >> kExhaustedShift;
     const unsigned exhausted = __ballot(ex_lane != 0u) == 0ull ? 0u : wave_sum(ex_lane); /* practically never set */
-    k.s_primary &= kExhaustedOne - 1u;
-    k.s_shadow &= kExhaustedOne - 1u;
+    k.n_hits &= kExhaustedOne - 1u;
     const unsigned s_primary_lane = k.s_primary, s_shadow_lane = k.s_shadow;
     if constexpr (UNIT) {
         k.n_primary = (unsigned)__builtin_popcountll(__ballot(k.n_primary != 0u));
@@ -1205,15 +1209,15 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel(const DBlock B) {
            sky, and for them it is the last link of a chain of dependent loads (kernarg -> instance / volume -> texel -> store) */
         const unsigned sky = env_fetch(F.env, F.env_size, d);
         /* the normal's length is the correctly rounded one: its dot product with the light decides whether a shadow ray is cast */
-        if (reach && trace_closest<PATH, SINGLE, DIAG, 2>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, k.s_primary, &dg)) {
-            k.n_hits = 1;
+        if (reach && trace_closest<PATH, SINGLE, DIAG, 2>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, k.s_primary, k.n_hits, &dg)) {
+            k.n_hits += 1; /* (its upper bits count exhausted marches) */
             bool shadowed = false;
             const F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
             /* A surface facing away from the light gets a contribution <= 0 from it, blocked or not, and this kernel has no
                other term: the tone-map clamps the pixel to 0 either way, so that shadow ray is not cast (oracle: same rule) */
             if (F.shadow && !F.unlit && dot3(n, ld) > 0.0f) {
                 k.n_shadow = 1;
-                shadowed = trace_any<PATH, SINGLE, DIAG, true>(F, shadow_origin(F, o, d, t_hit), ld, 5000.0f, t_hit, k.s_shadow, &dg);
+                shadowed = trace_any<PATH, SINGLE, DIAG, true>(F, shadow_origin(F, o, d, t_hit), ld, 5000.0f, t_hit, k.s_shadow, k.n_hits, &dg);
             }
             color = shade_hit(F, SINGLE ? F.vol0 : F.vols + F.inst[inst].slot, d, n, shadowed);
         } else {
@@ -1368,7 +1372,7 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DBlock 
             float t_hit = 0.0f;
             int inst = 0;
             F3 n = f3(0.0f, 0.0f, 0.0f);
-            if ((level == 1 && !reach) || !trace_closest<PATH, SINGLE, false, 2>(F, o, d, 10000.0f, t_base, t_hit, inst, n, k.s_primary)) {
+            if ((level == 1 && !reach) || !trace_closest<PATH, SINGLE, false, 2>(F, o, d, 10000.0f, t_base, t_hit, inst, n, k.s_primary, k.n_hits)) {
                 color = env_lookup(F.env, F.env_size, d);
                 break;
             }
@@ -1399,7 +1403,7 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DBlock 
                 const bool lone_backfacing = F.n_point == 0 && F.n_spot == 0 && !bounce && !(dot3(n, ld) > 0.0f);
                 if (shadows && !lone_backfacing) {
                     k.n_shadow++;
-                    sh = trace_any<PATH, SINGLE, false, true>(F, so, ld, 5000.0f, tb, k.s_shadow);
+                    sh = trace_any<PATH, SINGLE, false, true>(F, so, ld, 5000.0f, tb, k.s_shadow, k.n_hits);
                 }
                 if (!sh) sum = sum + radiance(f3(F.light_strength, F.light_strength, F.light_strength), ld, wo, n, albedo, rough, metal, kk);
             }
@@ -1413,7 +1417,7 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DBlock 
                     bool sh = false;
                     if (shadows) {
                         k.n_shadow++;
-                        sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow);
+                        sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow, k.n_hits);
                     }
                     if (!sh) sum = sum + radiance(f3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo, rough, metal, kk);
                 }
@@ -1435,7 +1439,7 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DBlock 
                     bool sh = false;
                     if (shadows) {
                         k.n_shadow++;
-                        sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow);
+                        sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow, k.n_hits);
                     }
                     if (!sh) sum = sum + radiance(f3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo, rough, metal, kk);
                 }
@@ -1605,7 +1609,7 @@ __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V,
  * lane is still marching): the LDS tail above.  Returns true on hit with t / cell / iteration.
  */
 __device__ __forceinline__ bool march_hybrid(const DFrame& F, const VolRef& V, const RaySeg& R, bool act, float* slots,
-                                             unsigned* tags, int lane, float& t_hit, Cell& c_hit, int& iter_hit, unsigned& steps) {
+                                             unsigned* tags, int lane, float& t_hit, Cell& c_hit, int& iter_hit, unsigned& steps, unsigned& ex) {
     MarchState st;
     st.t = st.t_prev = R.t0;
     st.s_prev = st.s_hit = 0.0f;
@@ -1619,7 +1623,7 @@ __device__ __forceinline__ bool march_hybrid(const DFrame& F, const VolRef& V, c
     const bool cont = act && !st.hit && st.i < max_steps && !(st.t > R.t_end);
     if (__ballot(cont) != 0ull) march_tail_lds(F, V, R, cont, st, slots, tags, lane, steps);
     if (!st.hit) {
-        if (act && max_steps > 0 && st.i >= max_steps && !(st.t > R.t_end)) steps += kExhaustedOne;
+        if (act && max_steps > 0 && st.i >= max_steps && !(st.t > R.t_end)) ex += kExhaustedOne;
         return false;
     }
     float t = st.t;
@@ -1679,11 +1683,11 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DBlock 
     float t_hit = 0.0f;
     Cell c_hit = {0, 0, 0, 0.0f, 0.0f, 0.0f};
     int iter_hit = 0;
-    const bool hit = march_hybrid(F, V, R, act, slots, tags, lane, t_hit, c_hit, iter_hit, k.s_primary);
+    const bool hit = march_hybrid(F, V, R, act, slots, tags, lane, t_hit, c_hit, iter_hit, k.s_primary, k.n_hits);
 
     F3 n = f3(0.0f, 0.0f, 0.0f);
     if (hit) {
-        k.n_hits = 1;
+        k.n_hits += 1;
         n = hit_normal<VRT_PATH_BRICK, true>(I, V, R, c_hit, iter_hit);
     }
     bool shadowed = false;
@@ -1699,7 +1703,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DBlock 
         float ts = 0.0f;
         Cell cs = {0, 0, 0, 0.0f, 0.0f, 0.0f};
         int is = 0;
-        shadowed = march_hybrid(F, V, Rs, act_s, slots, tags, lane, ts, cs, is, k.s_shadow);
+        shadowed = march_hybrid(F, V, Rs, act_s, slots, tags, lane, ts, cs, is, k.s_shadow, k.n_hits);
     }
     if (valid) {
         F3 color = hit ? shade_hit(F, Vd, d, n, shadowed) : env_lookup(F.env, F.env_size, d);

@@ -86,19 +86,25 @@ class VHipRenderer:
         if sc is None:
             raise RuntimeError("SetSceneToRender was not called")
         vols = sc.volumes()
-        # material textures no volume of the scene names any more leave the device (their ids are handed out again): a
-        # renderer that is given scene after scene does not run out of the VRT_MAX_TEXTURES slots
+        for slot, vol in enumerate(vols):
+            if self._uploaded.get(slot) != id(vol) or vol.dirty:
+                self.upload_volume(slot, vol)
+            else:
+                # the volume's voxels are unchanged, but its material may name other images or scalars than at the last sync
+                # (VMaterial is edited in place; VDXVoxelVolume::UpdateGeometryConstantBuffer, RDXVoxelVolume.cpp:368-397, runs
+                # every frame): re-send them — the C-ABI returns at once when nothing differs
+                self._bind_material(slot, vol)
+        for slot in [s for s in self._uploaded if s >= len(vols)]:
+            _abi.check(self._lib.vrt_volume_free(self._ctx, slot), "vrt_volume_free")
+            del self._uploaded[slot]
+        # only now, with every slot bound to its current images: material textures no volume of the scene names any more leave
+        # the device (their ids are handed out again), so a renderer that is given scene after scene does not run out of the
+        # VRT_MAX_TEXTURES slots.  (Freeing first would leave a slot pointing at an id that the next upload reuses.)
         live = {id(t) for vol in vols for t in vol.Material.textures() if t is not None}
         for key in [k for k in self._tex_ids if k not in live]:
             _abi.check(self._lib.vrt_texture_free(self._ctx, self._tex_ids[key]), "vrt_texture_free")
             del self._tex_ids[key]
             del self._tex_keep[key]
-        for slot, vol in enumerate(vols):
-            if self._uploaded.get(slot) != id(vol) or vol.dirty:
-                self.upload_volume(slot, vol)
-        for slot in [s for s in self._uploaded if s >= len(vols)]:
-            _abi.check(self._lib.vrt_volume_free(self._ctx, slot), "vrt_volume_free")
-            del self._uploaded[slot]
         env = sc.EnvironmentMap
         if env is None:
             if self._env_id is not None:
@@ -131,15 +137,20 @@ class VHipRenderer:
             rc = self._lib.vrt_volume_upload(self._ctx, slot, vol.Resolution, vol.VolumeExtends,
                                              d.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p))
         _abi.check(rc, "vrt_volume_upload")
-        mat = vol.Material.to_abi()
-        _abi.check(self._lib.vrt_volume_set_material(self._ctx, slot, C.byref(mat)), "vrt_volume_set_material")
         _abi.check(self._lib.vrt_volume_set_metric(self._ctx, slot, float(vol.density_scale), float(vol.step_max)),
                    "vrt_volume_set_metric")
+        self._bind_material(slot, vol)
+        self._uploaded[slot] = id(vol)
+        vol.dirty = False
+
+    def _bind_material(self, slot: int, vol: VVoxelVolume) -> None:
+        """The slot's material scalars and texture bindings as the volume's VMaterial holds them NOW (images uploaded on first
+        sight).  Both C-ABI calls return without touching the device when nothing changed."""
+        mat = vol.Material.to_abi()
+        _abi.check(self._lib.vrt_volume_set_material(self._ctx, slot, C.byref(mat)), "vrt_volume_set_material")
         ids = [self.upload_texture(t) if t is not None else -1 for t in vol.Material.textures()]
         _abi.check(self._lib.vrt_volume_set_textures(self._ctx, slot, ids[0], ids[1], ids[2], float(vol.Material.TextureScale[0]),
                                                      float(vol.Material.TextureScale[1])), "vrt_volume_set_textures")
-        self._uploaded[slot] = id(vol)
-        vol.dirty = False
 
     def voxelize_mesh(self, slot: int, positions: np.ndarray, indices: np.ndarray, resolution: int, extent: float) -> int:
         """The Voxelizer's hot loop on the device (vrt_voxelize_mesh): fills `slot` with the shell field of a
