@@ -2,33 +2,38 @@
 """Benchmark of the ray-march hot path (BASELINE.json metric: Mrays/s + ms/frame at 1080p over a
 256^3 SDF volume, 1/2/4/8 MI355X).
 
-A "step" is one pass of the hot path over one batch of input: a batch of 64 full frames of the workload (default: BASELINE
+A "step" is one pass of the hot path over one batch of input: a batch of 96 full frames of the workload (default: BASELINE
 config 3 — 1920x1080, 256^3 voxelized mesh, shadow ray on), consecutive views of a camera on a short orbit through the
 workload's own view (0.25 degrees apart) — frames of a moving camera, not copies of one frame; `ms_per_frame` =
-`ms_per_step` / 64 is in the line too.  (A single 1080p frame marches in 0.04 ms: K steps of ONE frame each would time the
-pipeline's fill and drain and the GPU's clock ramp, not the march — profiles/r02_launch_overhead.txt.)  With N ranks (one process per GPU) the SAME frame is split N ways — strong scaling, as the
-metric and config 4 define it: the frame is cut into 8-row strips dealt round-robin to the ranks
-(contiguous tiles would put every object row on the middle GPUs); every rank marches its strips into a
-compact device tile with ONE launch per frame.  Frames are issued in blocks (vrt_render_block: several
-launches per call, one event pair per block) on K streams, and the tiles are gathered onto rank 0 with ONE
-RCCL gather per BLOCK of frames (torch.distributed backend "nccl") that overlaps with the other streams'
-march; rank 0 un-shuffles the gathered strips into frame order.  The exchange format is R8G8B8A8_UNORM, the
-reference's own back-buffer precision (DXConstants.cpp:21).  `--scaling weak` (frame grows with N, fixed rays per GPU) is kept as an
-option; it is never the default.
+`ms_per_step` / 96 is in the line too.  The batch is rendered by vrt_render_block: ONE march launch per block of up to 48 frames
+(the kernel's grid has a frame axis; the dispatcher back-fills the wave slots a frame's latency-bound tail leaves empty with the
+next frame's waves).  One GPU: ONE stream, two launches per step.
+
+With N ranks (one process per GPU) the SAME frame is split N ways — strong scaling, as the metric and config 4 define it: the
+frame is cut into 8-row strips dealt round-robin to the ranks (contiguous tiles would put every object row on the middle GPUs);
+every rank marches its strips of a block of 24 frames into compact device tiles with ONE launch, then ONE RCCL collective per
+block (torch.distributed backend "nccl") assembles the frames, overlapping the next block's march on a second stream; the
+assembling rank un-shuffles the strips into frame order.  `--exchange rotate` (default): frame g of a block is assembled on rank
+g // (24 / N) — one all-to-all per block, every xGMI link of the node in use; `--exchange gather`: every frame on rank 0
+(ncclGather; its inbound links then bound the job) — the other one is measured as a leg of the same run.  The
+exchange format is R8G8B8A8_UNORM, the reference's own back-buffer precision (DXConstants.cpp:21).  `--scaling weak` (frame grows
+with N, fixed rays per GPU) is kept as an option; it is never the default.
 
 Launching: `python bench.py --gpus N` starts the N ranks itself (a child `python -m torch.distributed.run`,
 spawned BEFORE this process touches the GPU); under `torch.distributed.run` (WORLD_SIZE set) it is a rank.
 A rank whose WORLD_SIZE differs from --gpus exits non-zero.
 
 Prints ONE JSON line on rank 0 (driver contract) extended with:
-  roofline        contract fields (algorithmic bytes / event-timed kernel duration / 8 TB/s) PLUS the physical
-                  ones: measured HBM bytes per launch (PMC, from profiles/traffic_latest.json when it was taken
-                  with this very kernel source and these settings), their rate and fraction of peak, samples/s
-                  next to the measured gather ceilings, and what actually limits the kernel
+  roofline        the contract's fields (algorithmic bytes of one launch / its event-timed duration / 8 TB/s) PLUS what the
+                  counters say the kernel is bound by: vector-instruction issue fraction, mean occupancy, measured HBM bytes
+                  (PMC; from profiles/counters_latest.json when it was taken on this very kernel source with these settings),
+                  the HBM floor of a frame, and the lone frame's latency model (longest dependent chain x time per position)
   cpu_baseline    the scalar oracle on this host's cores (a reported baseline)
-  latency         one frame in flight: ms per frame as an application waiting for each frame sees it
+  latency         one frame per launch, one launch in flight: ms per frame as an application waiting for each frame sees it
+  scale_anchor    the ONE-GPU rate with the settings an N-GPU run uses (RGBA8 tiles, 2 streams x 24 frames per launch): the
+                  like-for-like base of the scaling curve; N > 1 lines carry speedup_vs_anchor (anchor re-measured on rank 0)
   end_to_end      vrt_render_begin/_end: march + copy of the frame to pinned host memory, pipelined
-  config4         the same scene at 3840x2160 split the same N ways (BASELINE config 4)
+  config4         the same scene at 3840x2160 split the same N ways (BASELINE config 4), with its own anchor
   reference_texel_format   the same frames with the volume kept as the reference's 16-bit texel (opt-in device format)
 """
 import argparse
@@ -77,10 +82,14 @@ def parse_args(argv=None):
     ap.add_argument("--k-relax", type=float, default=0.0,
                     help="over-relaxation factor of the sphere trace (vrt_params.k_relax); 0 = the renderer's default (1.7), 1 = plain")
     ap.add_argument("--tile-map", default="supertile", choices=["supertile", "band", "linear"], help="blockIdx -> tile map (speed only)")
+    ap.add_argument("--exchange", default="rotate", choices=["rotate", "gather"],
+                    help="N>1: where the frames of a block are assembled: rotate = frame g on rank g // (block / N), one all-to-all "
+                         "per block (every xGMI link carries tiles); gather = every frame on rank 0 (ncclGather; rank 0's inbound "
+                         "links bound the job).  The other one is measured as a leg of the same run")
     ap.add_argument("--gather", default="torch", choices=["torch", "native"],
-                    help="N>1: the per-frame tile gather: torch.distributed.gather (RCCL under torch), or the C-ABI's own "
-                         "vrt_gather_tiles (ncclGather on the march stream; then torch's gather is cross-checked after the "
-                         "timed region, native_gather_check)")
+                    help="N>1: the collective's implementation: torch.distributed (RCCL under torch), or the C-ABI's own "
+                         "vrt_gather_tiles / vrt_exchange_tiles (ncclGather / grouped ncclSend+ncclRecv on the march stream; then "
+                         "torch's is cross-checked after the timed region, native_gather_check)")
     ap.add_argument("--native-check", action="store_true",
                     help="N>1 with --gather torch: also bring up the C-ABI's own RCCL communicator and run a few frames through "
                          "vrt_gather_tiles after the timed region (native_gather_check)")
@@ -142,22 +151,23 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def traffic_key(args, world: int, K: int, rgba8: bool) -> dict:
+def traffic_key(args, world: int, K: int, G: int, rgba8: bool) -> dict:
     return {"workload": args.workload, "n_gpus": world, "path": args.path, "format": args.format, "tile_map": args.tile_map,
-            "frames_in_flight": K, "rgba8": bool(rgba8), "k_relax": args.k_relax, "frames_per_step": args.frames_per_step,
+            "streams": K, "frames_per_launch": G, "rgba8": bool(rgba8), "k_relax": args.k_relax, "frames_per_step": args.frames_per_step,
             "kernel_source_sha": kernel_source_hash()}
 
 
-def measured_traffic(key: dict):
-    """HBM bytes per march launch from the PMC passes of tools/profile_bench.sh, or None when the committed figure
-    was not taken on this kernel source with these settings."""
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+def measured_counters(key: dict):
+    """Per-launch PMC figures of the march kernel (HBM bytes, vector instructions, wave quad-cycles, GPU cycles) from the
+    passes of tools/r03_profile.sh, or None when the committed figures were not taken on this kernel source with these
+    settings."""
+    tpath = os.path.join(ROOT, "profiles", "counters_latest.json")
     try:
         tj = json.load(open(tpath))
     except Exception:
         return None
     if all(tj.get("key", {}).get(k) == v for k, v in key.items()):
-        return tj.get("hbm_bytes_per_launch")
+        return tj
     return None
 
 
@@ -192,7 +202,7 @@ class Pipeline:
     an event wait between streams costs several microseconds of queue time (profiles/r02_launch_overhead.txt)."""
 
     def __init__(self, r, p, W, H, world, rank, dev, rgba8, strip_rows, K, rehearsal, native=False, block_frames=8, cameras=None,
-                 n_cameras=0):
+                 n_cameras=0, rotate=False):
         import torch
 
         from volumetricraytracer_amd.tiles import FrameGather
@@ -202,14 +212,14 @@ class Pipeline:
         self.strip_rows, self.rehearsal, self.native = strip_rows, rehearsal, native and not rehearsal and world > 1
         pix = torch.uint8 if rgba8 else torch.float32
         self.fg = FrameGather(H, W, world, rank, torch.device("cpu") if rehearsal else dev, dtype=pix, buffers=K, strip_rows=strip_rows,
-                              frames_per_gather=G)
+                              frames_per_gather=G, rotate_roots=rotate and world > 1)
         self.march_tiles = [torch.zeros_like(x, device=dev) for x in self.fg.tiles] if rehearsal else self.fg.tiles
         self.frame_bytes = self.fg.rows_per * W * (4 if rgba8 else 16)
         # (the current stream + K-1 pool streams: with HIP's default 4 hardware queues this arrangement lands on distinct queues;
         # K pool streams measured 40 % slower at K = 3, profiles/r02_strong_scaling_probe.txt)
         self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(K - 1)]
         self.pending = [None] * K
-        self.unshuffle = world > 1 and rank == 0 and strip_rows > 0
+        self.unshuffle = world > 1 and strip_rows > 0 and (rank == 0 or self.fg.rotate)
         self.copy_stream = torch.cuda.Stream(device=dev) if self.unshuffle else None
         self.unshuffled = [None] * K
         self.blocks = 0
@@ -258,7 +268,8 @@ class Pipeline:
             self.blocks += 1
 
     def last_frame(self):
-        """Rank 0: the assembled last frame issued."""
+        """The assembled last frame issued, on the rank that assembles it (rank 0, or the frame's root with rotating roots);
+        None elsewhere."""
         return self.fg.frame(*self.last)
 
     def drain(self) -> None:
@@ -310,30 +321,38 @@ def launch_check(args) -> None:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    H, W, sr, G = 77, 16, 8, 3  # a block of G frames per gather, like the GPU pipeline
-    fg = FrameGather(H, W, world, rank, torch.device("cpu"), dtype=torch.uint8, buffers=1, strip_rows=sr if world > 1 else 0,
-                     frames_per_gather=G)
-
-    def tag(rows0, rows, g):  # a pixel value that names its frame row and its frame of the block
-        return ((torch.arange(rows0, rows0 + rows, dtype=torch.int32) + 7 * g) % 251).to(torch.uint8)[:, None, None]
-
+    H, W, sr = 77, 16, 8
     t0 = time.perf_counter()
-    for _ in range(max(args.steps, 1)):
-        for g in range(G):
-            if world == 1:
-                fg.tile(0, g)[:H] = tag(0, H, g)
-                continue
-            for local0, frame0, rows in strip_frame_rows(H, world, rank, sr):
-                fg.tile(0, g)[local0:local0 + rows] = tag(frame0, rows, g)
+    ok = True
+    for rot in (False, True):  # gather to rank 0, and rotating roots (one all-to-all per block)
+        G = 2 * world if rot else 3  # a block of G frames per collective, like the GPU pipeline
+        fg = FrameGather(H, W, world, rank, torch.device("cpu"), dtype=torch.uint8, buffers=1, strip_rows=sr if world > 1 else 0,
+                         frames_per_gather=G, rotate_roots=rot)
+
+        def tag(rows0, rows, g):  # a pixel value that names its frame row and its frame of the block
+            return ((torch.arange(rows0, rows0 + rows, dtype=torch.int32) + 7 * g) % 251).to(torch.uint8)[:, None, None]
+
+        for _ in range(max(args.steps, 1)):
+            for g in range(G):
+                if world == 1:
+                    fg.tile(0, g)[:H] = tag(0, H, g)
+                    continue
+                for local0, frame0, rows in strip_frame_rows(H, world, rank, sr):
+                    fg.tile(0, g)[local0:local0 + rows] = tag(frame0, rows, g)
+            if world > 1:
+                fg.gather(0, async_op=True).wait()
+                fg.unshuffle(0)
+        mine = [g for g in range(G) if fg.root_of(g) == rank]
+        good = all(bool(np.array_equal(fg.frame(0, g)[:, 0, 0].numpy(), ((np.arange(H) + 7 * g) % 251).astype(np.uint8))) for g in mine)
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32)
         if world > 1:
-            fg.gather(0, async_op=True).wait()
-            fg.unshuffle(0)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = ok and bool(flag.item())
     te = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.barrier()
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
     if rank == 0:
-        ok = all(bool(np.array_equal(fg.frame(0, g)[:, 0, 0].numpy(), ((np.arange(H) + 7 * g) % 251).astype(np.uint8))) for g in range(G))
         print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_joined": world, "gathered_frame_ok": ok,
                           "elapsed_s": round(float(te.item()), 4)}), flush=True)
         if not ok:
@@ -396,20 +415,21 @@ def main() -> None:
         label += f" -- the same {W}x{H} frame split over {world} GPUs (strong scaling)"
     rgba8 = args.output == "rgba8" or (args.output == "auto" and world > 1)
     strip_rows = args.strip_rows if world > 1 else 0
-    # one GPU: 3 = FrameCount, DXConstants.cpp:23.  Several: every GPU gets 1/N of a frame whose march lasts as long as its longest
-    # chain whatever its size (profiles/r02_strong_scaling_probe.txt), so the pipeline is deepened to 8 frames (about one whole
-    # frame's work in flight per GPU at N = 8) over 8 HIP hardware queues
-    K = args.frames_in_flight or (1 if world == 1 else 2)
+    rotate = world > 1 and args.exchange == "rotate"
+    # One GPU: ONE stream — a march launch covers a whole block of frames, the launch itself keeps the frames in flight (the
+    # reference keeps 3 on its swap chain, DXConstants.cpp:23).  Several: 2 streams, so that a block's collective overlaps the
+    # next block's march.  (No dependence on how HIP maps streams to hardware queues any more: profiles/r03_fused_launch_sweep.txt.)
+    K = args.frames_in_flight or (1 if world == 1 else MULTI_STREAMS)
     path = {"auto": _abi.PATH_AUTO, "dense": _abi.PATH_DENSE, "brick": _abi.PATH_BRICK, "lds": _abi.PATH_BRICK_LDS, "cells": _abi.PATH_CELLS}[args.path]
     fmt = {"auto": workloads.BENCH_VOLUME_FORMAT, "f32": _abi.FORMAT_F32, "texel16": _abi.FORMAT_TEXEL16}[args.format]
     for vol in sc.volumes():
         vol.set_device_format(fmt)
 
-    def params(w, h):
+    def params(w, h, as_rgba8=None):
         q = v.default_params(w, h, workloads.min_cell(sc), max_steps, shadow=shadow, path=path)
         if args.k_relax > 0.0:
             q.k_relax = args.k_relax
-        if rgba8:
+        if rgba8 if as_rgba8 is None else as_rgba8:
             q.flags |= _abi.FLAG_OUTPUT_RGBA8
         if args.per_frame_launches:
             q.flags |= _abi.FLAG_BLOCK_PER_FRAME
@@ -435,7 +455,7 @@ def main() -> None:
             dist.broadcast(idt, 0)
             r.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
             native_ready = True
-        except Exception as e:  # reported, never fatal: torch.distributed.gather remains
+        except Exception as e:  # reported, never fatal: torch.distributed remains
             native_error = repr(e)
         flag = torch.tensor([1 if native_ready else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -447,23 +467,30 @@ def main() -> None:
     # One STEP = one batch of B frames: consecutive views of a camera on a short orbit through the workload's own view
     # (frames of a moving camera, not B copies of one frame, so a frame does not find its predecessor's lines in L2).
     B = max(args.frames_per_step, 1)
-    # frames per vrt_render_block call = per march launch: one GPU 48 (the most a launch covers); several GPUs 24, gathered as ONE block per collective
-    G = min(args.block_frames or (_abi.MAX_BLOCK_FRAMES if world == 1 else 24), B)
+    # frames per vrt_render_block call = per march launch: one GPU 48 (the most a launch covers); several GPUs: about 24 (a multiple
+    # of N), exchanged as ONE block per collective
+    G = min(args.block_frames or (_abi.MAX_BLOCK_FRAMES if world == 1 else multi_block_frames(world)), B)
+    if rotate and G % world != 0:
+        raise SystemExit(f"[bench] --exchange rotate needs --block-frames to be a multiple of the {world} ranks")
     cams = workloads.orbit_cameras(sc, B)
     cam_arr = r.camera_array(cams + cams)
     KEYS = ("primary_rays", "shadow_rays", "bounce_rays", "primary_steps", "shadow_steps", "hits", "exhausted_rays")
 
-    def batch_counts(pp, w, h):
-        """The counters of one batch (every camera once, this rank's rows, untimed), summed over the ranks."""
+    def batch_counts(pp, w, h, alone=False):
+        """The counters of one batch (every camera once, this rank's rows — the whole frame with alone=True —, untimed), summed
+        over the ranks."""
         from volumetricraytracer_amd.tiles import strip_layout, tile_rows
         tot = {k: 0.0 for k in KEYS}
-        if strip_rows > 0:
+        is8 = bool(pp.flags & _abi.FLAG_OUTPUT_RGBA8)
+        if alone:
+            rows_here, kw = h, {"rows": (0, h)}
+        elif strip_rows > 0:
             per = strip_layout(h, world, strip_rows)[1]
             rows_here, kw = per * strip_rows, {"strips": (strip_rows, rank, world, per)}
         else:
             _, row0, rows_here = tile_rows(h, world, rank)
             kw = {"rows": (row0, rows_here)}
-        scratch = torch.empty((max(rows_here, 1), w, 4), dtype=torch.uint8 if rgba8 else torch.float32, device=dev)
+        scratch = torch.empty((max(rows_here, 1), w, 4), dtype=torch.uint8 if is8 else torch.float32, device=dev)
         for f in range(B):
             r.render_block(pp, 1, scratch.data_ptr(), scratch.numel() * scratch.element_size(), 0, cameras=(cam_arr, f), **kw)
             torch.cuda.synchronize()
@@ -471,13 +498,13 @@ def main() -> None:
             for k in KEYS:
                 tot[k] += tt[k]
         c = torch.tensor([tot[k] for k in KEYS], dtype=torch.float64, device=cdev)
-        if world > 1:
+        if world > 1 and not alone:
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
         return dict(zip(KEYS, (float(x) for x in c.tolist())))
 
-    def pipeline(pp, w, h, k, native, g=None):
+    def pipeline(pp, w, h, k, native, g=None, rot=None):
         return Pipeline(r, pp, w, h, world, rank, dev, rgba8, strip_rows, k, rehearsal, native=native, block_frames=g or G, cameras=cam_arr,
-                        n_cameras=B)
+                        n_cameras=B, rotate=rotate if rot is None else rot)
 
     pipe = pipeline(p, W, H, K, use_native)
     elapsed = timed_run(pipe, args.steps, args.warmup, world, cdev, B)
@@ -487,17 +514,33 @@ def main() -> None:
     kms = [ms for ms, fr in hist if fr == fpl]
 
     def single_gpu_frame(pp, w, h, cam_index):
-        whole = torch.empty((h, w, 4), dtype=torch.uint8 if rgba8 else torch.float32, device=dev)
+        whole = torch.empty((h, w, 4), dtype=torch.uint8 if pp.flags & _abi.FLAG_OUTPUT_RGBA8 else torch.float32, device=dev)
         r.render_block(pp, 1, whole.data_ptr(), whole.numel() * whole.element_size(), 0, cameras=(cam_arr, cam_index), rows=(0, h))
         torch.cuda.synchronize()
         return whole
 
+    def all_ok(ok: bool) -> bool:
+        if world == 1:
+            return ok
+        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(f.item())
+
+    def last_frame_ok(pl, pp, w, h) -> bool:
+        """The assembled (exchanged and un-shuffled) last frame of a pipeline is the frame ONE GPU renders alone from that
+        camera, bit for bit — checked on the rank that holds it, agreed on by all."""
+        ok = True
+        got = pl.last_frame()
+        if got is not None:
+            ok = bool(torch.equal(got.cpu(), single_gpu_frame(pp, w, h, (pl.frame_no - 1) % B).cpu()))
+        return all_ok(ok)
+
     verified = None
-    if os.environ.get("VRT_BENCH_VERIFY") and rank == 0 and args.steps > 0:
-        # the gathered (and un-shuffled) last frame must be the frame one GPU renders alone from that camera, bit for bit
-        verified = bool(torch.equal(pipe.last_frame().cpu(), single_gpu_frame(p, W, H, (pipe.frame_no - 1) % B).cpu()))
+    if args.steps > 0 and (world > 1 or os.environ.get("VRT_BENCH_VERIFY")):
+        # always on for N > 1 (it is one frame, outside the timed region)
+        verified = last_frame_ok(pipe, p, W, H)
         if not verified:
-            raise SystemExit("[bench] gathered frame differs from the single-GPU frame")
+            raise SystemExit("[bench] the assembled frame differs from the single-GPU frame")
 
     cnt = batch_counts(p, W, H)  # whole job, one batch
     rays_per_step = cnt["primary_rays"] + cnt["shadow_rays"]
@@ -508,13 +551,6 @@ def main() -> None:
     t = {k: cnt[k] / B / world for k in KEYS}
 
     # ---- extra legs (outside the timed region) ------------------------------------------------------------------
-    def all_ok(ok: bool) -> bool:
-        if world == 1:
-            return ok
-        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
-        dist.all_reduce(f, op=dist.ReduceOp.MIN)
-        return bool(f.item())
-
     def leg(build, run):
         """An extra leg must never cost the main line: its allocations (which differ per rank — rank 0 holds the gathered
         frames) are agreed on by all ranks before anyone enters the leg's collectives; a failure is reported in the leg's key."""
@@ -530,32 +566,61 @@ def main() -> None:
         except Exception as e:  # noqa: BLE001
             return {"error": repr(e)}
 
-    native_check = None
-    if world > 1 and native_ready and not args.no_extra_legs and args.steps > 0:
-        # the other gather implementation, a few frames: same pixels on rank 0, and its frame time
-        def run_other(other):
-            osteps = max(min(args.steps, 3), 1)
-            eo = timed_run(other, osteps, 1, world, cdev, B)
-            same = True
-            if rank == 0:
-                same = bool(torch.equal(other.last_frame(), single_gpu_frame(p, W, H, (other.frame_no - 1) % B)))
-            return {"gather": "torch" if use_native else "native (vrt_gather_tiles: ncclGather on the march stream)",
-                    "ms_per_frame": round(eo / (osteps * B) * 1e3, 4), "last_frame_equals_single_gpu_frame": same}
+    def anchor_leg(w, h):
+        """The like-for-like base of the scaling curve: ONE GPU renders the whole w x h frame alone with the settings an N-GPU run
+        uses — RGBA8 tiles, MULTI_STREAMS streams x 24 frames per launch — and no exchange.  N > 1: measured on rank 0 while the
+        other ranks wait, in the same run on the same hardware as the N-GPU figure."""
+        out = None
+        if rank == 0:
+            pa = params(w, h, as_rgba8=True)
+            asteps = max(min(args.steps, 4), 1)
+            try:
+                pl = Pipeline(r, pa, w, h, 1, 0, dev, True, 0, MULTI_STREAMS, False, block_frames=min(ANCHOR_BLOCK_FRAMES, B), cameras=cam_arr, n_cameras=B)
+                ea = timed_run(pl, asteps, 1, 1, cdev, B)
+                ca = batch_counts(pa, w, h, alone=True)
+                out = {"value": round((ca["primary_rays"] + ca["shadow_rays"]) * asteps / ea / 1e6, 2), "unit": "Mrays/s",
+                       "ms_per_frame": round(ea / (asteps * B) * 1e3, 4), "n_gpus": 1,
+                       "settings": f"whole {w}x{h} frame on one GPU, RGBA8 tiles, {MULTI_STREAMS} streams x {min(ANCHOR_BLOCK_FRAMES, B)} frames per launch, no exchange"}
+                del pl
+            except Exception as e:  # noqa: BLE001
+                out = {"error": repr(e)}
+        if world > 1:
+            dist.barrier()
+        return out
 
-        native_check = leg(lambda: pipeline(p, W, H, K, not use_native), run_other)
-    latency = end_to_end = config4 = None
+    native_check = exchange_other = None
+    if world > 1 and not args.no_extra_legs and args.steps > 0:
+        osteps = max(min(args.steps, 3), 1)
+
+        def run_other(other):
+            eo = timed_run(other, osteps, 1, world, cdev, B)
+            return {"ms_per_frame": round(eo / (osteps * B) * 1e3, 4), "value": round(rays_per_step * osteps / eo / 1e6, 2), "unit": "Mrays/s",
+                    "last_frame_equals_single_gpu_frame": last_frame_ok(other, p, W, H)}
+
+        if native_ready:  # the other implementation of the same collective, a few steps: same pixels, and its frame time
+            native_check = leg(lambda: pipeline(p, W, H, K, not use_native), run_other)
+            if isinstance(native_check, dict):
+                native_check["collective"] = "torch.distributed" if use_native else "native (vrt_gather_tiles / vrt_exchange_tiles on the march stream)"
+        G_other = G if (rotate or G % world == 0) else multi_block_frames(world)
+        exchange_other = leg(lambda: pipeline(p, W, H, K, use_native, G_other, not rotate), run_other)
+        if isinstance(exchange_other, dict):
+            exchange_other["exchange"] = exchange_label(not rotate, world, G_other, rehearsal)
+    latency = end_to_end = config4 = scale_anchor = None
     if not args.no_extra_legs and args.steps > 0:
         lsteps = max(min(args.steps, 4), 1)  # batches
 
         def run_latency(p1):
-            # one frame in flight: what an application that waits for every frame sees
+            # one frame per launch, one launch in flight: what an application that waits for every frame sees
             e1 = timed_run(p1, lsteps, 1, world, cdev, B)
-            k1 = [x for x, fr in r.launch_history(200) if x > 0.0 and fr == 1]
-            return {"frames_in_flight": 1, "frames_per_launch": 1, "ms_per_frame": round(e1 / (lsteps * B) * 1e3, 4),
+            g1 = world if rotate else 1
+            k1 = [x / g1 for x, fr in r.launch_history(200) if x > 0.0 and fr == g1]
+            return {"streams": 1, "frames_per_launch": g1, "ms_per_frame": round(e1 / (lsteps * B) * 1e3, 4),
                     "value": round(rays_per_step * lsteps / e1 / 1e6, 2), "unit": "Mrays/s",
-                    "kernel_ms": round(float(np.mean(k1)), 4) if k1 else None}
+                    "kernel_ms_per_frame": round(float(np.mean(k1)), 4) if k1 else None}
 
-        latency = leg(lambda: pipeline(p, W, H, 1, use_native, 1), run_latency)
+        latency = leg(lambda: pipeline(p, W, H, 1, use_native, world if rotate else 1), run_latency)
+        if args.scaling == "strong":
+            scale_anchor = anchor_leg(W, H)
         if world == 1:
             def e2e(_):
                 # the frame as the host gets it, in the bench's pixel format and in the reference's own back-buffer precision
@@ -578,15 +643,39 @@ def main() -> None:
             def run4(pipe4):
                 s4 = max(min(args.steps, 4), 1)
                 e4 = timed_run(pipe4, s4, 1, world, cdev, B)
+                ok4 = last_frame_ok(pipe4, p4, W4, H4) if world > 1 else None
                 c4 = batch_counts(p4, W4, H4)
+                v4 = (c4["primary_rays"] + c4["shadow_rays"]) * s4 / e4 / 1e6
+                a4 = anchor_leg(W4, H4)
                 return {"workload": f"config4: 256^3 voxelized mesh, 3840x2160 split over {world} GPU(s)" +
-                                    (f", {strip_rows}-row interleaved strips + RCCL gather to rank 0" if world > 1 else ""),
-                        "ms_per_frame": round(e4 / (s4 * B) * 1e3, 4),
-                        "value": round((c4["primary_rays"] + c4["shadow_rays"]) * s4 / e4 / 1e6, 2), "unit": "Mrays/s",
-                        "steps": s4, "frames_per_step": B, "frames_in_flight": K}
+                                    (f", {strip_rows}-row interleaved strips + " + exchange_label(rotate, world, G, rehearsal) if world > 1 else ""),
+                        "ms_per_frame": round(e4 / (s4 * B) * 1e3, 4), "value": round(v4, 2), "unit": "Mrays/s",
+                        "steps": s4, "frames_per_step": B, "streams": K, "frames_per_launch": G,
+                        "assembled_frame_equals_single_gpu_frame": ok4, "scale_anchor": a4,
+                        "speedup_vs_anchor": round(v4 / a4["value"], 3) if world > 1 and a4 and a4.get("value") else None}
 
             config4 = leg(build4, run4)
             r.ResizeRenderOutput(W, H)
+
+    marching = no_cull = None
+    if world == 1 and args.steps > 0:
+        # How many of a frame's primary rays belong to waves that march at all: 4 out of 5 waves of the frame lie outside the
+        # host's cull rectangle (or miss the volume's active box) and go straight to the sky.  From the per-wave records of the
+        # batch's middle frame.  And the same frames with the rectangle switched off (every wave looks at the scene).
+        single_gpu_frame(p, W, H, B // 2)
+        rec = r.wave_records(0).astype(np.int64)
+        busy = (rec[:, 3] + rec[:, 4]) > 0
+        marching = {"primary_rays_in_marching_waves": int(rec[busy, 0].sum()), "primary_rays": int(rec[:, 0].sum()),
+                    "waves_marching": int(busy.sum()), "waves": int((rec[:, 0] > 0).sum())}
+        if not args.no_extra_legs:
+            pn = params(W, H)
+            pn.flags |= _abi.FLAG_NO_CULL_RECT
+            pipen = pipeline(pn, W, H, K, False)
+            sn = max(min(args.steps, 4), 1)
+            en = timed_run(pipen, sn, 1, world, cdev, B)
+            no_cull = {"ms_per_frame": round(en / (sn * B) * 1e3, 4), "value": round(rays_per_step * sn / en / 1e6, 2), "unit": "Mrays/s",
+                       "what": "the same frames with VRT_FLAG_NO_CULL_RECT: every wave loads the scene and slab-tests its rays"}
+            del pipen
 
     texel_leg = None
     if not args.no_extra_legs and args.steps > 0 and world == 1 and fmt == _abi.FORMAT_F32 and args.path == "auto":
@@ -602,7 +691,7 @@ def main() -> None:
         ct = batch_counts(pt, W, H)
         texel_leg = {"volume_format": "reference texel (sign + 15-bit |d|*100) as 16-byte cell records, --format texel16 --path cells",
                      "ms_per_frame": round(et / (st_ * B) * 1e3, 4),
-                     "value": round((ct["primary_rays"] + ct["shadow_rays"]) * st_ / et / 1e6, 2), "unit": "Mrays/s", "frames_in_flight": K}
+                     "value": round((ct["primary_rays"] + ct["shadow_rays"]) * st_ / et / 1e6, 2), "unit": "Mrays/s", "streams": K, "frames_per_launch": G}
         del pipet
         for vol in sc.volumes():
             vol.set_device_format(fmt)
@@ -613,25 +702,49 @@ def main() -> None:
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if kms else 0.0
         samples = int(t["primary_steps"] + t["shadow_steps"]) * fpl
         psteps, ssteps = cnt["primary_steps"], cnt["shadow_steps"]
-        traffic = measured_traffic(traffic_key(args, world, K, rgba8))
-        roofline = {
-            # contract fields: ALGORITHMIC bytes (32 B per trilinear sample + 192 B per hit + the pixel store)
-            # of one launch / its mean event-timed duration / the HBM peak
-            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_key": traffic_key(args, world, K, rgba8),
-            "kernel": "march_kernel", "kernel_ms": round(k_ms, 4), "frames_per_launch": fpl, "algorithmic_bytes_per_launch": int(alg_bytes),
-            "samples_per_launch": samples,
-            # physical picture: what really crosses the HBM interface, and what the kernel really waits for
-            "hbm_measured_GBps": round(traffic / (k_ms * 1e-3) / 1e9, 2) if traffic and kms else None,
-            "hbm_measured_frac": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and kms else None,
-            "hbm_measured_frac_of_ms_per_frame": round(traffic / (ms_per_step / B * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and world == 1 else None,
-            "limiter": "latency of dependent position chains (a lone frame) and vector-instruction issue (62 % of the issue slots with three frames in flight, profiles/r02_pmc_sq_tcp_tcc.txt); not HBM bandwidth",
-            "gsamples_per_s": round(samples / (k_ms * 1e-3) / 1e9, 2) if kms else None,
-            "gather_ceiling_gsamples_per_s": GATHER_CEILING_GSAMPLES,
-        }
+        key = traffic_key(args, world, K, G, rgba8)
+        pmc = measured_counters(key)
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(sc, p, args.cpu_seconds)
+        roofline = {
+            # What the counters say the kernel is on: vector-instruction issue while the chip is full, the latency of dependent
+            # position chains when it is not (a lone frame); HBM carries a few per cent of its peak (the bricks are served by L1 /
+            # L2), MFMA is not used (gather-type lookups).  The contract's fields stay what the contract defines: ALGORITHMIC bytes
+            # (32 B per trilinear sample + 192 B per hit + the pixel store) of one launch / its mean event-timed
+            # duration / the HBM peak
+            "bound": "valu-issue (vector-instruction issue slots; a lone frame: dependent-load latency) -- PMC counters; not hbm, not mfma",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_key": key,
+            "kernel": "march_kernel", "kernel_ms": round(k_ms, 4), "frames_per_launch": fpl, "algorithmic_bytes_per_launch": int(alg_bytes),
+            "samples_per_launch": samples,
+            "gsamples_per_s": round(samples / (k_ms * 1e-3) / 1e9, 2) if kms else None,
+            "gather_ceiling_gsamples_per_s": GATHER_CEILING_GSAMPLES,
+        }
+        if pmc and kms:
+            # physical picture, from the keyed PMC passes (profiles/counters_latest.json: tools/r03_profile.sh on this kernel source
+            # with these settings): what really crosses the HBM interface, and how busy the vector issue is
+            cyc = pmc.get("gpu_cycles_per_launch")  # GRBM_GUI_ACTIVE / 8 XCDs, taken under the counters' own (serialised) run
+            clock = float(pmc.get("clock_ghz") or 2.4)
+            valu = pmc.get("SQ_INSTS_VALU")
+            roofline.update({
+                "hbm_measured_GBps": round(traffic / (k_ms * 1e-3) / 1e9, 2) if traffic else None,
+                "hbm_measured_frac": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                "hbm_floor_us_per_frame": round(traffic / fpl / (HBM_PEAK_GBS * 1e9) * 1e6, 2) if traffic else None,
+                # wave-level vector instructions x 2 cycles (a wave64 op on a 32-lane SIMD, MI355X_MICROARCH.md) / 1024 SIMDs / clock /
+                # the launch's duration in THIS run
+                "valu_issue_frac": round(valu * 2.0 / 1024.0 / (clock * 1e9) / (k_ms * 1e-3), 4) if valu else None,
+                "valu_insts_per_launch": int(valu) if valu else None, "clock_ghz": round(clock, 3),
+                "occupancy_mean_waves_per_cu": pmc.get("occupancy_mean_waves_per_cu"),
+                "valu_lane_utilisation": pmc.get("valu_lane_utilisation"),
+                "counters_from": pmc.get("tag"),
+            })
+        if latency and latency.get("kernel_ms_per_frame") and cpu and cpu.get("chain_positions_max"):
+            # the lone frame: its longest chain of dependent positions (oracle, same frame) x the time a position takes
+            roofline["latency_model"] = {"chain_positions_max": cpu["chain_positions_max"],
+                                         "lone_frame_kernel_us": round(latency["kernel_ms_per_frame"] * 1e3, 1),
+                                         "us_per_position": round(latency["kernel_ms_per_frame"] * 1e3 / cpu["chain_positions_max"], 3)}
         out = {
             "metric": "Mrays/sec at 1080p, 256^3 SDF volume" if args.workload in ("c3", "c3sdf") else "Mrays/sec",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -643,26 +756,49 @@ def main() -> None:
                        "max_steps": max_steps, "shadow": bool(shadow), "k_relax": round(float(p.k_relax), 3), "data_path": args.path,
                        "output": "rgba8 (R8G8B8A8_UNORM tiles; march and shading in f32)" if rgba8 else "f32 (float4)",
                        "step": f"one batch of {B} frames: consecutive views of a camera orbiting the workload's view, 0.25 degrees apart",
-                       "frames_per_step": B, "frames_in_flight": K, "frames_per_call": G,
+                       "frames_per_step": B, "streams": K, "frames_per_launch": G,
                        "parallelism": ("1 GPU" if world == 1 else
                                        (f"{strip_rows}-row interleaved strips" if strip_rows else "contiguous row tiles") +
-                                       f" x{world} + " + ("gloo gather, REHEARSAL on one GPU" if rehearsal else f"one RCCL gather to rank 0 per block of {G} frames")),
+                                       f" x{world} + " + exchange_label(rotate, world, G, rehearsal)),
                        "rays_per_step": int(rays_per_step), "rays_per_frame": int(rays_per_frame),
+                       # (the waves of a frame that lie outside the host's cull rectangle go straight to the sky: their pixels count as
+                       # primary rays, like the reference's DispatchRays(W, H) counts them; how many rays sit in waves that march:)
+                       "marching": marching,
                        "samples_per_ray": round((psteps + ssteps) / max(rays_per_step, 1), 2)},
             "roofline": roofline, "cpu_baseline": cpu,
-            "latency": latency, "end_to_end": end_to_end, "config4": config4, "reference_texel_format": texel_leg,
+            "latency": latency, "scale_anchor": scale_anchor, "end_to_end": end_to_end, "config4": config4, "reference_texel_format": texel_leg,
+            "no_cull_rect": no_cull,
         }
         if world > 1:
-            out["gather"] = ("native (vrt_gather_tiles: ncclGather on the march stream)" if use_native else
-                             "torch.distributed.gather (" + ("gloo, REHEARSAL" if rehearsal else "RCCL") + ")")
+            out["speedup_vs_anchor"] = round(value / scale_anchor["value"], 3) if scale_anchor and scale_anchor.get("value") else None
+            out["collective"] = ("native (vrt_gather_tiles / vrt_exchange_tiles on the march stream)" if use_native else
+                                 "torch.distributed (" + ("gloo, REHEARSAL" if rehearsal else "RCCL") + ")")
             out["native_gather_check"] = native_check if native_check is not None else ({"error": native_error} if native_error else None)
+            out["other_exchange"] = exchange_other
         if verified is not None:
-            out["gathered_frame_equals_single_gpu_frame"] = verified
+            out["assembled_frame_equals_single_gpu_frame"] = verified
         print(json.dumps(out), flush=True)
 
     r.Stop()
     if world > 1:
         dist.destroy_process_group()
+
+
+MULTI_STREAMS = 2          # N > 1: streams per rank (a block's collective overlaps the next block's march)
+ANCHOR_BLOCK_FRAMES = 24   # frames per launch of the one-GPU scale anchor (= the N-GPU block for N = 2, 4, 8)
+
+
+def multi_block_frames(world: int) -> int:
+    """Frames per block (= per march launch and per collective) of an N-GPU run: about 24, a multiple of N (rotating roots deal
+    whole frames to the ranks)."""
+    return world * max(1, round(24 / world))
+
+
+def exchange_label(rotate: bool, world: int, G: int, rehearsal: bool) -> str:
+    how = "gloo, REHEARSAL on one GPU" if rehearsal else "RCCL"
+    if rotate:
+        return f"one all-to-all ({how}) per block of {G} frames: frame g of a block is assembled on rank g // {max(G // world, 1)}"
+    return f"one gather ({how}) to rank 0 per block of {G} frames"
 
 
 def end_to_end_leg(r, p, rays_per_frame: float, steps: int):
@@ -712,6 +848,26 @@ def cpu_baseline(sc, p, target_seconds: float):
         dt = time.perf_counter() - t0
         if dt >= target_seconds or frames >= 10000:
             break
+    # the longest chain of dependent march positions a lane of the GPU frame runs (primary ray + the rays after it): one whole
+    # frame at full size with the oracle's debug position image (the oracle visits exactly the positions the kernel visits)
+    chain = None
+    try:
+        import ctypes as C
+
+        import numpy as np
+
+        from oracle import binding
+        lib = binding.load()
+        lib.vrto_debug_set_steps_image.argtypes = [C.c_void_p]
+        img = np.zeros((p.height, p.width), np.uint32)
+        lib.vrto_debug_set_steps_image(img.ctypes.data)
+        try:
+            o.render(p, threads=cores)
+        finally:
+            lib.vrto_debug_set_steps_image(None)
+        chain = int(((img & 0xFFFF).astype(np.int64) + (img >> 16).astype(np.int64)).max())
+    except Exception:  # noqa: BLE001
+        chain = None
     q1 = _abi.vrt_params.from_buffer_copy(p)
     q1.width, q1.height = max(p.width // 4, 1), max(p.height // 4, 1)
     t1 = time.perf_counter()
@@ -723,6 +879,7 @@ def cpu_baseline(sc, p, target_seconds: float):
                   f"({rays} rays, {dt:.1f} s wall on {cores} threads)",
         "single_thread_value": round((st1["primary_rays"] + st1["shadow_rays"]) / dt1 / 1e6, 3),
         "single_thread_sample": f"one {q1.width}x{q1.height} frame, {dt1:.1f} s",
+        "chain_positions_max": chain,
     }
 
 

@@ -57,6 +57,8 @@ extern "C" {
 
 #define VRT_FLAG_BLOCK_PER_FRAME 64 /* vrt_render_block: one march launch per frame, back to back on the stream, instead of ONE launch
                                       for the block's frames (A/B measurements and tests; same pixels) */
+#define VRT_FLAG_NO_CULL_RECT 128 /* the host computes no cull rectangle: every wave looks at the scene and slab-tests its rays
+                                    (measurements of what the rectangle saves; same pixels) */
 #define VRT_FLAG_NO_TIMING 16    /* the launch records no event pair: vrt_last_timing / vrt_timing_history report 0 ms for it.
                                    An event pair costs 5-7 us of queue time per launch (profiles/r02_launch_overhead.txt);
                                    callers that keep many small launches in flight time a sample of them */
@@ -180,7 +182,8 @@ typedef struct vrt_params {
     int32_t flags;        /* bits 0-1: blockIdx→tile map, 0 supertile (default) / 1 XCD band / 2 linear
                              (speed only, never results); bit 2: VRT_FLAG_DIAG_TIMELINE; bit 3:
                              VRT_FLAG_OUTPUT_RGBA8; bit 4: VRT_FLAG_NO_TIMING; bit 5: accepted and ignored (it was round 1's
-                             VRT_FLAG_SKIP_EMPTY: the march never samples empty cells now); bit 6: VRT_FLAG_BLOCK_PER_FRAME.  Others 0 */
+                             VRT_FLAG_SKIP_EMPTY: the march never samples empty cells now); bit 6: VRT_FLAG_BLOCK_PER_FRAME; bit 7: VRT_FLAG_NO_CULL_RECT.
+                             Others 0 */
     float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
     float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
     float step_min;       /* lower bound of one march step (ray-parameter units) */
@@ -211,10 +214,11 @@ typedef struct vrt_timing {
 
 typedef struct vrt_ctx vrt_ctx;
 
-/* device_count >= 1; devices[i] are HIP ordinals.  One context may drive 1..8 devices: vrt_render deals the frame's 32-row
+/* device_count >= 1; devices[i] are HIP ordinals.  One context may drive 1..8 devices: vrt_render deals the frame's 8-row
  * strips round-robin to them (device g renders strips g, g+n, ...; contiguous tiles would put every object row on the middle
  * devices), volumes are replicated, and every device copies its strips into device 0's frame over the peer links as soon as
- * its own march is done.  One process per GPU uses vrt_render_strips + vrt_gather_tiles instead. */
+ * its own march is done — one strided copy per device, joined to device 0's stream by events.  One process per GPU
+ * uses vrt_render_strips / vrt_render_block + vrt_gather_tiles / vrt_exchange_tiles instead. */
 int vrt_create(vrt_ctx** out, int device_count, const int* devices);
 int vrt_destroy(vrt_ctx* ctx);
 
@@ -341,12 +345,20 @@ int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* bl
  *   vrt_comm_init        every rank: ncclCommInitRank on the context's first device; collective, blocks until all joined
  *   vrt_gather_tiles     asynchronously on hip_stream: every rank contributes tile_bytes from device_tile; on `root`,
  *                        device_frame receives world x tile_bytes, rank-major (other ranks pass NULL).  In-order with the
- *                        march launches of the same stream: no host synchronisation */
+ *                        march launches of the same stream: no host synchronisation
+ *   vrt_exchange_tiles   the all-to-all form of the same exchange, for frames that are assembled on DIFFERENT ranks (frame g of a
+ *                        block on rank g / m): device_tiles holds world chunks of chunk_bytes, chunk d goes to rank d;
+ *                        device_recv receives world chunks, chunk s from rank s.  One group of ncclSend / ncclRecv
+ *                        (rccl.h:690-725).  A gather onto ONE rank moves (world-1)/world of every frame over that rank's inbound
+ *                        xGMI links (7 x ~77 GB/s): at 8.3 MB per RGBA8 1080p frame that caps an 8-GPU job near 60 000
+ *                        frames/s whatever the march does; spread over all ranks the same bytes use every link of the node
+ * librccl's version is checked when it is first resolved: anything but major version 2 disables these entry points. */
 #define VRT_COMM_ID_BYTES 128
 int vrt_comm_unique_id(void* id_out);
 int vrt_comm_init(vrt_ctx* ctx, int world, int rank, const void* id);
 int vrt_comm_destroy(vrt_ctx* ctx);
 int vrt_gather_tiles(vrt_ctx* ctx, const void* device_tile, void* device_frame_or_null, size_t tile_bytes, int root, void* hip_stream);
+int vrt_exchange_tiles(vrt_ctx* ctx, const void* device_tiles, void* device_recv, size_t chunk_bytes, void* hip_stream);
 
 /* Pipelined rendering — the reference keeps FrameCount = 3 frames in flight and paces them with fences
  * (DXConstants.cpp:23, DXRenderer.cpp:974-989); a frame's last third is a few latency-bound waves, which the next frame's

@@ -218,6 +218,74 @@ def test_block_of_frames_per_gather(world, height, strip_rows, G):
         assert torch.equal(got[:, 1, 2], 1000.0 * g + torch.arange(height, dtype=torch.float32)), g
 
 
+def _rotate_worker(rank, world, port, height, width, strip_rows, m, out_dir):
+    """One rank of the rotating-root exchange over gloo: tiles of a block of G = m x world frames, every row tagged with
+    (frame of the block, frame row); after ONE all-to-all and the un-shuffle this rank holds ITS m frames whole."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from volumetricraytracer_amd.tiles import FrameGather, strip_frame_rows, tile_rows
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        G = m * world
+        fg = FrameGather(height, width, world, rank, torch.device("cpu"), dtype=torch.float32, buffers=2, strip_rows=strip_rows,
+                         frames_per_gather=G, rotate_roots=True)
+        assert fg.rotate and fg.m == m and [fg.root_of(g) for g in range(G)] == [g // m for g in range(G)]
+        if strip_rows > 0:
+            spans = strip_frame_rows(height, world, rank, strip_rows)
+        else:
+            _, row0, rows = tile_rows(height, world, rank)
+            spans = [(0, row0, rows)] if rows > 0 else []
+        for b in range(2):
+            for g in range(G):
+                tile = fg.tile(b, g)
+                tile.fill_(-1.0)
+                for local0, frame0, rows in spans:
+                    tile[local0:local0 + rows] = (100000.0 * b + 1000.0 * g + torch.arange(frame0, frame0 + rows, dtype=torch.float32))[:, None, None]
+            fg.gather(b, async_op=True).wait()
+            fg.unshuffle(b)
+        ok = True
+        for b in range(2):
+            for g in range(G):
+                got = fg.frame(b, g)
+                if fg.root_of(g) != rank:
+                    ok = ok and got is None
+                    continue
+                want = 100000.0 * b + 1000.0 * g + torch.arange(height, dtype=torch.float32)
+                ok = ok and got.shape == (height, width, 4) and bool(torch.equal(got[:, width - 1, 3], want))
+        np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.array([1 if ok else 0]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height,strip_rows,m", [(2, 54, 8, 2), (3, 50, 4, 1), (2, 37, 0, 3), (3, 1080, 8, 2)])
+def test_rotating_roots_exchange_assembles_every_frame_on_its_rank(tmp_path, world, height, strip_rows, m):
+    """FrameGather(rotate_roots=True): ONE all_to_all_single per block of m x world frames; frame g ends up whole on rank
+    g // m (strips un-shuffled there), with ragged last strips, empty strip slots and contiguous tiles; nobody else has it."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_rotate_worker, args=(world, _free_port(), height, 5, strip_rows, m, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        assert int(np.load(str(tmp_path / f"ok{rank}.npy"))[0]) == 1, rank
+
+
+def test_rotating_roots_reject_a_block_that_does_not_deal_out():
+    import torch
+
+    from volumetricraytracer_amd.tiles import FrameGather
+
+    with pytest.raises(ValueError):
+        FrameGather(16, 4, 3, 0, torch.device("cpu"), frames_per_gather=4, rotate_roots=True)
+    # one rank: nothing to rotate
+    fg = FrameGather(16, 4, 1, 0, torch.device("cpu"), frames_per_gather=4, rotate_roots=True)
+    assert not fg.rotate and fg.root_of(3) == 0 and fg.frame(0, 3).shape == (16, 4, 4)
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver calls it) must start two ranks itself: the launch
     path without a march (--launch-check: gloo rendezvous, strip layout, gather, un-shuffle, max-over-ranks), runnable

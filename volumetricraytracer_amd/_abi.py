@@ -42,6 +42,7 @@ FLAG_DIAG_TIMELINE = 4
 FLAG_OUTPUT_RGBA8 = 8
 FLAG_NO_TIMING = 16
 FLAG_BLOCK_PER_FRAME = 64
+FLAG_NO_CULL_RECT = 128
 MAX_BLOCK_FRAMES = 48  # frames one march launch covers (csrc/vrt_device.h kMaxBlockFrames)
 
 FORMAT_F32 = 0
@@ -193,6 +194,7 @@ SYMBOLS = {
     "vrt_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vrt_comm_destroy": (C.c_int, [C.c_void_p]),
     "vrt_gather_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "vrt_exchange_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vrt_render_begin": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int]),
     "vrt_render_end": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "vrt_last_timing": (C.c_int, [C.c_void_p, C.POINTER(vrt_timing)]),

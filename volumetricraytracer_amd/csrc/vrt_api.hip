@@ -32,9 +32,18 @@ using namespace vrt;
 namespace {
 
 /* RCCL, resolved at run time (librccl is not a link-time dependency: the library loads on hosts without it).  Only what
-   the tile gather needs; signatures from /opt/rocm/include/rccl/rccl.h:187,220,260,339,745. */
+   the tile exchange needs; signatures from /opt/rocm/include/rccl/rccl.h:164,187,220,260,339,700,722,745,910-920.  The
+   function pointers below are declared by hand, so the library's version is checked once: only major version 2 (the API these
+   signatures and the value of ncclUint8 = 1, rccl.h:460, belong to) is accepted. */
+constexpr int kNcclUint8 = 1;
 struct RcclApi {
     typedef struct { char internal[VRT_COMM_ID_BYTES]; } UniqueId;
+    int (*GetVersion)(int*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int version = 0;
     int (*GetUniqueId)(UniqueId*) = nullptr;
     int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
@@ -56,7 +65,23 @@ RcclApi* rccl() {
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     api.Gather = reinterpret_cast<decltype(api.Gather)>(dlsym(h, "ncclGather"));
-    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GetErrorString && api.Gather;
+    api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(h, "ncclGetVersion"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    api.Send = reinterpret_cast<decltype(api.Send)>(dlsym(h, "ncclSend"));
+    api.Recv = reinterpret_cast<decltype(api.Recv)>(dlsym(h, "ncclRecv"));
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GetErrorString && api.Gather && api.GetVersion && api.GroupStart &&
+             api.GroupEnd && api.Send && api.Recv;
+    if (api.ok) {
+        /* NCCL_VERSION_CODE: major * 10000 + minor * 100 + patch from 2.9 on, major * 1000 + minor * 100 + patch before (rccl.h:20) */
+        int v = 0;
+        const int major = api.GetVersion(&v) == 0 ? (v >= 10000 ? v / 10000 : v / 1000) : -1;
+        api.version = v;
+        if (major != 2) {
+            fprintf(stderr, "[vrt] librccl reports version code %d (major %d): only major version 2 is known to this build; the multi-GPU exchange is disabled\n", v, major);
+            api.ok = false;
+        }
+    }
     return api.ok ? &api : nullptr;
 }
 
@@ -145,6 +170,7 @@ struct DeviceState {
     int last_blocks = 0;         /* workgroups per frame of the last launch */
     int last_frames = 1;         /* frames of the last launch: vrt_last_timing / vrt_debug_wave_records read its LAST frame's records */
     bool last_diag = false;
+    hipEvent_t joined = nullptr; /* multi-device vrt_render: this device's strips have arrived in device 0's frame */
     hipEvent_t ev0[kRing];
     hipEvent_t ev1[kRing];
     FrameSlot slot[VRT_FRAMES_IN_FLIGHT];
@@ -507,6 +533,7 @@ void destroy_device(DeviceState& D) {
         if (D.d_stats[i]) (void)hipFree(D.d_stats[i]);
     for (unsigned* r : D.stats_retired) (void)hipFree(r);
     if (D.d_diag) (void)hipFree(D.d_diag);
+    if (D.joined) (void)hipEventDestroy(D.joined);
     if (D.events_ok)
         for (int i = 0; i < kRing; i++) {
             (void)hipEventDestroy(D.ev0[i]);
@@ -676,7 +703,7 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
     if (p->mode < VRT_MODE_INTERP || p->mode > VRT_MODE_CUBE_NOTEX_UNLIT) return VRT_ERR_INVALID;
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_CELLS) return VRT_ERR_INVALID;
     /* (bit 5 was round 1's VRT_FLAG_SKIP_EMPTY: empty-space skipping is always on now; the bit is accepted and ignored) */
-    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_NO_TIMING | 32 | VRT_FLAG_BLOCK_PER_FRAME)) != 0 || (p->flags & 3) == 3)
+    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_NO_TIMING | 32 | VRT_FLAG_BLOCK_PER_FRAME | VRT_FLAG_NO_CULL_RECT)) != 0 || (p->flags & 3) == 3)
         return VRT_ERR_INVALID;
     if (!ctx->have_scene) return VRT_ERR_NOT_READY;
     return VRT_OK;
@@ -714,6 +741,7 @@ void cull_rect(const vrt_ctx* ctx, const vrt_params* p, DCam& F) {
     /* (frames are at most 16384 pixels wide and high: 16 bits per coordinate) */
     F.cull_lo = pack_cull(0, 0);
     F.cull_hi = pack_cull(p->width - 1, p->height - 1);
+    if (p->flags & VRT_FLAG_NO_CULL_RECT) return;
     double x0 = 1e30, y0 = 1e30, x1 = -1e30, y1 = -1e30;
     for (int i = 0; i < ctx->scene.n_instances; i++) {
         const HostVolume& h = ctx->vol[ctx->scene.instances[i].volume_slot];
@@ -1277,9 +1305,10 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
     const size_t row_bytes = (size_t)W * ((params->flags & VRT_FLAG_OUTPUT_RGBA8) ? 4 : 4 * sizeof(float));
     auto t0 = std::chrono::steady_clock::now();
 
-    /* One device: the whole frame.  Several: 32-row strips dealt round-robin (device g renders strips g, g+n, ... into
-       a compact tile) — contiguous tiles would put every object row on the middle devices */
-    constexpr int kStripRows = 32;
+    /* One device: the whole frame.  Several: 8-row strips (one row of waves, what bench.py's ranks use: samples max / mean over 8
+       devices 1.02 against 1.17 with 32-row strips, profiles/r02_strip_balance_c3.txt) dealt round-robin (device g renders
+       strips g, g+n, ... into a compact tile) — contiguous tiles would put every object row on the middle devices */
+    constexpr int kStripRows = 8;
     const int total_strips = (H + kStripRows - 1) / kStripRows;
     const int strips_per = n > 1 ? (total_strips + n - 1) / n : 0;
     const int tile_rows = n > 1 ? strips_per * kStripRows : H;
@@ -1332,25 +1361,42 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
     float gather_ms = 0.f;
     if (n > 1) {
         /* every device copies its strips into device 0's frame over the peer links right behind its own march, in its own
-           stream: no host synchronisation between march and gather, a device that is done early transfers while the others
-           still march.  gather_ms = what the frame waits for after the slowest march has finished. */
+           stream: ONE strided 2D copy per device (a "row" of the copy is one strip: contiguous in the compact tile, n strips
+           apart in the frame) plus one plain copy when the frame ends inside the device's last strip.  No host synchronisation
+           between march and gather: a device that is done early transfers while the others still march; device 0's stream then
+           waits for every device's event, and the host waits for device 0 alone.  gather_ms = what the frame waits for after the
+           slowest march has finished. */
+        const size_t strip_bytes = (size_t)kStripRows * row_bytes;
         for (int g = 0; g < n; g++) {
             DeviceState& D = ctx->dev[(size_t)g];
             HIP_TRY(hipSetDevice(D.ordinal));
-            for (int k = 0; k < strips_per; k++) {
-                const int frame_row = (k * n + g) * kStripRows;
-                const int rows = std::min(kStripRows, H - frame_row);
-                if (rows <= 0) break;
-                char* dst = reinterpret_cast<char*>(ctx->gather) + (size_t)frame_row * row_bytes;
-                const char* src = reinterpret_cast<const char*>(D.fb) + (size_t)k * kStripRows * row_bytes;
-                HIP_TRY(hipMemcpyPeerAsync(dst, ctx->dev[0].ordinal, src, D.ordinal, (size_t)rows * row_bytes, D.stream));
+            int whole = 0; /* strips of this device that lie wholly inside the frame */
+            while (whole < strips_per && ((whole * n + g) + 1) * kStripRows <= H) whole++;
+            char* dst = reinterpret_cast<char*>(ctx->gather) + (size_t)g * strip_bytes;
+            const char* src = reinterpret_cast<const char*>(D.fb);
+            if (whole > 0 && hipMemcpy2DAsync(dst, (size_t)n * strip_bytes, src, strip_bytes, strip_bytes, (size_t)whole, hipMemcpyDeviceToDevice,
+                                              D.stream) != hipSuccess) {
+                (void)hipGetLastError(); /* no direct peer mapping between the two devices: strip by strip through hipMemcpyPeerAsync */
+                for (int k = 0; k < whole; k++)
+                    HIP_TRY(hipMemcpyPeerAsync(dst + (size_t)k * n * strip_bytes, ctx->dev[0].ordinal, src + (size_t)k * strip_bytes, D.ordinal,
+                                               strip_bytes, D.stream));
+            }
+            const int frame_row = (whole * n + g) * kStripRows;
+            if (whole < strips_per && frame_row < H) /* the frame's last, partial strip */
+                HIP_TRY(hipMemcpyPeerAsync(reinterpret_cast<char*>(ctx->gather) + (size_t)frame_row * row_bytes, ctx->dev[0].ordinal,
+                                           src + (size_t)whole * strip_bytes, D.ordinal, (size_t)(H - frame_row) * row_bytes, D.stream));
+            if (g > 0) {
+                if (!D.joined) HIP_TRY(hipEventCreateWithFlags(&D.joined, hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(D.joined, D.stream));
             }
         }
+        HIP_TRY(hipSetDevice(ctx->dev[0].ordinal));
+        for (int g = 1; g < n; g++) HIP_TRY(hipStreamWaitEvent(ctx->dev[0].stream, ctx->dev[(size_t)g].joined, 0));
+        HIP_TRY(hipStreamSynchronize(ctx->dev[0].stream));
         float march_ms = 0.f;
         for (int g = 0; g < n; g++) {
             DeviceState& D = ctx->dev[(size_t)g];
             HIP_TRY(hipSetDevice(D.ordinal));
-            HIP_TRY(hipStreamSynchronize(D.stream));
             float ms = 0.f;
             if (D.timed[ring] && hipEventElapsedTime(&ms, D.ev0[ring], D.ev1[ring]) == hipSuccess) march_ms = std::max(march_ms, ms);
         }
@@ -1426,9 +1472,32 @@ int vrt_gather_tiles(vrt_ctx* ctx, const void* device_tile, void* device_frame_o
     RcclApi* R = rccl();
     if (!R) return VRT_ERR_UNSUPPORTED;
     HIP_TRY(hipSetDevice(ctx->dev[0].ordinal));
-    const int rc = R->Gather(device_tile, device_frame_or_null, tile_bytes, 1 /* ncclUint8 */, root, ctx->comm, static_cast<hipStream_t>(hip_stream));
+    const int rc = R->Gather(device_tile, device_frame_or_null, tile_bytes, kNcclUint8, root, ctx->comm, static_cast<hipStream_t>(hip_stream));
     if (rc != 0) {
         fprintf(stderr, "[vrt] ncclGather failed: %s\n", R->GetErrorString(rc));
+        return VRT_ERR_HIP;
+    }
+    return VRT_OK;
+}
+
+int vrt_exchange_tiles(vrt_ctx* ctx, const void* device_tiles, void* device_recv, size_t chunk_bytes, void* hip_stream) {
+    if (!ctx || !ctx->comm) return VRT_ERR_NOT_READY;
+    if ((!device_tiles || !device_recv) && chunk_bytes > 0) return VRT_ERR_INVALID;
+    RcclApi* R = rccl();
+    if (!R) return VRT_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->dev[0].ordinal));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    /* one group: every rank's sends and receives progress together (rccl.h:690-691); chunk d of my buffer goes to rank d, chunk
+       s of the receive buffer comes from rank s (the own chunk is a device copy inside RCCL) */
+    int rc = R->GroupStart();
+    for (int peer = 0; rc == 0 && peer < ctx->comm_world; peer++) {
+        rc = R->Send(static_cast<const char*>(device_tiles) + (size_t)peer * chunk_bytes, chunk_bytes, kNcclUint8, peer, ctx->comm, stream);
+        if (rc == 0) rc = R->Recv(static_cast<char*>(device_recv) + (size_t)peer * chunk_bytes, chunk_bytes, kNcclUint8, peer, ctx->comm, stream);
+    }
+    const int rc_end = R->GroupEnd();
+    if (rc == 0) rc = rc_end;
+    if (rc != 0) {
+        fprintf(stderr, "[vrt] ncclSend/ncclRecv group failed: %s\n", R->GetErrorString(rc));
         return VRT_ERR_HIP;
     }
     return VRT_OK;

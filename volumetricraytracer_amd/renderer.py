@@ -300,6 +300,13 @@ class VHipRenderer:
         _abi.check(self._lib.vrt_gather_tiles(self._ctx, C.c_void_p(tile_ptr), C.c_void_p(frame_ptr) if frame_ptr else None, int(tile_bytes),
                                               int(root), C.c_void_p(stream)), "vrt_gather_tiles")
 
+    def exchange_tiles(self, tiles_ptr: int, recv_ptr: int, chunk_bytes: int, stream: int = 0) -> None:
+        """Asynchronous all-to-all of equal chunks (vrt_exchange_tiles): chunk d of `tiles_ptr` goes to rank d, chunk s of
+        `recv_ptr` comes from rank s."""
+        self._require()
+        _abi.check(self._lib.vrt_exchange_tiles(self._ctx, C.c_void_p(tiles_ptr), C.c_void_p(recv_ptr), int(chunk_bytes), C.c_void_p(stream)),
+                   "vrt_exchange_tiles")
+
     def last_timing(self) -> dict:
         self._require()
         t = _abi.vrt_timing()

@@ -13,7 +13,14 @@ The tiles are equal-sized buffers gathered with ONE collective: `torch.distribut
 `vrt_gather_tiles` (ncclGather on the march stream, no torch in the data path).  For strips rank 0 then
 un-shuffles the gathered [rank, strip] order into frame order with one strided device copy.  A buffer may hold
 a BLOCK of several frames' tiles (`frames_per_gather`): one collective then moves the whole block — what
-bench.py does, because at a few tens of microseconds per frame the per-call cost of a collective bounds the job."""
+bench.py does, because at a few tens of microseconds per frame the per-call cost of a collective bounds the job.
+
+`rotate_roots`: the frames of a block are assembled on DIFFERENT ranks — frame g of a block of G = m x world frames on rank
+g // m — with ONE all-to-all per block (`torch.distributed.all_to_all_single`, or `vrt_exchange_tiles`: grouped
+ncclSend / ncclRecv).  A gather onto one rank moves (world - 1) / world of every frame over that rank's inbound xGMI links:
+8.3 MB of RGBA8 per 1080p frame against about 0.5 TB/s of inbound links caps the job near 60 000 frames/s whatever the march
+does, while 8 GPUs march 160 000; spread over all ranks the same bytes use every link of the node.  Each frame still ends up
+whole on one GPU."""
 from __future__ import annotations
 
 from typing import List, Optional, Tuple
@@ -59,13 +66,18 @@ class FrameGather:
     `dtype` float32 → [rows, W, 4] float RGBA; uint8 → [rows, W, 4] R8G8B8A8."""
 
     def __init__(self, height: int, width: int, world: int, rank: int, device, dtype=None, buffers: int = 2,
-                 strip_rows: int = 0, frames_per_gather: int = 1):
+                 strip_rows: int = 0, frames_per_gather: int = 1, rotate_roots: bool = False):
         """frames_per_gather = G > 1: a buffer holds a BLOCK of G frames' tiles ([G, rows, W, 4]) and one gather moves the whole
         block (fewer, larger collectives: at a few tens of microseconds per frame the per-call cost of a collective is what
-        bounds an N-GPU job); tile(b, g) / frame(b, g) address frame g of block b."""
+        bounds an N-GPU job); tile(b, g) / frame(b, g) address frame g of block b.
+        rotate_roots (G a multiple of world, m = G / world): frame g of a block is assembled on rank g // m by one all-to-all
+        per block (exchange()); every rank then holds ITS m frames: frame(b, g) is valid on rank root_of(g) only."""
         import torch
 
         self.height, self.width, self.world, self.rank = height, width, world, rank
+        self.rotate = bool(rotate_roots) and world > 1
+        if self.rotate and (frames_per_gather < world or frames_per_gather % world != 0):
+            raise ValueError("rotate_roots needs a block of a multiple of `world` frames")
         self.strip_rows = int(strip_rows)
         if self.strip_rows > 0:
             self.total_strips, self.strips_per = strip_layout(height, world, self.strip_rows)
@@ -80,7 +92,17 @@ class FrameGather:
         self.final: Optional[List] = None   # strips only: frame-ordered copies
         self._glist = None      # per buffer: the views torch.distributed.gather receives into (built once, not per frame)
         self._unshuffle = None  # per buffer: (source view, destination view) of the strip un-shuffle
-        if world > 1 and rank == 0:
+        self.m = G // world if self.rotate else G  # frames of a block this rank assembles
+        if self.rotate:
+            m = self.m
+            # received: [source rank, my frame of the block, rows of a tile] — the layout a gather of my m frames would give
+            self.frames = [torch.zeros((world * m * self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
+            if self.strip_rows > 0:
+                self.final = [torch.zeros((m * world * self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
+                n, per, sr = world, self.strips_per, self.strip_rows
+                self._unshuffle = [(f.view(n, m, per, sr, width, 4).permute(1, 2, 0, 3, 4, 5), g.view(m, per, n, sr, width, 4))
+                                   for f, g in zip(self.frames, self.final)]
+        elif world > 1 and rank == 0:
             # gathered: [rank, frame of the block, rows of a tile]
             self.frames = [torch.zeros((world * G * self.rows_per, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
             self._glist = [[f[k * G * self.rows_per:(k + 1) * G * self.rows_per] for k in range(world)] for f in self.frames]
@@ -91,12 +113,19 @@ class FrameGather:
                 self._unshuffle = [(f.view(n, G, per, sr, width, 4).permute(1, 2, 0, 3, 4, 5), g.view(G, per, n, sr, width, 4))
                                    for f, g in zip(self.frames, self.final)]
 
+    def root_of(self, g: int) -> int:
+        """The rank that assembles frame g of a block."""
+        return g // self.m if self.rotate else 0
+
     def gather(self, b: int, async_op: bool = False):
-        """Gather tile buffer `b` of every rank into frame buffer `b` on rank 0."""
+        """Gather tile buffer `b` of every rank into frame buffer `b` on rank 0 — or, with rotate_roots, exchange the block so
+        that every rank receives all tiles of its own m frames (one all-to-all)."""
         import torch.distributed as dist
 
         if self.world == 1:
             return None
+        if self.rotate:
+            return dist.all_to_all_single(self.frames[b], self.tiles[b], async_op=async_op)
         return dist.gather(self.tiles[b], self._glist[b] if self.rank == 0 else None, dst=0, async_op=async_op)
 
     def native_gather(self, renderer, b: int, stream: int = 0) -> None:
@@ -104,15 +133,18 @@ class FrameGather:
         `stream` behind the march that produced tile buffer `b`.  The renderer must have joined a communicator
         (VHipRenderer.comm_init) of `world` ranks."""
         tile = self.tiles[b]
-        frame_ptr = self.frames[b].data_ptr() if self.rank == 0 and self.frames is not None else 0
         if self.world == 1:
             return
+        if self.rotate:  # vrt_exchange_tiles: chunk d of my tile buffer (my tiles of rank d's frames) goes to rank d
+            renderer.exchange_tiles(tile.data_ptr(), self.frames[b].data_ptr(), tile.numel() * tile.element_size() // self.world, stream)
+            return
+        frame_ptr = self.frames[b].data_ptr() if self.rank == 0 and self.frames is not None else 0
         renderer.gather_tiles(tile.data_ptr(), frame_ptr, tile.numel() * tile.element_size(), 0, stream)
 
     def unshuffle(self, b: int) -> None:
         """Strips, rank 0: gathered [rank, strip, row] order → frame order, one strided copy on the
         current stream (after the gather of buffer `b` has completed)."""
-        if self.strip_rows == 0 or self.world == 1 or self.rank != 0:
+        if self.strip_rows == 0 or self.world == 1 or (self.rank != 0 and not self.rotate):
             return
         src, dst = self._unshuffle[b]
         dst.copy_(src)
@@ -125,9 +157,16 @@ class FrameGather:
         """The assembled H x W x 4 frame g of buffer (block) b (rank 0 only; for strips call unshuffle(b) first)."""
         if self.world == 1:
             return self.tile(b, g)[: self.height]
+        full = self.world * self.rows_per
+        if self.rotate:  # my j-th frame of the block
+            if self.root_of(g) != self.rank:
+                return None
+            j = g - self.rank * self.m
+            if self.strip_rows > 0:
+                return self.final[b][j * full: j * full + self.height]
+            return self.frames[b].view(self.world, self.m, self.rows_per, self.width, 4)[:, j].reshape(full, self.width, 4)[: self.height]
         if self.rank != 0:
             return None
-        full = self.world * self.rows_per
         if self.strip_rows > 0:
             return self.final[b][g * full: g * full + self.height]
         if self.G == 1:
