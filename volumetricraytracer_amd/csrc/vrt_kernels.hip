@@ -21,6 +21,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include "vrt_device.h"
 #include "vrt_launch.h"
 #include "voxelize_core.h"
@@ -1176,6 +1177,10 @@ __device__ __forceinline__ int frame_row(const DFrame& F, int pyl) {
     return F.row0 + pyl;
 }
 
+/* (Round 3 experiment, removed: ONE wave rendering a whole 16x16 sky tile — four pixels per lane — while the tile's other three
+ * waves end at once.  Letting three out of four sky waves end at once changes nothing (41.1 against 41.0 us per frame: the sky
+ * waves only fill wave slots the marching waves leave empty), and the four-pixel sky wave made the frame 20 % slower:
+ * profiles/r03_sky_tile_and_occupancy_experiments.txt.) */
 template <int PATH, bool SINGLE, bool DIAG>
 __global__ __launch_bounds__(kMarchThreads) void march_kernel(const DBlock B) {
     unsigned long long t_start = 0;
@@ -2015,15 +2020,25 @@ __global__ void split_voxels_kernel(const uint2* __restrict__ voxels, float* __r
 
 /* ---- launch wrappers (host) -------------------------------------------------------------- */
 
+/* A/B only (VRT_AB_LDS_BYTES in the environment): dynamic LDS per one-wave workgroup that the kernel never touches, to cap the
+ * number of resident waves per CU (160 KB of LDS per CU) without changing a line of kernel code. */
+static unsigned ab_lds_bytes() {
+    static const unsigned v = [] {
+        const char* e = getenv("VRT_AB_LDS_BYTES");
+        return e ? (unsigned)strtoul(e, nullptr, 10) : 0u;
+    }();
+    return v;
+}
+
 template <int PATH, bool SINGLE>
 static hipError_t launch_t(const DBlock& B, hipStream_t stream) {
     const DFrame& F = B.f;
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
     if (F.diag)
-        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, true>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), 0, stream, B);
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, true>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), ab_lds_bytes(), stream, B);
     else
-        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), 0, stream, B);
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), ab_lds_bytes(), stream, B);
     return hipGetLastError();
 }
 
@@ -2033,7 +2048,7 @@ static hipError_t launch_nodiag_t(const DBlock& B, hipStream_t stream) {
     const DFrame& F = B.f;
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), 0, stream, B);
+    hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), ab_lds_bytes(), stream, B);
     return hipGetLastError();
 }
 
@@ -2053,7 +2068,7 @@ static hipError_t launch_full_t(const DBlock& B, hipStream_t stream) {
     const DFrame& F = B.f;
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), 0, stream, B);
+    hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), ab_lds_bytes(), stream, B);
     return hipGetLastError();
 }
 
