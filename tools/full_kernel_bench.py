@@ -16,15 +16,14 @@ for name, sc, bounces in (("config 3 volume, Cube mode (exact voxel walk, lean k
     mode=_abi.MODE_INTERP if name=="textured" else (_abi.MODE_CUBE_NOTEX if "Cube mode" in name else _abi.MODE_INTERP_NOTEX)
     p=v.default_params(W,H,workloads.min_cell(sc),255,shadow=True,mode=mode); p.max_bounces=bounces
     r=v.VHipRenderer(); assert r.Start(); r.SetSceneToRender(sc); r.ResizeRenderOutput(W,H); r.SyncWithScene()
-    streams=[torch.cuda.Stream() for _ in range(3)]
-    bufs=[torch.empty((2,H,W,4),dtype=torch.float32,device="cuda:0") for _ in range(3)]
+    G=_abi.MAX_BLOCK_FRAMES  # ONE launch per block of 48 frames, one stream
+    buf=torch.empty((G,H,W,4),dtype=torch.float32,device="cuda:0")
     def run(n):
         for i in range(n):
-            b=i%3
-            r.render_block(p,2,bufs[b].data_ptr(),H*W*16,streams[b].cuda_stream)
+            r.render_block(p,G,buf.data_ptr(),H*W*16,0)
         torch.cuda.synchronize()
-    run(600)  # the GPU's clocks take tens of milliseconds to ramp: untimed
-    t0=time.perf_counter(); run(600); dt=(time.perf_counter()-t0)/1200
+    run(6)  # the GPU's clocks take tens of milliseconds to ramp: untimed
+    t0=time.perf_counter(); run(12); dt=(time.perf_counter()-t0)/(12*G)
     t=r.last_timing()
     rays=t["primary_rays"]+t["shadow_rays"]+t["bounce_rays"]
     print(f"{name}: {dt*1e3:.4f} ms/frame, {rays/dt/1e9:.2f} Grays/s, rays/frame {rays}, samples/ray {(t['primary_steps']+t['shadow_steps'])/rays:.2f}, hits {t['hits']}")
