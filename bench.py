@@ -59,7 +59,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3sdf", "c4", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3sdf", "c3light", "c4", "c5"],
+                    help="c3 = BASELINE config 3 (the metric); c3light = the same with one point light: the full closest-hit kernel "
+                         "(the reference's default render mode once a scene has a point light)")
     ap.add_argument("--path", default="auto", choices=["auto", "dense", "brick", "lds", "cells"])
     ap.add_argument("--format", default="auto", choices=["auto", "f32", "texel16"],
                     help="device volume format: f32 bricks, or the reference's 16-bit texel (sign + 15-bit |d|*100)")
@@ -127,6 +129,13 @@ def build_workload(name: str):
     if name == "c3":
         sc = workloads.bench_config3()
         return sc, 1920, 1080, 255, True, "config3: 256^3 voxelized glTF-style mesh (torus, 16384 triangles), 1920x1080, shadow ray on"
+    if name == "c3light":
+        import copy
+
+        import volumetricraytracer_amd as v
+        sc = copy.copy(workloads.bench_config3())
+        sc.PointLights = [v.VPointLight(Position=(120.0, 60.0, 140.0), Color=(1.0, 0.9, 0.8, 1.0), IlluminationStrength=40.0)]
+        return sc, 1920, 1080, 255, True, "config3 + one point light: 256^3 voxelized mesh, 1920x1080, directional + point light with their shadow rays (full closest-hit kernel)"
     if name == "c3sdf":
         sc = workloads.config3_torus(8, 256, distance=190.0)
         return sc, 1920, 1080, 255, True, "config3 (analytic SDF variant): 256^3 torus SDF, 1920x1080, shadow ray on"
@@ -717,7 +726,7 @@ def main() -> None:
             "bound": "valu-issue (vector-instruction issue slots; a lone frame: dependent-load latency) -- PMC counters; not hbm, not mfma",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_key": key,
-            "kernel": "march_kernel", "kernel_ms": round(k_ms, 4), "frames_per_launch": fpl, "algorithmic_bytes_per_launch": int(alg_bytes),
+            "kernel": "march_kernel_full" if args.workload == "c3light" else "march_kernel", "kernel_ms": round(k_ms, 4), "frames_per_launch": fpl, "algorithmic_bytes_per_launch": int(alg_bytes),
             "samples_per_launch": samples,
             "gsamples_per_s": round(samples / (k_ms * 1e-3) / 1e9, 2) if kms else None,
             "gather_ceiling_gsamples_per_s": GATHER_CEILING_GSAMPLES,

@@ -1,8 +1,9 @@
 /*
  * vrt_kernels.hip — gfx950 (CDNA4) kernels of the volumetric SDF ray-marcher.
  *
- * One wavefront lane per primary ray, one 64-lane wave per 8x8 pixel tile, 4 waves per
- * workgroup (16x16 pixels).  The march is a sphere-trace over the trilinear interpolant of
+ * One wavefront lane per primary ray, one 64-lane wave per 8x8 pixel tile, one wave per workgroup (four consecutive
+ * workgroups of an XCD cover a 16x16-pixel tile); the grid's y axis is the FRAME: one launch marches a block of frames, each
+ * with its own camera from the kernarg segment.  The march is a sphere-trace over the trilinear interpolant of
  * the density grid; taps come either from the dense grid or from 4^3-cell bricks (5^3 samples:
  * 512 B of fp32 = four 128-B lines, or 256 B of int16 — the reference's own volume texel — = two)
  * so that the 8 taps of a sample share one brick.  A two-level empty-space table (brick bytes +
@@ -509,9 +510,25 @@ __device__ __forceinline__ F3 hit_normal(const DInstance* __restrict__ I, const 
         int xp = c.cx + 1 > N2 ? N2 : c.cx + 1, xm = c.cx - 1 < 0 ? 0 : c.cx - 1;
         int yp = c.cy + 1 > N2 ? N2 : c.cy + 1, ym = c.cy - 1 < 0 ? 0 : c.cy - 1;
         int zp = c.cz + 1 > N2 ? N2 : c.cz + 1, zm = c.cz - 1 < 0 ? 0 : c.cz - 1;
+#ifdef VRT_AB_NORMAL_ALL_AT_ONCE
         n.x = trilinear<PATH>(V, xp, c.cy, c.cz, c.fx, c.fy, c.fz) - trilinear<PATH>(V, xm, c.cy, c.cz, c.fx, c.fy, c.fz);
         n.y = trilinear<PATH>(V, c.cx, yp, c.cz, c.fx, c.fy, c.fz) - trilinear<PATH>(V, c.cx, ym, c.cz, c.fx, c.fy, c.fz);
         n.z = trilinear<PATH>(V, c.cx, c.cy, zp, c.fx, c.fy, c.fz) - trilinear<PATH>(V, c.cx, c.cy, zm, c.fx, c.fy, c.fz);
+#else
+        /* one axis at a time (a real loop): the six interpolations' 24 tap loads all in flight at once were the register peak of the
+           whole kernel (48 registers of taps); a hit happens once per ray, its latency is not what the kernel waits for */
+        n = f3(0.0f, 0.0f, 0.0f);
+#pragma unroll 1
+        for (int a = 0; a < 3; a++) {
+            const int px_ = a == 0 ? xp : c.cx, mx_ = a == 0 ? xm : c.cx;
+            const int py_ = a == 1 ? yp : c.cy, my_ = a == 1 ? ym : c.cy;
+            const int pz_ = a == 2 ? zp : c.cz, mz_ = a == 2 ? zm : c.cz;
+            const float v = trilinear<PATH>(V, px_, py_, pz_, c.fx, c.fy, c.fz) - trilinear<PATH>(V, mx_, my_, mz_, c.fx, c.fy, c.fz);
+            n.x = a == 0 ? v : n.x;
+            n.y = a == 1 ? v : n.y;
+            n.z = a == 2 ? v : n.z;
+        }
+#endif
     }
     float l2 = dot3(n, n);
     if (!(l2 > 0.0f)) {
@@ -954,7 +971,8 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 }
 
 /*
- * Primary-ray kernel.  One workgroup = one 16x16-pixel tile.  blockIdx → tile map (F.tile_map):
+ * Primary-ray kernel.  Four consecutive one-wave workgroups of an XCD = one 16x16-pixel tile (block_and_wave below).  blockIdx → tile
+ * map (F.tile_map):
  *   SUPERTILE (default): tiles are grouped into 4x4-tile supertiles (64x64 pixels); supertile s
  *     goes to XCD s % 8 (workgroups are dealt round-robin over the 8 XCDs, so the blocks
  *     b ≡ k (mod 8) share XCD k's L2).  An XCD's 16 consecutive blocks cover one supertile, so its
@@ -1182,7 +1200,13 @@ __device__ __forceinline__ int frame_row(const DFrame& F, int pyl) {
  * waves only fill wave slots the marching waves leave empty), and the four-pixel sky wave made the frame 20 % slower:
  * profiles/r03_sky_tile_and_occupancy_experiments.txt.) */
 template <int PATH, bool SINGLE, bool DIAG>
-__global__ __launch_bounds__(kMarchThreads) void march_kernel(const DBlock B) {
+/* The multi-instance (BVH) instantiations on brick / cell-record paths are asked to fit 7 waves per SIMD (72 VGPRs instead of the 78 the
+ * register allocator settles for; 3 registers and 10 scalars spilled outside the march loop): config 5 68.6 -> 70.9 Grays/s.  The
+ * single-instance ones sit at the hardware's 8 waves per SIMD anyway. */
+#ifndef VRT_BVH_WAVES
+#define VRT_BVH_WAVES 7
+#endif
+__global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu((!SINGLE && !DIAG && PATH != VRT_PATH_DENSE) ? VRT_BVH_WAVES : 1))) void march_kernel(const DBlock B) {
     unsigned long long t_start = 0;
     if constexpr (DIAG) t_start = __builtin_amdgcn_s_memrealtime(); /* 100 MHz; diagnostic build only */
     const DFrame& F = B.f;
