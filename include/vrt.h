@@ -379,7 +379,8 @@ int vrt_timing_history(vrt_ctx* ctx, int n, float* kernel_ms_out);
 /* The same, with the number of frames each launch covered (vrt_render_block: up to 32 per launch; everything else: 1). */
 int vrt_launch_history(vrt_ctx* ctx, int n, float* kernel_ms_out, int* frames_out);
 
-/* Diagnostics: per-wave records of the last frame of the last launch on the first device, 8 words each, record
+/* Diagnostics: per-wave records of the last frame of the last launch on the first device (which = 2, 3: of ALL frames of that
+ * launch, frame after frame, for which = 0, 1 respectively), 8 words each, record
  * index = blockIdx*4 + wave.  which = 0: counters {primary_rays, shadow_rays, bounce_rays,
  * primary_steps, shadow_steps, hits, exhausted_rays, 0}.  which = 1 (only after a VRT_FLAG_DIAG_TIMELINE launch):
  * {start, end (100 MHz ticks), iterations whose taps were back within 450 cycles, XCC_ID | HW_ID<<4, longest

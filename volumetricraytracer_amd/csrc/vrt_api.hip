@@ -188,6 +188,7 @@ struct vrt_ctx {
     int env_size = 0;
     int upload_format = VRT_FORMAT_F32; /* vrt_set_volume_format: device format of the following uploads */
     bool have_scene = false;
+    bool scene_stale = true; /* a volume was uploaded / freed / re-measured since the scene arrays were packed (boxes, BVH) */
     vrt_scene scene;
     DInstance inst[VRT_MAX_INSTANCES];
     DBvhNode nodes[kMaxBvhNodes];
@@ -637,6 +638,7 @@ int upload_volume(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, cons
         h.tex[0] = h.tex[1] = h.tex[2] = -1;
         h.tex_scale[0] = h.tex_scale[1] = 100.f;
     }
+    ctx->scene_stale = true;
     int rc = rebuild_skip(ctx, slot);
     if (rc != VRT_OK) return rc;
     return sync_volume_table(ctx);
@@ -1088,6 +1090,7 @@ int vrt_volume_set_metric(vrt_ctx* ctx, int slot, float density_scale, float ste
     }
     ctx->vol[slot].density_scale = density_scale;
     ctx->vol[slot].step_max = step_max;
+    ctx->scene_stale = true;
     int rc = rebuild_skip(ctx, slot);
     if (rc != VRT_OK) return rc;
     return sync_volume_table(ctx);
@@ -1163,6 +1166,7 @@ int vrt_volume_free(vrt_ctx* ctx, int slot) {
         if (rc != VRT_OK) return rc;
     }
     ctx->vol[slot] = HostVolume();
+    ctx->scene_stale = true;
     return sync_volume_table(ctx);
 }
 
@@ -1195,11 +1199,15 @@ int vrt_scene_set(vrt_ctx* ctx, const vrt_scene* scene) {
         if (!valid_slot(I.volume_slot) || !ctx->vol[I.volume_slot].used) return VRT_ERR_SLOT;
         if (I.scale[0] == 0.0f || I.scale[1] == 0.0f || I.scale[2] == 0.0f) return VRT_ERR_INVALID;
     }
+    /* an adaptor re-sends the scene every frame (VRDXScene::SyncWithScene runs per frame): the same scene over the same volumes
+       needs no re-packing and no copies to the device */
+    if (ctx->have_scene && !ctx->scene_stale && memcmp(&ctx->scene, scene, sizeof *scene) == 0) return VRT_OK;
     ctx->scene = *scene;
     ctx->have_scene = false;
     int rc = pack_scene(ctx);
     if (rc != VRT_OK) return rc;
     ctx->have_scene = true;
+    ctx->scene_stale = false;
     return VRT_OK;
 }
 
@@ -1634,15 +1642,17 @@ int vrt_launch_history(vrt_ctx* ctx, int n, float* kernel_ms_out, int* frames_ou
 }
 
 long long vrt_debug_wave_records(vrt_ctx* ctx, int which, uint32_t* out, long long max_words) {
-    if (!ctx || max_words < 0 || (max_words > 0 && !out) || which < 0 || which > 1) return VRT_ERR_INVALID;
+    if (!ctx || max_words < 0 || (max_words > 0 && !out) || which < 0 || which > 3) return VRT_ERR_INVALID;
     if (ctx->launches == 0) return VRT_ERR_NOT_READY;
     DeviceState& D = ctx->dev[0];
-    if (which == 1 && (!D.last_diag || !D.d_diag)) return VRT_ERR_NOT_READY;
-    const long long words = (long long)D.last_blocks * 4 * (which == 0 ? kStatRecord : kDiagRecord);
+    const bool diag = (which & 1) != 0, whole = which >= 2;
+    if (diag && (!D.last_diag || !D.d_diag)) return VRT_ERR_NOT_READY;
+    const long long frame_words = (long long)D.last_blocks * 4 * (diag ? kDiagRecord : kStatRecord);
+    const long long words = whole ? frame_words * D.last_frames : frame_words;
     if (out && max_words > 0) {
         HIP_TRY(hipSetDevice(D.ordinal));
         HIP_TRY(hipDeviceSynchronize());
-        const uint32_t* src = (which == 0 ? D.d_stats[D.last_slot] : D.d_diag) + (size_t)(D.last_frames - 1) * (size_t)words;
+        const uint32_t* src = (diag ? D.d_diag : D.d_stats[D.last_slot]) + (whole ? 0 : (size_t)(D.last_frames - 1) * (size_t)frame_words);
         HIP_TRY(hipMemcpy(out, src, sizeof(uint32_t) * (size_t)std::min(words, max_words), hipMemcpyDeviceToHost));
     }
     return words;
