@@ -810,23 +810,26 @@ def exchange_label(rotate: bool, world: int, G: int, rehearsal: bool) -> str:
     return f"one gather ({how}) to rank 0 per block of {G} frames"
 
 
-def end_to_end_leg(r, p, rays_per_frame: float, steps: int):
-    """The frame as a host application gets it: vrt_render_begin / vrt_render_end with two frame slots — march,
-    then the copy of the frame into pinned host memory, the next frame's march overlapping the copy."""
-    for i in range(2):
-        r.render_begin(i % 2, p)
-        r.render_end(i % 2, p, copy=False)
+def end_to_end_leg(r, p, rays_per_frame: float, steps: int, slots: int = 3):
+    """The frame as a host application gets it: vrt_render_begin / vrt_render_end with the reference's three frame slots
+    (FrameCount, DXConstants.cpp:23) — march, then the copy of the frame into pinned host memory, the next frames' marches
+    overlapping the copy."""
+    for i in range(slots):
+        r.render_begin(i % slots, p)
+    for i in range(slots):
+        r.render_end(i % slots, p, copy=False)
     t0 = time.perf_counter()
-    r.render_begin(0, p)
-    for i in range(1, steps):
-        r.render_begin(i % 2, p)
-        r.render_end((i - 1) % 2, p, copy=False)
-    r.render_end((steps - 1) % 2, p, copy=False)
+    for i in range(steps):
+        if i >= slots:
+            r.render_end(i % slots, p, copy=False)
+        r.render_begin(i % slots, p)
+    for i in range(max(steps - slots, 0), steps):
+        r.render_end(i % slots, p, copy=False)
     dt = time.perf_counter() - t0
     bpp = 4 if p.flags & 8 else 16
     return {"value": round(rays_per_frame * steps / dt / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(dt / steps * 1e3, 4),
             "includes": f"march + D2H of the {p.width}x{p.height} frame ({bpp} B/pixel) into pinned host memory, "
-                        "vrt_render_begin/_end with 2 frame slots (scene re-synchronised every frame)"}
+                        f"vrt_render_begin/_end with {slots} frame slots (scene re-sent every frame)"}
 
 
 def cpu_baseline(sc, p, target_seconds: float):

@@ -890,6 +890,7 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
                  int ring, const SceneArrays* snapshot = nullptr, int n_frames = 1, const vrt_camera* cams = nullptr, size_t frame_stride = 0) {
     if (n_frames < 1 || n_frames > kMaxBlockFrames) return VRT_ERR_INVALID;
     DBlock B;
+    memset(B.cam, 0, sizeof B.cam); /* (the whole struct travels as the kernarg: no stale stack bytes behind the block's frames) */
     DFrame& F = B.f;
     build_frame(ctx, D, p, rs, out, nullptr, F, snapshot);
     if ((long long)F.tiles_x * F.tiles_y > kMaxBlocks / 2) return VRT_ERR_INVALID;
