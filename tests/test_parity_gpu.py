@@ -825,6 +825,41 @@ def test_bench_two_rank_rehearsal(oracle_lib):
     assert bad.returncode != 0 and "refusing" in bad.stderr
 
 
+def test_bench_one_gpu_line_has_the_contract_fields(oracle_lib):
+    """`python bench.py` on one GPU (a short run): ONE JSON line with the driver contract's fields, the `roofline` and
+    `cpu_baseline` objects, one stream x 48 frames per launch, launch durations that add up to the timed region (nothing
+    overlaps: kernel time x launches per step ~ ms_per_step), and the legs (latency, scale anchor, end to end, config 4)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: val for k, val in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "1"], env=env,
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    o = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in o, k
+    assert o["n_gpus"] == 1 and o["steps"] == 3 and o["warmup"] == 1 and o["unit"] == "Mrays/s" and o["vs_baseline"] is None and o["dtype"] == "f32"
+    assert o["config"]["width"] == 1920 and o["config"]["height"] == 1080 and o["config"]["streams"] == 1 and o["config"]["frames_per_launch"] == 48
+    r = o["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frames_per_launch"] == 48
+    # one stream: the launches run one after the other, so their durations add up to the step (two launches per 96-frame step)
+    assert 0.85 < 2 * r["kernel_ms"] / o["ms_per_step"] <= 1.02
+    # value = rays of the batch x steps / time
+    assert abs(o["value"] - o["config"]["rays_per_step"] / (o["ms_per_step"] * 1e-3) / 1e6) / o["value"] < 0.01
+    c = o["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["chain_positions_max"] > 50
+    assert o["latency"]["ms_per_frame"] > o["ms_per_step"] / 96 and o["scale_anchor"]["value"] > 0 and o["end_to_end"]["value"] > 0
+    assert o["config4"]["value"] > 0 and o["config4"]["scale_anchor"]["value"] > 0
+    assert 0 < o["config"]["marching"]["primary_rays_in_marching_waves"] < o["config"]["marching"]["primary_rays"] == 1920 * 1080
+
+
 def test_native_tile_gather_with_one_rank(oracle_lib):
     """vrt_comm_unique_id / vrt_comm_init / vrt_gather_tiles — RCCL's ncclGather behind the C-ABI, resolved from librccl at
     run time — with the one rank this box has: the gather enqueued on the march stream right behind vrt_render_strips must
