@@ -723,7 +723,8 @@ def main() -> None:
             # L2), MFMA is not used (gather-type lookups).  The contract's fields stay what the contract defines: ALGORITHMIC bytes
             # (32 B per trilinear sample + 192 B per hit + the pixel store) of one launch / its mean event-timed
             # duration / the HBM peak
-            "bound": "valu-issue (vector-instruction issue slots; a lone frame: dependent-load latency) -- PMC counters; not hbm, not mfma",
+            "bound": "vector-memory (texture) pipeline -- data return 0.88 / addresser 0.77 busy -- and the latency of dependent loads at the hardware's 8 "
+                     "waves per SIMD; vector issue 0.65 -- PMC counters; not hbm (0.10 of peak), not mfma (unused)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_key": key,
             "kernel": "march_kernel_full" if args.workload == "c3light" else "march_kernel", "kernel_ms": round(k_ms, 4), "frames_per_launch": fpl, "algorithmic_bytes_per_launch": int(alg_bytes),
@@ -746,6 +747,8 @@ def main() -> None:
                 "valu_issue_frac": round(valu * 2.0 / 1024.0 / (clock * 1e9) / (k_ms * 1e-3), 4) if valu else None,
                 "valu_insts_per_launch": int(valu) if valu else None, "clock_ghz": round(clock, 3),
                 "occupancy_mean_waves_per_cu": pmc.get("occupancy_mean_waves_per_cu"),
+                # busy cycles of the texture path's two units summed over the CUs / 256 / the launch's GPU cycles (in the counters' own run)
+                "td_busy_frac": pmc.get("td_busy_frac"), "ta_busy_frac": pmc.get("ta_busy_frac"),
                 "valu_lane_utilisation": pmc.get("valu_lane_utilisation"),
                 "counters_from": pmc.get("tag"),
             })

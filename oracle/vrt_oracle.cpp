@@ -133,7 +133,8 @@ struct Volume {
        holds an ACTIVE cell (a cell with a corner closer than step_max to the surface), capped at 255.  nib: per
        brick eight 4-bit fields, one per 2^3-cell sub-block (bit offset 4*((lx>>1)*4 + (lz>>1)*2 + (ly>>1))): the
        floor of the Euclidean distance, in cells, from the sub-block's cells to the nearest active cell, capped at
-       15; only consulted where D <= 1.  Null: no leaping. */
+       15 — the leap of a position in that sub-block.  skip only bounds the active box (and says that the volume has tables).
+       Null: no leaping. */
     int nb = 0;
     const uint8_t* skip = nullptr;
     const uint32_t* nib = nullptr;
@@ -773,19 +774,14 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
         float czf = minf(maxf(floorf(uz), 0.0f), cmax);
         float fx = ux - cxf, fy = uy - cyf, fz = uz - czf;
         int cx = (int)cxf, cy = (int)cyf, cz = (int)czf;
-        /* Empty-space leap L from the two-level table: (D-1) brick edges where the nearest near brick is D >= 2 bricks
-           away, else the sub-block's distance to the nearest active cell in cell edges.  Such a move cannot enter an
-           active cell, and the interpolant is below the step clamp only inside active cells. */
+        /* Empty-space leap L from the sub-block table: the sub-block's distance to the nearest active cell in cell edges (at most
+           15).  Such a move cannot enter an active cell, and the interpolant is below the step clamp only inside active cells.
+           (The brick-level table only bounds the active box since round 3: ONE table word per new brick for the GPU's march.) */
         float leap = 0.0f;
         if (V.skip) {
             const size_t brick = ((size_t)(cx >> 2) * V.nb + (size_t)(cz >> 2)) * V.nb + (size_t)(cy >> 2);
-            const int dd = V.skip[brick];
-            if (dd > 1) {
-                leap = (float)(dd - 1) * leap_unit;
-            } else {
-                const int k = ((cx >> 1) & 1) * 4 + ((cz >> 1) & 1) * 2 + ((cy >> 1) & 1);
-                leap = (float)((V.nib[brick] >> (4 * k)) & 15u) * cell_unit;
-            }
+            const int k = ((cx >> 1) & 1) * 4 + ((cz >> 1) & 1) * 2 + ((cy >> 1) & 1);
+            leap = (float)((V.nib[brick] >> (4 * k)) & 15u) * cell_unit;
             /* No active cell here: a sample would be >= smax, so it cannot be a hit while the threshold is below smax
                (factor 2: rounding margin), and max(min(s*k, smax), footprint, leap) = max(footprint, leap) once
                leap >= smax.  The ray advances without sampling (no tap is read, no sample is counted). */

@@ -74,7 +74,7 @@ def counters(dirname):
 
 
 c = {}
-for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_tatd", "pmc_tcp"):
     res, ns = counters(d)
     c.update(res)
     if d == "pmc_sq" and ns:
@@ -104,7 +104,8 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 "hbm_bytes_per_launch_raw": rd + wr, "hbm_bytes_per_launch": 2 * rd + wr})
     lines.append(f"== HBM traffic per launch: read {rd / 1e6:.2f} MB raw ({2 * rd / 1e6:.2f} MB x2-corrected), write {wr / 1e6:.2f} MB ==")
 for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU",
-          "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+          "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "TD_TD_BUSY_sum", "TA_TA_BUSY_sum",
+          "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_ACCESSES_sum"):
     if k in c:
         res[k] = c[k]
 if c.get("GRBM_GUI_ACTIVE"):
@@ -116,6 +117,13 @@ if c.get("GRBM_GUI_ACTIVE"):
     if c.get("SQ_WAVE_CYCLES"):
         res["occupancy_mean_waves_per_cu"] = round(c["SQ_WAVE_CYCLES"] * 4.0 / (cyc * 256.0), 2)
         lines.append(f"== mean occupancy: {res['occupancy_mean_waves_per_cu']} of 32 waves per CU (SQ_WAVE_CYCLES x 4 / (GPU cycles x 256 CUs)) ==")
+    if c.get("TD_TD_BUSY_sum"):
+        res["td_busy_frac"] = round(c["TD_TD_BUSY_sum"] / 256.0 / cyc, 4)
+        res["ta_busy_frac"] = round(c.get("TA_TA_BUSY_sum", 0.0) / 256.0 / cyc, 4)
+        lines.append(f"== texture path busy (sum over the CUs / 256 / GPU cycles of the SQ pass): data return TD {res['td_busy_frac']}, addresser TA {res['ta_busy_frac']} ==")
+    if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        res["l1_cache_line_accesses_per_cu_cycle"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cyc, 3)
+        lines.append(f"== L1 (TCP): {res['l1_cache_line_accesses_per_cu_cycle']} cache-line accesses per CU and cycle; {c.get('TCP_TCC_READ_REQ_sum', 0) / max(c['TCP_TOTAL_CACHE_ACCESSES_sum'], 1):.3f} of them go on to L2 ==")
     if c.get("SQ_INSTS_VALU"):
         res["valu_issue_frac_in_sq_pass"] = round(c["SQ_INSTS_VALU"] * 2.0 / 1024.0 / cyc, 4)
         lines.append(f"== vector-instruction issue: {c['SQ_INSTS_VALU']:.0f} wave-instructions x 2 cycles / 1024 SIMDs / {cyc:.0f} cycles = {res['valu_issue_frac_in_sq_pass']} (in the SQ pass itself) ==")

@@ -449,12 +449,14 @@ __device__ __forceinline__ Cell cell_at(const RaySeg& R, float t) {
     return c;
 }
 
-/* Empty-space leap (ray-parameter units) of cell c from the two table words of its brick: leap count B > 0 (the
- * nearest near brick is B+1 bricks away): B brick edges; else the cell's sub-block nibble: that many cell edges.  Both
- * tables are small (nb^3 bytes / words) and stay in L2. */
-__device__ __forceinline__ float leap_of(const RaySeg& R, const Cell& c, unsigned B, unsigned nibw) {
+/* Empty-space leap (ray-parameter units) of cell c from the table word of its brick: the cell's sub-block nibble, that many
+ * cell edges (at most 15).  The table is small (nb^3 words) and stays in L2.  Round 2 also read the brick-level byte (leaps of
+ * whole bricks where the nearest near brick is >= 2 bricks away): two of every five vector loads of a frame were table loads, and
+ * the texture path is what the march keeps busiest (TD 0.88): ONE table load per new brick, +3.7 % (the march is clipped to the
+ * active box anyway: leaps beyond 15 cells were 2 % of the skipped positions). */
+__device__ __forceinline__ float leap_of(const RaySeg& R, const Cell& c, unsigned nibw) {
     const unsigned k = (((unsigned)c.cx >> 1) & 1u) * 4u + (((unsigned)c.cz >> 1) & 1u) * 2u + (((unsigned)c.cy >> 1) & 1u);
-    return B > 0u ? (float)B * R.leap_unit : (float)((nibw >> (4u * k)) & 15u) * R.cell_unit;
+    return (float)((nibw >> (4u * k)) & 15u) * R.cell_unit;
 }
 
 constexpr float kRelaxGate = 0.8f; /* over-relaxation: a step is stretched only when the sample is at least this fraction of the one before */
@@ -672,7 +674,7 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
     int i = st.i;
     Cell c = st.c;
     const bool tables = V.skip != nullptr;
-    unsigned last_brick = 0xffffffffu, B = 1u, nibw = 0u;
+    unsigned last_brick = 0xffffffffu, nibw = 0u;
     while (i < limit && !(t > t_end)) {
         unsigned long long st0 = 0, st1 = 0;
         if constexpr (DIAG) st0 = stamp();
@@ -685,12 +687,11 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
         float leap = 0.0f;
         bool skip = false;
         if (tables) {
-            if (brick != last_brick) { /* the two table words are re-read only when the ray changes brick */
-                B = V.skip[brick];
+            if (brick != last_brick) { /* the table word is re-read only when the ray changes brick */
                 nibw = V.nib[brick];
                 last_brick = brick;
             }
-            leap = leap_of(R, c, B, nibw);
+            leap = leap_of(R, c, nibw);
             /* no active cell within the leap, and the hit threshold still below half the clamp: the sample could neither hit
                nor shorten the step (oracle: same condition, same advance; smax > 0 wherever there are tables) */
             skip = leap >= R.smax && t <= R.t_skip_end;
@@ -1539,7 +1540,7 @@ __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V,
         bool need = active;
         if (V.skip != nullptr && active) {
             const unsigned brick = (bx * nb + bz) * nb + by;
-            leap = leap_of(R, c, (unsigned)V.skip[brick], V.nib[brick]);
+            leap = leap_of(R, c, V.nib[brick]);
             if (leap >= R.smax && t <= R.t_skip_end) {
                 t_prev = t;
                 s_prev = R.smax;
