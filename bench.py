@@ -723,8 +723,8 @@ def main() -> None:
             # L2), MFMA is not used (gather-type lookups).  The contract's fields stay what the contract defines: ALGORITHMIC bytes
             # (32 B per trilinear sample + 192 B per hit + the pixel store) of one launch / its mean event-timed
             # duration / the HBM peak
-            "bound": "vector-memory (texture) pipeline -- data return 0.88 / addresser 0.77 busy -- and the latency of dependent loads at the hardware's 8 "
-                     "waves per SIMD; vector issue 0.65 -- PMC counters; not hbm (0.10 of peak), not mfma (unused)",
+            "bound": "vector-memory (texture) pipeline (td_busy_frac / ta_busy_frac below) and the latency of dependent loads at the hardware's 8 waves "
+                     "per SIMD, ahead of vector issue (valu_issue_frac) -- PMC counters; not hbm (hbm_measured_frac), not mfma (unused)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_key": key,
             "kernel": "march_kernel_full" if args.workload == "c3light" else "march_kernel", "kernel_ms": round(k_ms, 4), "frames_per_launch": fpl, "algorithmic_bytes_per_launch": int(alg_bytes),
