@@ -532,7 +532,7 @@ def test_skybox_from_a_dds_cube_map(tmp_path, layout):
     """The reference loads its sky box from a .dds cube map (VTextureFactory::LoadTextureCubeFromFile,
     Renderer/Private/TextureFactory.cpp:28-67; Resources/Skybox/Skybox.dds is missing from the checkout).  Uncompressed
     cube maps in the DX10 and the legacy header layouts, with and without a mip chain, decode to the six RGBA faces;
-    a 2D texture, a block-compressed or a truncated file is refused."""
+    a 2D texture, a format the loader does not decode (BC5) or a truncated file is refused."""
     rng = np.random.default_rng(4)
     faces = rng.integers(0, 256, size=(6, 8, 8, 4), dtype=np.uint8)
     path = str(tmp_path / "sky.dds")
@@ -556,7 +556,7 @@ def test_skybox_from_a_dds_cube_map(tmp_path, layout):
     with pytest.raises(RuntimeError):
         vx.load_skybox_faces(bad)
     bc = bytearray(raw)
-    bc[80:88] = struct.pack("<I4s", 0x4, b"DXT1")  # block-compressed
+    bc[80:88] = struct.pack("<I4s", 0x4, b"ATI2")  # BC5: a block-compressed format the loader does not decode
     open(bad, "wb").write(bc)
     with pytest.raises(RuntimeError):
         vx.load_skybox_faces(bad)
@@ -586,6 +586,100 @@ def test_skybox_from_a_dds_cube_map(tmp_path, layout):
     upper = str(tmp_path / "SKY.DdS")
     open(upper, "wb").write(raw)
     assert np.array_equal(vx.load_skybox_faces(upper), want)
+
+
+def _bc_decode_block(b, bc):
+    """One 4x4 block of BC1 / BC2 / BC3 by the published rules ("Texture Block Compression in Direct3D 11"), float32 like the
+    loader: end points c/31, c/63; palette at 1/3, 2/3 (BC1 with c0 <= c1: midpoint + transparent black); byte = floor(c*255 + 0.5)."""
+    f = np.float32
+    col = b if bc == 1 else b[8:]
+    c0, c1 = int(col[0]) | int(col[1]) << 8, int(col[2]) | int(col[3]) << 8
+
+    def expand(c):
+        return np.array([f((c >> 11) & 31) / f(31), f((c >> 5) & 63) / f(63), f(c & 31) / f(31)], dtype=f)
+
+    p0, p1 = expand(c0), expand(c1)
+    four = bc != 1 or c0 > c1
+    if four:
+        p2, p3, a3 = p0 + (p1 - p0) * f(1.0 / 3.0), p0 + (p1 - p0) * f(2.0 / 3.0), 255
+    else:
+        p2, p3, a3 = p0 + (p1 - p0) * f(0.5), np.zeros(3, f), 0
+    pal = [p0, p1, p2, p3]
+    idx = int.from_bytes(bytes(col[4:8]), "little")
+    out = np.zeros((16, 4), np.uint8)
+    if bc == 3:
+        a0, a1 = int(b[0]), int(b[1])
+        alpha = [a0, a1]
+        for k in range(2, 8):
+            if a0 > a1:
+                a = (f(8 - k) * f(a0) + f(k - 1) * f(a1)) / f(7)
+            elif k < 6:
+                a = (f(6 - k) * f(a0) + f(k - 1) * f(a1)) / f(5)
+            else:
+                a = f(0) if k == 6 else f(255)
+            alpha.append(int(f(a) + f(0.5)))
+        abits = int.from_bytes(bytes(b[2:8]), "little")
+    for i in range(16):
+        k = (idx >> (2 * i)) & 3
+        out[i, :3] = (pal[k] * f(255) + f(0.5)).astype(np.uint8)
+        if bc == 1:
+            out[i, 3] = 255 if k < 3 or four else a3
+        elif bc == 2:
+            out[i, 3] = ((int(b[i >> 1]) >> ((i & 1) * 4)) & 15) * 17
+        else:
+            out[i, 3] = alpha[(abits >> (3 * i)) & 7]
+    return out.reshape(4, 4, 4)
+
+
+@pytest.mark.parametrize("bc,dx10", [(1, False), (2, False), (3, False), (1, True), (3, True)])
+def test_skybox_from_a_block_compressed_dds_cube_map(tmp_path, bc, dx10):
+    """SURVEY §8(f)-4's last leftover: the reference's Skybox.dds (missing from the checkout) goes through DirectXTex, which
+    writes BC1 / BC2 / BC3 as readily as RGBA.  Cube maps of random blocks (every palette mode, both BC3 alpha modes, a mip chain)
+    in the legacy FourCC and the DX10 header layouts decode to what the published block rules give, texel for texel; a truncated
+    file and BC7 are refused."""
+    rng = np.random.default_rng(40 + bc)
+    S, block = 12, 8 if bc == 1 else 16
+    mips = 3
+    faces_blocks = []
+    body = b""
+    want = np.zeros((6, S, S, 4), np.uint8)
+    for f in range(6):
+        for m in range(mips):
+            w = max(S >> m, 1)
+            nbk = ((w + 3) // 4) ** 2
+            blocks = rng.integers(0, 256, size=(nbk, block), dtype=np.uint8)
+            if m == 0:
+                blocks[0, block - 8:block - 4] = [0x00, 0x10, 0xff, 0xf0]   # c0 < c1: BC1's three-colour + transparent mode
+                if bc == 3:
+                    blocks[1, 0:2] = [10, 200]                              # a0 < a1: BC3's six-value alpha mode with 0 and 255
+                bw = (w + 3) // 4
+                for k in range(nbk):
+                    tex = _bc_decode_block(blocks[k], bc)
+                    by, bx = divmod(k, bw)
+                    want[f, by * 4:by * 4 + 4, bx * 4:bx * 4 + 4] = tex[: min(4, S - by * 4), : min(4, S - bx * 4)]
+            body += blocks.tobytes()
+    fourcc = {1: b"DXT1", 2: b"DXT3", 3: b"DXT5"}[bc]
+    hdr = struct.pack("<4s7I44x", b"DDS ", 124, 0x1 | 0x2 | 0x4 | 0x1000 | 0x20000 | 0x80000, S, S, ((S + 3) // 4) ** 2 * block, 0, mips)
+    if dx10:
+        hdr += struct.pack("<2I4s5I", 32, 0x4, b"DX10", 0, 0, 0, 0, 0)
+        tail = struct.pack("<5I", {1: 71, 2: 74, 3: 77}[bc], 3, 0x4, 1, 0)
+    else:
+        hdr += struct.pack("<2I4s5I", 32, 0x4, fourcc, 0, 0, 0, 0, 0)
+        tail = b""
+    hdr += struct.pack("<5I", 0x1008 | 0x400000, 0x200 | 0xfc00, 0, 0, 0)
+    assert len(hdr) == 128
+    path = str(tmp_path / "sky_bc.dds")
+    open(path, "wb").write(hdr + tail + body)
+    cube = vx.load_skybox_faces(path)
+    assert cube.shape == (6, S, S, 4) and np.array_equal(cube, want)
+    bad = str(tmp_path / "bad.dds")
+    open(bad, "wb").write((hdr + tail + body)[:-9])
+    with pytest.raises(RuntimeError):
+        vx.load_skybox_faces(bad)
+    if dx10:
+        open(bad, "wb").write(hdr + struct.pack("<5I", 98, 3, 0x4, 1, 0) + body)  # BC7_UNORM: not decoded
+        with pytest.raises(RuntimeError):
+            vx.load_skybox_faces(bad)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/VolumetricRaytracer/VolumetricRaytracer/Resources/Skybox"),

@@ -147,6 +147,59 @@ VObjectPtr<VTextureCube> VTextureCube::LoadFromFaceDirectory(const std::string& 
     return std::make_shared<VTextureCube>(size, std::move(all));
 }
 
+/* One 4x4 block of BC1 / BC2 / BC3 (DXT1 / DXT3 / DXT5; "Texture Block Compression in Direct3D 11", the format every DDS sky box
+ * exported with the reference's toolchain — DirectXTex `texassemble` / `texconv` — is most likely to be in) into 16 RGBA8 texels,
+ * row-major.  Colours: two R5G6B5 end points expanded to [0,1] (c/31, c/63), palette entries 2 and 3 at 1/3 and 2/3 (BC1 with
+ * c0 <= c1: the midpoint and transparent black); bytes = round(c * 255).  BC2: explicit 4-bit alpha; BC3: two 8-bit alpha end
+ * points with six or four interpolated steps. */
+static void decode_bc_block(const uint8_t* b, int bc /* 1, 2, 3 */, uint8_t out[16][4]) {
+    const uint8_t* col = bc == 1 ? b : b + 8;
+    const unsigned c0 = col[0] | col[1] << 8, c1 = col[2] | col[3] << 8;
+    float pal[4][4];
+    auto expand = [](unsigned c, float* o) {
+        o[0] = (float)((c >> 11) & 31u) / 31.0f;
+        o[1] = (float)((c >> 5) & 63u) / 63.0f;
+        o[2] = (float)(c & 31u) / 31.0f;
+        o[3] = 1.0f;
+    };
+    expand(c0, pal[0]);
+    expand(c1, pal[1]);
+    const bool four = bc != 1 || c0 > c1;
+    for (int k = 0; k < 3; k++) {
+        if (four) {
+            pal[2][k] = pal[0][k] + (pal[1][k] - pal[0][k]) * (1.0f / 3.0f);
+            pal[3][k] = pal[0][k] + (pal[1][k] - pal[0][k]) * (2.0f / 3.0f);
+        } else {
+            pal[2][k] = pal[0][k] + (pal[1][k] - pal[0][k]) * 0.5f;
+            pal[3][k] = 0.0f;
+        }
+    }
+    pal[2][3] = 1.0f;
+    pal[3][3] = four ? 1.0f : 0.0f;
+    const unsigned idx = col[4] | col[5] << 8 | col[6] << 16 | (unsigned)col[7] << 24;
+    uint8_t alpha[8];
+    unsigned long long abits = 0;
+    if (bc == 3) {
+        alpha[0] = b[0];
+        alpha[1] = b[1];
+        for (int k = 2; k < 8; k++) {
+            float a;
+            if (alpha[0] > alpha[1]) a = ((float)(8 - k) * (float)alpha[0] + (float)(k - 1) * (float)alpha[1]) / 7.0f;
+            else if (k < 6) a = ((float)(6 - k) * (float)alpha[0] + (float)(k - 1) * (float)alpha[1]) / 5.0f;
+            else a = k == 6 ? 0.0f : 255.0f;
+            alpha[k] = (uint8_t)(a + 0.5f);
+        }
+        for (int k = 0; k < 6; k++) abits |= (unsigned long long)b[2 + k] << (8 * k);
+    }
+    for (int i = 0; i < 16; i++) {
+        const float* p = pal[(idx >> (2 * i)) & 3u];
+        for (int k = 0; k < 3; k++) out[i][k] = (uint8_t)(p[k] * 255.0f + 0.5f);
+        if (bc == 1) out[i][3] = (uint8_t)(p[3] * 255.0f + 0.5f);
+        else if (bc == 2) out[i][3] = (uint8_t)(((b[i >> 1] >> ((i & 1) * 4)) & 15u) * 17u);
+        else out[i][3] = alpha[(abits >> (3 * i)) & 7u];
+    }
+}
+
 VObjectPtr<VTextureCube> VTextureCube::LoadFromDDSFile(const std::string& path) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return nullptr;
@@ -168,9 +221,13 @@ VObjectPtr<VTextureCube> VTextureCube::LoadFromDDSFile(const std::string& path) 
     if (mips == 0) mips = 1;
     size_t data = 128;
     int bpp = 0;          /* bytes per pixel in the file */
+    int bc = 0;           /* block-compressed: 1 = BC1 (DXT1), 2 = BC2 (DXT3), 3 = BC3 (DXT5) */
     int ri = 0, gi = 1, bi = 2, ai = 3; /* byte index of each channel; ai < 0: opaque */
     bool cube = false;
-    if ((pf_flags & 0x4u) && fourcc == 0x30315844u /* "DX10" */) {
+    if ((pf_flags & 0x4u) && (fourcc == 0x31545844u /* "DXT1" */ || fourcc == 0x33545844u /* "DXT3" */ || fourcc == 0x35545844u /* "DXT5" */)) {
+        cube = (caps2 & 0x200u) && (caps2 & 0xfc00u) == 0xfc00u;
+        bc = fourcc == 0x31545844u ? 1 : fourcc == 0x33545844u ? 2 : 3;
+    } else if ((pf_flags & 0x4u) && fourcc == 0x30315844u /* "DX10" */) {
         if (file.size() < 148) return nullptr;
         const uint32_t dxgi = u32(128), dim = u32(132), misc = u32(136);
         data = 148;
@@ -179,6 +236,7 @@ VObjectPtr<VTextureCube> VTextureCube::LoadFromDDSFile(const std::string& path) 
         if (dxgi == 28 || dxgi == 29 || dxgi == 27) { /* R8G8B8A8 (typeless, unorm, srgb) */
         } else if (dxgi == 87 || dxgi == 91 || dxgi == 90) { ri = 2; bi = 0; /* B8G8R8A8 */
         } else if (dxgi == 88 || dxgi == 93 || dxgi == 92) { ri = 2; bi = 0; ai = -1; /* B8G8R8X8 */
+        } else if (dxgi >= 70 && dxgi <= 78) { bc = 1 + (int)(dxgi - 70) / 3; /* BC1 / BC2 / BC3 (typeless, unorm, srgb) */
         } else return nullptr;
     } else if (pf_flags & 0x40u /* DDPF_RGB */) {
         cube = (caps2 & 0x200u) && (caps2 & 0xfc00u) == 0xfc00u; /* DDSCAPS2_CUBEMAP with all six faces */
@@ -190,19 +248,35 @@ VObjectPtr<VTextureCube> VTextureCube::LoadFromDDSFile(const std::string& path) 
         else return nullptr;
         if (ri < 0 || gi < 0 || bi < 0 || ri >= bpp || gi >= bpp || bi >= bpp) return nullptr;
     } else {
-        return nullptr; /* block-compressed or exotic: not supported */
+        return nullptr; /* BC4-BC7, float or exotic formats: not supported */
     }
     if (!cube || width == 0 || width != height || width > 16384) return nullptr;
     uint32_t max_mips = 1;
     while ((width >> max_mips) != 0) max_mips++;
     mips = std::min(mips, max_mips);
     size_t face_bytes = 0; /* all mip levels of one face */
-    for (uint32_t m = 0; m < mips; m++) face_bytes += (size_t)std::max(1u, width >> m) * std::max(1u, height >> m) * (size_t)bpp;
+    const size_t block_bytes = bc == 1 ? 8 : 16;
+    for (uint32_t m = 0; m < mips; m++) {
+        const size_t w = std::max(1u, width >> m), h = std::max(1u, height >> m);
+        face_bytes += bc ? ((w + 3) / 4) * ((h + 3) / 4) * block_bytes : w * h * (size_t)bpp;
+    }
     if (file.size() < data + 6 * face_bytes) return nullptr; /* truncated */
     std::vector<uint8_t> rgba((size_t)6 * width * height * 4);
     for (int face = 0; face < 6; face++) {
         const uint8_t* src = file.data() + data + (size_t)face * face_bytes;
         uint8_t* dst = rgba.data() + (size_t)face * width * height * 4;
+        if (bc) { /* top mip level: rows of 4x4 blocks */
+            const size_t bw = (width + 3) / 4;
+            uint8_t texels[16][4];
+            for (size_t by = 0; by < (height + 3) / 4; by++)
+                for (size_t bx = 0; bx < bw; bx++) {
+                    decode_bc_block(src + (by * bw + bx) * block_bytes, bc, texels);
+                    for (size_t y = 0; y < 4 && by * 4 + y < height; y++)
+                        for (size_t x = 0; x < 4 && bx * 4 + x < width; x++)
+                            memcpy(dst + ((by * 4 + y) * width + bx * 4 + x) * 4, texels[y * 4 + x], 4);
+                }
+            continue;
+        }
         for (size_t i = 0; i < (size_t)width * height; i++) {
             dst[i * 4 + 0] = src[i * bpp + ri];
             dst[i * 4 + 1] = src[i * bpp + gi];
