@@ -425,6 +425,25 @@ def main() -> None:
     rgba8 = args.output == "rgba8" or (args.output == "auto" and world > 1)
     strip_rows = args.strip_rows if world > 1 else 0
     rotate = world > 1 and args.exchange == "rotate"
+    exchange_fallback = None
+    if rotate:
+        # the all-to-all is what the default exchange stands on: try it once on a few bytes, and fall back to the gather (said in the
+        # line) rather than lose the whole run if this backend cannot do it — every rank fails or passes the same way
+        try:
+            probe_in = torch.arange(world * 4, dtype=torch.uint8, device=cdev)
+            probe_out = torch.zeros_like(probe_in)
+            dist.all_to_all_single(probe_out, probe_in)
+            if not rehearsal:
+                torch.cuda.synchronize()
+            # chunk s of the output is chunk `rank` of rank s's input: bytes 4*rank .. 4*rank+3 from every rank
+            ok = bool((probe_out.view(world, 4).cpu() == (torch.arange(4, dtype=torch.uint8) + 4 * rank)[None, :]).all())
+        except Exception as e:  # noqa: BLE001
+            ok, exchange_fallback = False, f"all_to_all_single unavailable ({e!r}): gather to rank 0 instead"
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not bool(flag.item()):
+            rotate = False
+            exchange_fallback = exchange_fallback or "all_to_all_single failed on another rank: gather to rank 0 instead"
     # One GPU: ONE stream — a march launch covers a whole block of frames, the launch itself keeps the frames in flight (the
     # reference keeps 3 on its swap chain, DXConstants.cpp:23).  Several: 2 streams, so that a block's collective overlaps the
     # next block's march.  (No dependence on how HIP maps streams to hardware queues any more: profiles/r03_fused_launch_sweep.txt.)
@@ -787,6 +806,8 @@ def main() -> None:
                                  "torch.distributed (" + ("gloo, REHEARSAL" if rehearsal else "RCCL") + ")")
             out["native_gather_check"] = native_check if native_check is not None else ({"error": native_error} if native_error else None)
             out["other_exchange"] = exchange_other
+            if exchange_fallback:
+                out["exchange_fallback"] = exchange_fallback
         if verified is not None:
             out["assembled_frame_equals_single_gpu_frame"] = verified
         print(json.dumps(out), flush=True)
