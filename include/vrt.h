@@ -59,6 +59,11 @@ extern "C" {
                                       for the block's frames (A/B measurements and tests; same pixels) */
 #define VRT_FLAG_NO_CULL_RECT 128 /* the host computes no cull rectangle: every wave looks at the scene and slab-tests its rays
                                     (measurements of what the rectangle saves; same pixels) */
+#define VRT_FLAG_FULL_ONE_KERNEL 256 /* full closest hit (point / spot lights, mirror bounces, material textures): one kernel even for a block
+                                       of frames — vrt_render_block's launches otherwise run it as three passes (camera-ray march /
+                                       light shadow rays / shading + bounces; same pixels and counters, more waves per SIMD).  A lone
+                                       frame is one kernel by default */
+#define VRT_FLAG_FULL_THREE_PASS 512 /* ... and the three passes even for a lone frame (tests, measurements).  Not both */
 #define VRT_FLAG_NO_TIMING 16    /* the launch records no event pair: vrt_last_timing / vrt_timing_history report 0 ms for it.
                                    An event pair costs 5-7 us of queue time per launch (profiles/r02_launch_overhead.txt);
                                    callers that keep many small launches in flight time a sample of them */
@@ -182,8 +187,8 @@ typedef struct vrt_params {
     int32_t flags;        /* bits 0-1: blockIdx→tile map, 0 supertile (default) / 1 XCD band / 2 linear
                              (speed only, never results); bit 2: VRT_FLAG_DIAG_TIMELINE; bit 3:
                              VRT_FLAG_OUTPUT_RGBA8; bit 4: VRT_FLAG_NO_TIMING; bit 5: accepted and ignored (it was round 1's
-                             VRT_FLAG_SKIP_EMPTY: the march never samples empty cells now); bit 6: VRT_FLAG_BLOCK_PER_FRAME; bit 7: VRT_FLAG_NO_CULL_RECT.
-                             Others 0 */
+                             VRT_FLAG_SKIP_EMPTY: the march never samples empty cells now); bit 6: VRT_FLAG_BLOCK_PER_FRAME; bit 7: VRT_FLAG_NO_CULL_RECT;
+                             bit 8: VRT_FLAG_FULL_ONE_KERNEL; bit 9: VRT_FLAG_FULL_THREE_PASS.  Others 0 */
     float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
     float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
     float step_min;       /* lower bound of one march step (ray-parameter units) */

@@ -1256,8 +1256,15 @@ def test_random_scenes_parity(oracle_lib, seed):
     assert r.Start()
     try:
         img, t = gpu_render(r, sc, p)
+        # the full closest hit's three-pass form (what a block of frames runs; a scene without extra lights, bounces or textures
+        # never runs it and renders the same way twice): the same bits and the same counters as the one kernel
+        p3 = _abi.vrt_params.from_buffer_copy(p)
+        p3.flags |= _abi.FLAG_FULL_THREE_PASS
+        img3, t3 = gpu_render(r, sc, p3)
     finally:
         r.Stop()
+    assert np.array_equal(img, img3), f"seed {seed}: three-pass form differs in {np.count_nonzero(img != img3)} values"
+    assert {k: t[k] for k in STAT_KEYS} == {k: t3[k] for k in STAT_KEYS}, f"seed {seed}"
     ref, st = OracleScene(sc).render(p, threads=8)
     assert not np.isnan(img).any()
     err = np.abs(img - ref)

@@ -18,13 +18,15 @@ for name, sc, bounces in (("config 3 volume, Cube mode (exact voxel walk, lean k
     r=v.VHipRenderer(); assert r.Start(); r.SetSceneToRender(sc); r.ResizeRenderOutput(W,H); r.SyncWithScene()
     G=_abi.MAX_BLOCK_FRAMES  # ONE launch per block of 48 frames, one stream
     buf=torch.empty((G,H,W,4),dtype=torch.float32,device="cuda:0")
-    def run(n):
+    def run(n, q):
         for i in range(n):
-            r.render_block(p,G,buf.data_ptr(),H*W*16,0)
+            r.render_block(q,G,buf.data_ptr(),H*W*16,0)
         torch.cuda.synchronize()
-    run(6)  # the GPU's clocks take tens of milliseconds to ramp: untimed
-    t0=time.perf_counter(); run(12); dt=(time.perf_counter()-t0)/(12*G)
-    t=r.last_timing()
-    rays=t["primary_rays"]+t["shadow_rays"]+t["bounce_rays"]
-    print(f"{name}: {dt*1e3:.4f} ms/frame, {rays/dt/1e9:.2f} Grays/s, rays/frame {rays}, samples/ray {(t['primary_steps']+t['shadow_steps'])/rays:.2f}, hits {t['hits']}")
+    for form, flag in (("three passes", 0), ("one kernel", _abi.FLAG_FULL_ONE_KERNEL)):
+        q=_abi.vrt_params.from_buffer_copy(p); q.flags |= flag
+        run(6, q)  # the GPU's clocks take tens of milliseconds to ramp: untimed
+        t0=time.perf_counter(); run(12, q); dt=(time.perf_counter()-t0)/(12*G)
+        t=r.last_timing()
+        rays=t["primary_rays"]+t["shadow_rays"]+t["bounce_rays"]
+        print(f"{name} [{form}]: {dt*1e3:.4f} ms/frame, {rays/dt/1e9:.2f} Grays/s, rays/frame {rays}, samples/ray {(t['primary_steps']+t['shadow_steps'])/rays:.2f}, hits {t['hits']}")
     r.Stop()

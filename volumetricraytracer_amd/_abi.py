@@ -43,6 +43,8 @@ FLAG_OUTPUT_RGBA8 = 8
 FLAG_NO_TIMING = 16
 FLAG_BLOCK_PER_FRAME = 64
 FLAG_NO_CULL_RECT = 128
+FLAG_FULL_ONE_KERNEL = 256   # full closest hit of a block of frames as ONE kernel (default: three passes)
+FLAG_FULL_THREE_PASS = 512   # ... and three passes even for a lone frame
 MAX_BLOCK_FRAMES = 48  # frames one march launch covers (csrc/vrt_device.h kMaxBlockFrames)
 
 FORMAT_F32 = 0

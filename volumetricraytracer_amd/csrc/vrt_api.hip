@@ -165,6 +165,11 @@ struct DeviceState {
     bool stats_bound[kStatSlots] = {};
     uint64_t stats_used[kStatSlots] = {}; /* launch number of the last use (LRU) */
     std::vector<unsigned*> stats_retired;
+    /* three-pass full closest hit: hit records of a launch (16 + 4 bytes per pixel of the block's tiles + 8 per wave), per launch
+       stream like the counters, allocated by the first such launch of that size */
+    void* d_pass[kStatSlots] = {};
+    size_t pass_cap[kStatSlots] = {}; /* records */
+    std::vector<void*> pass_retired;
     int last_slot = 0;
     unsigned* d_diag = nullptr;  /* allocated on first use of VRT_FLAG_DIAG_TIMELINE (never in a capture) */
     int last_blocks = 0;         /* workgroups per frame of the last launch */
@@ -533,6 +538,9 @@ void destroy_device(DeviceState& D) {
     for (int i = 0; i < kStatSlots; i++)
         if (D.d_stats[i]) (void)hipFree(D.d_stats[i]);
     for (unsigned* r : D.stats_retired) (void)hipFree(r);
+    for (int i = 0; i < kStatSlots; i++)
+        if (D.d_pass[i]) (void)hipFree(D.d_pass[i]);
+    for (void* r : D.pass_retired) (void)hipFree(r);
     if (D.d_diag) (void)hipFree(D.d_diag);
     if (D.joined) (void)hipEventDestroy(D.joined);
     if (D.events_ok)
@@ -705,7 +713,9 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
     if (p->mode < VRT_MODE_INTERP || p->mode > VRT_MODE_CUBE_NOTEX_UNLIT) return VRT_ERR_INVALID;
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_CELLS) return VRT_ERR_INVALID;
     /* (bit 5 was round 1's VRT_FLAG_SKIP_EMPTY: empty-space skipping is always on now; the bit is accepted and ignored) */
-    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_NO_TIMING | 32 | VRT_FLAG_BLOCK_PER_FRAME | VRT_FLAG_NO_CULL_RECT)) != 0 || (p->flags & 3) == 3)
+    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_NO_TIMING | 32 | VRT_FLAG_BLOCK_PER_FRAME | VRT_FLAG_NO_CULL_RECT |
+                      VRT_FLAG_FULL_ONE_KERNEL | VRT_FLAG_FULL_THREE_PASS)) != 0 || (p->flags & 3) == 3 ||
+        ((p->flags & VRT_FLAG_FULL_ONE_KERNEL) && (p->flags & VRT_FLAG_FULL_THREE_PASS)))
         return VRT_ERR_INVALID;
     if (!ctx->have_scene) return VRT_ERR_NOT_READY;
     return VRT_OK;
@@ -932,6 +942,25 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
     }
     D.last_slot = slot;
     F.stats = D.d_stats[slot];
+    /* the full closest hit of a block of frames runs as three passes (vrt_kernels.hip, primary_pass_kernel); a lone frame as one
+       kernel: three launches would pay a launch's latency-bound tail three times */
+    const bool passes = F.full && !F.diag && ((n_frames > 1 && !(p->flags & VRT_FLAG_FULL_ONE_KERNEL)) || (p->flags & VRT_FLAG_FULL_THREE_PASS));
+    if (passes) {
+        const size_t per_frame = (size_t)D.last_blocks * 256, records = per_frame * (size_t)n_frames;
+        if (per_frame > 0xffffffffull) return VRT_ERR_INVALID;
+        if (D.pass_cap[slot] < records) {
+            void* grown = nullptr;
+            HIP_TRY(hipMalloc(&grown, records * (sizeof(HitRecord) + sizeof(unsigned)) + records / 64 * sizeof(unsigned long long)));
+            if (D.d_pass[slot]) D.pass_retired.push_back(D.d_pass[slot]);
+            D.d_pass[slot] = grown;
+            D.pass_cap[slot] = records;
+        }
+        char* base = static_cast<char*>(D.d_pass[slot]);
+        F.hit_rec = reinterpret_cast<HitRecord*>(base);
+        F.hit_mask = reinterpret_cast<unsigned long long*>(base + D.pass_cap[slot] * sizeof(HitRecord));
+        F.hit_aux = reinterpret_cast<unsigned*>(base + D.pass_cap[slot] * sizeof(HitRecord) + D.pass_cap[slot] / 64 * sizeof(unsigned long long));
+        F.rec_stride = (uint32_t)per_frame;
+    }
     D.last_diag = F.diag != 0;
     if (F.diag) {
         if (stat_blocks > (size_t)kMaxBlocks) return VRT_ERR_INVALID; /* the timeline buffer holds kMaxBlocks workgroups */

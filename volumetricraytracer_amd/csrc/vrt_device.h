@@ -139,6 +139,10 @@ struct DCam {
 inline uint32_t pack_cull(int x, int y) { return (uint32_t)x | ((uint32_t)y << 16); }
 
 /* Everything the frames of a launch share; passed by value (kernarg segment → scalar loads). */
+struct HitRecord {
+    float nx, ny, nz, t;
+};
+
 struct DFrame {
     float inv_w, inv_h; /* 1 / width, 1 / height */
     /* directional light */
@@ -186,6 +190,13 @@ struct DFrame {
     const DVolume* vol0;       /* single-instance scenes: vols + inst[0].slot, resolved on the host so that a wave loads its instance
                                   and its volume record side by side instead of one after the other (four out of five waves of
                                   a frame only need them to find out that their rays miss) */
+    /* full closest hit in three passes (primary march / light shadow rays / shading + bounces), null: the one-kernel form.
+       One record per (frame, wave, lane) in the launch's own order: record ((frame * blocks + b) * 4 + wave) * 64 + lane. */
+    HitRecord* hit_rec;        /* {world normal, t} of the camera ray's closest hit (hit lanes only) */
+    unsigned* hit_aux;         /* instance | shadowed-by-light bits << 16 (bit 0 directional, 1.. point, 6.. spot lights) */
+    unsigned long long* hit_mask; /* per (frame, wave): the lanes whose camera ray hit */
+    uint32_t rec_stride;       /* records between the frames of a launch (= workgroups per frame * 64) */
+    int32_t pad2_;
 };
 
 /* The kernarg of a march launch: the shared part and one DCam per frame of the block.  The dispatcher walks blockIdx.x

@@ -1072,7 +1072,7 @@ struct Counters {
  */
 /* UNIT: every ray / hit counter of a lane is 0 or 1 (the lean kernels): one ballot + popcount each on the scalar unit instead of
    a 12-instruction shuffle reduction. */
-template <bool DIAG, bool UNIT = false>
+template <bool DIAG, bool UNIT = false, bool ADD = false /* a later pass of a launch adds to the record an earlier one wrote */>
 __device__ __forceinline__ void write_records(const DFrame& F, int frame, int b, int wave, int lane, Counters k, const DiagAcc& dg,
                                               unsigned long long t_start) {
     const size_t frame_words = (size_t)(unsigned)frame * F.stats_stride; /* this frame's records within the launch's buffers */
@@ -1098,7 +1098,9 @@ __device__ __forceinline__ void write_records(const DFrame& F, int frame, int b,
     if (F.stats != nullptr && lane < 8) {
         unsigned v = lane == 0 ? k.n_primary : lane == 1 ? k.n_shadow : lane == 2 ? k.n_bounce : lane == 3 ? k.s_primary
                    : lane == 4 ? k.s_shadow : lane == 5 ? k.n_hits : lane == 6 ? exhausted : 0u;
-        F.stats[frame_words + ((size_t)b * 4 + wave) * kStatRecord + lane] = v;
+        unsigned* const rec = F.stats + (frame_words + ((size_t)b * 4 + wave) * kStatRecord + lane);
+        if constexpr (ADD) v += *rec;
+        *rec = v;
     }
     if constexpr (DIAG) {
         /* diagnostic timeline record: where and when this wave ran and where its march cycles went
@@ -1370,43 +1372,75 @@ __device__ __forceinline__ void textured_surface(const DVolume* __restrict__ V, 
  */
 constexpr int kMaxDepth = 3;
 
-template <int PATH, bool SINGLE>
-__global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DBlock B) {
+#ifndef VRT_FULL_WAVES
+#define VRT_FULL_WAVES 1
+#endif
+/* The record of this wave's lane in the three-pass form (DFrame::hit_rec / hit_aux), and the wave's word of hit_mask. */
+__device__ __forceinline__ size_t pass_record(const DFrame& F, int frame, int b, int wave, int lane) {
+    return (size_t)(unsigned)frame * F.rec_stride + (size_t)(((unsigned)b * 4u + (unsigned)wave) * 64u + (unsigned)lane);
+}
+__device__ __forceinline__ size_t pass_wave(const DFrame& F, int frame, int b, int wave) {
+    return ((size_t)(unsigned)frame * F.rec_stride >> 6) + (size_t)((unsigned)b * 4u + (unsigned)wave);
+}
+constexpr unsigned kShadowBitDir = 1u << 16, kShadowBitPoint = 2u << 16, kShadowBitSpot = 64u << 16;
+
+/* SHADE_PASS: third pass of the three-pass form (below): the camera ray's hit comes from the first pass's record, the verdicts of its
+ * light shadow rays from the second's bits; everything behind a mirror bounce is traced here as in the one-kernel form. */
+template <int PATH, bool SINGLE, bool SHADE_PASS = false>
+__global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(VRT_FULL_WAVES))) void march_kernel_full(const DBlock B) {
     const DFrame& F = B.f;
     const int frame = (int)blockIdx.y;
-    const DCam C = load_cam(B, frame);
     int b, wave;
     block_and_wave(b, wave);
+    const int lane = (int)threadIdx.x & 63;
+    bool rec_hit = false;
+    if constexpr (SHADE_PASS) {
+        const unsigned long long m = F.hit_mask[pass_wave(F, frame, b, wave)];
+        if (m == 0ull) return; /* sky: the first pass stored these pixels and their records */
+        rec_hit = ((m >> lane) & 1ull) != 0ull;
+    }
+    const DCam C = load_cam(B, frame);
     int tile_x, tile_y;
     tile_of_block(F, b, (int)gridDim.x / kMarchGridMul, tile_x, tile_y);
-    const int lane = (int)threadIdx.x & 63;
     const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
     const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int py = frame_row(F, pyl);
-    const bool valid = tile_x < F.tiles_x && tile_y < F.tiles_y && px < F.width && pyl < F.rows && py < F.height;
+    const bool valid = SHADE_PASS ? rec_hit : (tile_x < F.tiles_x && tile_y < F.tiles_y && px < F.width && pyl < F.rows && py < F.height);
 
     Counters k;
     DiagAcc dg;
-    const bool reach = wave_can_reach(C, valid, px, py);
+    const bool reach = SHADE_PASS ? true : wave_can_reach(C, valid, px, py);
     if (valid) {
         F3 o, d;
         camera_ray(F, C, px, py, o, d);
-        k.n_primary = 1;
+        if constexpr (!SHADE_PASS) k.n_primary = 1;
         F3 direct[kMaxDepth - 1], brdf[kMaxDepth - 1];
         float ndwi[kMaxDepth - 1], fade[kMaxDepth - 1];
         int pending = 0;
         float t_base = 0.0f;
         F3 color = f3(0.0f, 0.0f, 0.0f);
+        unsigned shadow_bits = 0u;
 #pragma unroll 1
         for (int level = 1; level <= kMaxDepth; level++) {
             float t_hit = 0.0f;
             int inst = 0;
             F3 n = f3(0.0f, 0.0f, 0.0f);
-            if ((level == 1 && !reach) || !trace_closest<PATH, SINGLE, false, 2>(F, o, d, 10000.0f, t_base, t_hit, inst, n, k.s_primary, k.n_hits)) {
-                color = env_lookup(F.env, F.env_size, d);
-                break;
+            if (SHADE_PASS && level == 1) {
+                const size_t r = pass_record(F, frame, b, wave, lane);
+                const HitRecord h = F.hit_rec[r];
+                const unsigned aux = F.hit_aux[r];
+                t_hit = h.t;
+                n = f3(h.nx, h.ny, h.nz);
+                inst = (int)(aux & 0xffffu);
+                shadow_bits = aux;
+            } else {
+                if ((level == 1 && !reach) || !trace_closest<PATH, SINGLE, false, 2>(F, o, d, 10000.0f, t_base, t_hit, inst, n, k.s_primary, k.n_hits)) {
+                    color = env_lookup(F.env, F.env_size, d);
+                    break;
+                }
+                k.n_hits++;
             }
-            k.n_hits++;
+            const bool from_bits = SHADE_PASS && level == 1; /* this level's shadow rays were cast (and counted) by the second pass */
             const DVolume* V = SINGLE ? F.vol0 : F.vols + F.inst[inst].slot;
             F3 albedo = f3(V->tint[0], V->tint[1], V->tint[2]);
             float rough = V->roughness, metal = V->metallic;
@@ -1432,8 +1466,12 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DBlock 
                    blocked or not) and nothing else is added at this hit (no point / spot light, no mirror bounce) */
                 const bool lone_backfacing = F.n_point == 0 && F.n_spot == 0 && !bounce && !(dot3(n, ld) > 0.0f);
                 if (shadows && !lone_backfacing) {
-                    k.n_shadow++;
-                    sh = trace_any<PATH, SINGLE, false, true>(F, so, ld, 5000.0f, tb, k.s_shadow, k.n_hits);
+                    if (from_bits) {
+                        sh = (shadow_bits & kShadowBitDir) != 0u;
+                    } else {
+                        k.n_shadow++;
+                        sh = trace_any<PATH, SINGLE, false, true>(F, so, ld, 5000.0f, tb, k.s_shadow, k.n_hits);
+                    }
                 }
                 if (!sh) sum = sum + radiance(f3(F.light_strength, F.light_strength, F.light_strength), ld, wo, n, albedo, rough, metal, kk);
             }
@@ -1446,8 +1484,12 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DBlock 
                     const F3 ld = dl * (1.0f / dist);
                     bool sh = false;
                     if (shadows) {
-                        k.n_shadow++;
-                        sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow, k.n_hits);
+                        if (from_bits) {
+                            sh = (shadow_bits & (kShadowBitPoint << i)) != 0u;
+                        } else {
+                            k.n_shadow++;
+                            sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow, k.n_hits);
+                        }
                     }
                     if (!sh) sum = sum + radiance(f3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo, rough, metal, kk);
                 }
@@ -1468,8 +1510,12 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DBlock 
                     const F3 ld = dl * (1.0f / dist);
                     bool sh = false;
                     if (shadows) {
-                        k.n_shadow++;
-                        sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow, k.n_hits);
+                        if (from_bits) {
+                            sh = (shadow_bits & (kShadowBitSpot << i)) != 0u;
+                        } else {
+                            k.n_shadow++;
+                            sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow, k.n_hits);
+                        }
                     }
                     if (!sh) sum = sum + radiance(f3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo, rough, metal, kk);
                 }
@@ -1501,7 +1547,151 @@ __global__ __launch_bounds__(kMarchThreads) void march_kernel_full(const DBlock 
         }
         store_pixel(F, frame, (unsigned)pyl * (unsigned)F.width + (unsigned)px, color);
     }
-    write_records<false>(F, frame, b, wave, lane, k, dg, 0ull);
+    write_records<false, false, SHADE_PASS>(F, frame, b, wave, lane, k, dg, 0ull);
+}
+
+/*
+ * The full closest hit in three passes — what vrt_render_block launches for a block of frames (a lone frame keeps the one kernel
+ * above: three launches would pay the latency-bound tail of a launch three times).  The one-kernel form holds a level's whole
+ * shading state across every march (109-123 VGPRs: 4 waves per SIMD, and the march lives on occupancy,
+ * profiles/r03_sky_tile_and_occupancy_experiments.txt); here every march of the first level — the camera rays and the shadow rays
+ * of their hits, nearly all the rays of a frame — runs in a kernel that keeps almost nothing else alive:
+ *   1. primary_pass_kernel: the lean kernel's camera-ray march; a miss stores its sky pixel, a hit writes {normal, t} and its
+ *      instance (hit_rec / hit_aux) and the wave its lane mask (hit_mask);
+ *   2. shadow_pass_kernel (frames with shadows): per hit, one any-hit march per light that the one-kernel form would cast,
+ *      in its order and by its rules; the verdicts go into hit_aux as bits;
+ *   3. march_kernel_full<.., SHADE_PASS>: shading from the record and the bits; a mirror bounce continues inside this pass.
+ * Waves whose mask is zero (four out of five) end after one scalar load in passes 2 and 3.  Same rays, same arithmetic, same
+ * counters (passes 2 and 3 add to the per-wave record pass 1 wrote): bit-identical to the one-kernel form, which the tests check.
+ */
+#ifndef VRT_PRIMARY_PASS_WAVES
+#define VRT_PRIMARY_PASS_WAVES 7
+#endif
+#ifndef VRT_SHADOW_PASS_WAVES
+#define VRT_SHADOW_PASS_WAVES 7
+#endif
+template <int PATH, bool SINGLE>
+__global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu((!SINGLE && PATH != VRT_PATH_DENSE) ? VRT_PRIMARY_PASS_WAVES : 1)))
+void primary_pass_kernel(const DBlock B) {
+    const DFrame& F = B.f;
+    const int frame = (int)blockIdx.y;
+    const DCam C = load_cam(B, frame);
+    int b, wave;
+    block_and_wave(b, wave);
+    int tile_x, tile_y;
+    tile_of_block(F, b, (int)gridDim.x / kMarchGridMul, tile_x, tile_y);
+    const int lane = (int)threadIdx.x & 63;
+    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int py = frame_row(F, pyl);
+    const bool valid = tile_x < F.tiles_x && tile_y < F.tiles_y && px < F.width && pyl < F.rows && py < F.height;
+
+    Counters k;
+    DiagAcc dg;
+    const bool reach = wave_can_reach(C, valid, px, py);
+    bool hit = false;
+    if (valid) {
+        F3 o, d;
+        camera_ray(F, C, px, py, o, d);
+        k.n_primary = 1;
+        float t_hit = 0.0f;
+        int inst = 0;
+        F3 n = f3(0.0f, 0.0f, 0.0f);
+        const unsigned sky = env_fetch(F.env, F.env_size, d);
+        if (reach && trace_closest<PATH, SINGLE, false, 2>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, k.s_primary, k.n_hits)) {
+            k.n_hits += 1;
+            hit = true;
+            const size_t r = pass_record(F, frame, b, wave, lane);
+            F.hit_rec[r] = HitRecord{n.x, n.y, n.z, t_hit};
+            F.hit_aux[r] = (unsigned)inst;
+        } else {
+            store_pixel(F, frame, (unsigned)pyl * (unsigned)F.width + (unsigned)px, env_decode(sky));
+        }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) F.hit_mask[pass_wave(F, frame, b, wave)] = m;
+    write_records<false, true>(F, frame, b, wave, lane, k, dg, 0ull);
+}
+
+template <int PATH, bool SINGLE>
+__global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(VRT_SHADOW_PASS_WAVES))) void shadow_pass_kernel(const DBlock B) {
+    const DFrame& F = B.f;
+    const int frame = (int)blockIdx.y;
+    int b, wave;
+    block_and_wave(b, wave);
+    const int lane = (int)threadIdx.x & 63;
+    const unsigned long long m = F.hit_mask[pass_wave(F, frame, b, wave)];
+    if (m == 0ull) return;
+    const DCam C = load_cam(B, frame);
+    int tile_x, tile_y;
+    tile_of_block(F, b, (int)gridDim.x / kMarchGridMul, tile_x, tile_y);
+    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int py = frame_row(F, tile_y * 16 + (wave >> 1) * 8 + (lane >> 3));
+    Counters k;
+    DiagAcc dg;
+    if (((m >> lane) & 1ull) != 0ull) {
+        F3 o, d;
+        camera_ray(F, C, px, py, o, d);
+        const size_t r = pass_record(F, frame, b, wave, lane);
+        const HitRecord h = F.hit_rec[r];
+        const unsigned aux = F.hit_aux[r];
+        const F3 so = shadow_origin(F, o, d, h.t);
+        const float tb = 0.0f + h.t;
+        const F3 sun = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
+        /* the directional light's ray is left out where the one-kernel form leaves it out: it is this hit's only term and the
+           surface (with its material's normal map, if any) faces away from the light */
+        bool cast_sun = true;
+        if (F.n_point == 0 && F.n_spot == 0) {
+            const int inst = (int)(aux & 0xffffu);
+            const DVolume* V = SINGLE ? F.vol0 : F.vols + F.inst[inst].slot;
+            F3 n = f3(h.nx, h.ny, h.nz);
+            F3 albedo = f3(V->tint[0], V->tint[1], V->tint[2]);
+            float rough = V->roughness, metal = V->metallic;
+            if (F.textured) {
+                const F3 hp = f3(__builtin_fmaf(d.x, h.t, o.x), __builtin_fmaf(d.y, h.t, o.y), __builtin_fmaf(d.z, h.t, o.z));
+                textured_surface(V, SINGLE ? F.inst : F.inst + inst, hp, albedo, n, rough, metal);
+            }
+            const bool bounce = rough < 0.3f && 1 <= F.max_bounces;
+            cast_sun = bounce || dot3(n, sun) > 0.0f;
+        }
+        unsigned bits = 0u;
+        if (cast_sun) {
+            k.n_shadow++;
+            if (trace_any<PATH, SINGLE, false, true>(F, so, sun, 5000.0f, tb, k.s_shadow, k.n_hits)) bits |= kShadowBitDir;
+        }
+        const int n_lights = F.n_point + F.n_spot;
+#pragma unroll 1
+        for (int i = 0; i < n_lights; i++) {
+            const bool is_point = i < F.n_point;
+            const float* pos = is_point ? F.point[i].pos : F.spot[i - F.n_point].pos;
+            const F3 dl = f3(pos[0] - so.x, pos[1] - so.y, pos[2] - so.z);
+            const float dist = sqrtf(dot3(dl, dl));
+            float inten, least;
+            if (is_point) { /* ComputePointLightIntensity, Lighting.hlsli:17-20 */
+                const DPointLight L = F.point[i];
+                inten = L.intensity / ((1.0f + L.att_linear * dist) + (L.att_exp * dist) * dist);
+                least = 0.005f;
+            } else {        /* ComputeSpotLightIntensity, Lighting.hlsli:30-48 */
+                const DSpotLight L = F.spot[i - F.n_point];
+                const F3 sd = f3(-dl.x, -dl.y, -dl.z) * (1.0f / dist);
+                const float cs = dot3(f3(L.fwd[0], L.fwd[1], L.fwd[2]), sd);
+                inten = 0.0f;
+                if (cs >= 0.0f && cs > L.cos_angle) {
+                    const float delta = (cs - L.cos_angle) / (L.cos_falloff - L.cos_angle);
+                    const float base = L.intensity * minf_(delta, 1.0f);
+                    inten = base / ((1.0f + L.att_linear * dist) + (L.att_exp * dist) * dist);
+                }
+                least = 0.01f;
+            }
+            if (inten > least) {
+                k.n_shadow++;
+                if (trace_any<PATH, SINGLE>(F, so, dl * (1.0f / dist), dist, tb, k.s_shadow, k.n_hits))
+                    bits |= is_point ? (kShadowBitPoint << i) : (kShadowBitSpot << (i - F.n_point));
+            }
+        }
+        F.hit_aux[r] = aux | bits;
+    }
+    write_records<false, false, true>(F, frame, b, wave, lane, k, dg, 0ull);
 }
 
 /* ---- hybrid march: per-lane head, wave-cooperative LDS tail ----------------------------------- */
@@ -2093,7 +2283,14 @@ static hipError_t launch_full_t(const DBlock& B, hipStream_t stream) {
     const DFrame& F = B.f;
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), ab_lds_bytes(), stream, B);
+    const dim3 g((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), t(kMarchThreads);
+    if (F.hit_rec != nullptr) { /* three passes, see primary_pass_kernel */
+        hipLaunchKernelGGL((primary_pass_kernel<PATH, SINGLE>), g, t, ab_lds_bytes(), stream, B);
+        if (F.shadow && !F.unlit) hipLaunchKernelGGL((shadow_pass_kernel<PATH, SINGLE>), g, t, ab_lds_bytes(), stream, B);
+        hipLaunchKernelGGL((march_kernel_full<PATH, false, true>), g, t, ab_lds_bytes(), stream, B);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE>), g, t, ab_lds_bytes(), stream, B);
     return hipGetLastError();
 }
 
@@ -2103,7 +2300,10 @@ static hipError_t launch_path(const DBlock& B, bool single, bool diag_build, hip
     /* the full closest hit always walks the (wave-uniform) BVH, a one-node tree included: its single-instance specialisation
        kept every instance / volume field live across the whole kernel (128-153 VGPRs, 3 waves per SIMD, against 108-125 and 4)
        and measured 7 % slower on a one-instance scene with a point light (profiles/r02_full_closest_hit_kernel.txt) */
-    if (F.full) return launch_full_t<PATH, false>(B, stream);
+    if (F.full) {
+        if (F.hit_rec != nullptr && single) return launch_full_t<PATH, true>(B, stream); /* passes 1 and 2 without the BVH walk */
+        return launch_full_t<PATH, false>(B, stream);
+    }
     if constexpr (PATH == VRT_PATH_DENSE || PATH == VRT_PATH_BRICK || PATH == kPathBrick16 || PATH == kPathCells16) {
         if (diag_build) return single ? launch_t<PATH, true>(B, stream) : launch_t<PATH, false>(B, stream);
     }
