@@ -10,6 +10,8 @@ import copy
 _c3 = copy.copy(workloads.bench_config3())
 _c3.PointLights = [v.VPointLight(Position=(120.0, 60.0, 140.0), Color=(1.0, 0.9, 0.8), IlluminationStrength=40.0)]
 for name, sc, bounces in (("config 3 volume, Cube mode (exact voxel walk, lean kernel)", workloads.bench_config3(), 0), ("config 3 volume + one point light (single instance, full kernel)", _c3, 0), ("full_closest_hit (lights+mirror bounce)", workloads.full_closest_hit_scene(7, 64), 2), ("textured", workloads.textured_scene(7, 64), 2), ("same scene, lean kernel (no lights/bounces)", None, 0)):
+    if len(sys.argv) > 1 and sys.argv[1] not in name:
+        continue
     if sc is None:
         sc = workloads.full_closest_hit_scene(7, 64); sc.PointLights=[]; sc.SpotLights=[]
     W,H=1920,1080
@@ -22,7 +24,7 @@ for name, sc, bounces in (("config 3 volume, Cube mode (exact voxel walk, lean k
         for i in range(n):
             r.render_block(q,G,buf.data_ptr(),H*W*16,0)
         torch.cuda.synchronize()
-    for form, flag in (("three passes", 0), ("one kernel", _abi.FLAG_FULL_ONE_KERNEL)):
+    for form, flag in (("three passes", 0), ("one kernel", _abi.FLAG_FULL_ONE_KERNEL))[:1 if len(sys.argv) > 2 else 2]:
         q=_abi.vrt_params.from_buffer_copy(p); q.flags |= flag
         run(6, q)  # the GPU's clocks take tens of milliseconds to ramp: untimed
         t0=time.perf_counter(); run(12, q); dt=(time.perf_counter()-t0)/(12*G)

@@ -878,6 +878,7 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     }
     F.textured = textured ? 1 : 0;
     F.full = (ctx->scene.n_point_lights > 0 || ctx->scene.n_spot_lights > 0 || (p->max_bounces > 0 && smooth) || textured) ? 1 : 0;
+    F.may_bounce = (p->max_bounces > 0 && (smooth || textured)) ? 1 : 0;
     F.n_inst = ctx->scene.n_instances;
     F.n_nodes = ctx->n_nodes;
     F.n_point = std::min(ctx->scene.n_point_lights, VRT_MAX_POINT_LIGHTS);

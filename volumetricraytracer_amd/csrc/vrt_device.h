@@ -190,13 +190,13 @@ struct DFrame {
     const DVolume* vol0;       /* single-instance scenes: vols + inst[0].slot, resolved on the host so that a wave loads its instance
                                   and its volume record side by side instead of one after the other (four out of five waves of
                                   a frame only need them to find out that their rays miss) */
-    /* full closest hit in three passes (primary march / light shadow rays / shading + bounces), null: the one-kernel form.
+    /* full closest hit in passes (camera-ray march / light shadow rays + shading / mirror bounces), null: the one-kernel form.
        One record per (frame, wave, lane) in the launch's own order: record ((frame * blocks + b) * 4 + wave) * 64 + lane. */
     HitRecord* hit_rec;        /* {world normal, t} of the camera ray's closest hit (hit lanes only) */
     unsigned* hit_aux;         /* instance | shadowed-by-light bits << 16 (bit 0 directional, 1.. point, 6.. spot lights) */
     unsigned long long* hit_mask; /* per (frame, wave): the lanes whose camera ray hit */
     uint32_t rec_stride;       /* records between the frames of a launch (= workgroups per frame * 64) */
-    int32_t pad2_;
+    int32_t may_bounce;        /* 1: bounces allowed and some material can mirror (smooth, or roughness from a texture) */
 };
 
 /* The kernarg of a march launch: the shared part and one DCam per frame of the block.  The dispatcher walks blockIdx.x

@@ -1384,6 +1384,49 @@ __device__ __forceinline__ size_t pass_wave(const DFrame& F, int frame, int b, i
 }
 constexpr unsigned kShadowBitDir = 1u << 16, kShadowBitPoint = 2u << 16, kShadowBitSpot = 64u << 16;
 
+/* The direct light of a hit whose shadow rays have been cast already (their verdicts in `bits`): the three light loops of
+ * march_kernel_full below, operation for operation, with a bit test where they march. */
+__device__ __forceinline__ F3 direct_light_from_bits(const DFrame& F, F3 so, F3 wo, F3 n, F3 albedo, float rough, float metal, float kk,
+                                                     bool shadows, bool bounce, unsigned bits) {
+    F3 sum = f3(0.0f, 0.0f, 0.0f);
+    {
+        const F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
+        const bool lone_backfacing = F.n_point == 0 && F.n_spot == 0 && !bounce && !(dot3(n, ld) > 0.0f);
+        const bool sh = shadows && !lone_backfacing && (bits & kShadowBitDir) != 0u;
+        if (!sh) sum = sum + radiance(f3(F.light_strength, F.light_strength, F.light_strength), ld, wo, n, albedo, rough, metal, kk);
+    }
+    for (int i = 0; i < F.n_point; i++) {
+        const DPointLight L = F.point[i];
+        const F3 dl = f3(L.pos[0] - so.x, L.pos[1] - so.y, L.pos[2] - so.z);
+        const float dist = sqrtf(dot3(dl, dl));
+        const float inten = L.intensity / ((1.0f + L.att_linear * dist) + (L.att_exp * dist) * dist);
+        if (inten > 0.005f) {
+            const F3 ld = dl * (1.0f / dist);
+            const bool sh = shadows && (bits & (kShadowBitPoint << i)) != 0u;
+            if (!sh) sum = sum + radiance(f3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo, rough, metal, kk);
+        }
+    }
+    for (int i = 0; i < F.n_spot; i++) {
+        const DSpotLight L = F.spot[i];
+        const F3 dl = f3(L.pos[0] - so.x, L.pos[1] - so.y, L.pos[2] - so.z);
+        const float dist = sqrtf(dot3(dl, dl));
+        const F3 sd = f3(-dl.x, -dl.y, -dl.z) * (1.0f / dist);
+        const float cs = dot3(f3(L.fwd[0], L.fwd[1], L.fwd[2]), sd);
+        float inten = 0.0f;
+        if (cs >= 0.0f && cs > L.cos_angle) {
+            const float delta = (cs - L.cos_angle) / (L.cos_falloff - L.cos_angle);
+            const float base = L.intensity * minf_(delta, 1.0f);
+            inten = base / ((1.0f + L.att_linear * dist) + (L.att_exp * dist) * dist);
+        }
+        if (inten > 0.01f) {
+            const F3 ld = dl * (1.0f / dist);
+            const bool sh = shadows && (bits & (kShadowBitSpot << i)) != 0u;
+            if (!sh) sum = sum + radiance(f3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo, rough, metal, kk);
+        }
+    }
+    return sum;
+}
+
 /* SHADE_PASS: third pass of the three-pass form (below): the camera ray's hit comes from the first pass's record, the verdicts of its
  * light shadow rays from the second's bits; everything behind a mirror bounce is traced here as in the one-kernel form. */
 template <int PATH, bool SINGLE, bool SHADE_PASS = false>
@@ -1459,6 +1502,9 @@ __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(V
             const bool shadows = F.shadow && level < kMaxDepth;
             const bool bounce = rough < 0.3f && level <= F.max_bounces && level < kMaxDepth;
             F3 sum = f3(0.0f, 0.0f, 0.0f);
+            if (from_bits) {
+                sum = direct_light_from_bits(F, so, wo, n, albedo, rough, metal, kk, shadows, bounce, shadow_bits);
+            } else {
             {   /* directional light */
                 const F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
                 bool sh = false;
@@ -1466,12 +1512,8 @@ __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(V
                    blocked or not) and nothing else is added at this hit (no point / spot light, no mirror bounce) */
                 const bool lone_backfacing = F.n_point == 0 && F.n_spot == 0 && !bounce && !(dot3(n, ld) > 0.0f);
                 if (shadows && !lone_backfacing) {
-                    if (from_bits) {
-                        sh = (shadow_bits & kShadowBitDir) != 0u;
-                    } else {
-                        k.n_shadow++;
-                        sh = trace_any<PATH, SINGLE, false, true>(F, so, ld, 5000.0f, tb, k.s_shadow, k.n_hits);
-                    }
+                    k.n_shadow++;
+                    sh = trace_any<PATH, SINGLE, false, true>(F, so, ld, 5000.0f, tb, k.s_shadow, k.n_hits);
                 }
                 if (!sh) sum = sum + radiance(f3(F.light_strength, F.light_strength, F.light_strength), ld, wo, n, albedo, rough, metal, kk);
             }
@@ -1484,12 +1526,8 @@ __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(V
                     const F3 ld = dl * (1.0f / dist);
                     bool sh = false;
                     if (shadows) {
-                        if (from_bits) {
-                            sh = (shadow_bits & (kShadowBitPoint << i)) != 0u;
-                        } else {
-                            k.n_shadow++;
-                            sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow, k.n_hits);
-                        }
+                        k.n_shadow++;
+                        sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow, k.n_hits);
                     }
                     if (!sh) sum = sum + radiance(f3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo, rough, metal, kk);
                 }
@@ -1510,15 +1548,12 @@ __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(V
                     const F3 ld = dl * (1.0f / dist);
                     bool sh = false;
                     if (shadows) {
-                        if (from_bits) {
-                            sh = (shadow_bits & (kShadowBitSpot << i)) != 0u;
-                        } else {
-                            k.n_shadow++;
-                            sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow, k.n_hits);
-                        }
+                        k.n_shadow++;
+                        sh = trace_any<PATH, SINGLE>(F, so, ld, dist, tb, k.s_shadow, k.n_hits);
                     }
                     if (!sh) sum = sum + radiance(f3(L.color[0] * inten, L.color[1] * inten, L.color[2] * inten), ld, wo, n, albedo, rough, metal, kk);
                 }
+            }
             }
             if (bounce) {
                 /* mirror bounce: continue along the reflected ray, fold this level in afterwards */
@@ -1551,16 +1586,18 @@ __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(V
 }
 
 /*
- * The full closest hit in three passes — what vrt_render_block launches for a block of frames (a lone frame keeps the one kernel
- * above: three launches would pay the latency-bound tail of a launch three times).  The one-kernel form holds a level's whole
- * shading state across every march (109-123 VGPRs: 4 waves per SIMD, and the march lives on occupancy,
+ * The full closest hit in passes — what vrt_render_block launches for a block of frames (a lone frame keeps the one kernel
+ * above: every further launch pays a launch's latency-bound tail again).  The one-kernel form holds a level's whole shading state
+ * across every march (109-123 VGPRs: 4 waves per SIMD, and the march lives on occupancy,
  * profiles/r03_sky_tile_and_occupancy_experiments.txt); here every march of the first level — the camera rays and the shadow rays
- * of their hits, nearly all the rays of a frame — runs in a kernel that keeps almost nothing else alive:
+ * of their hits, nearly all the rays of a frame — runs in a kernel that keeps almost nothing else alive (58 VGPRs, 8 waves):
  *   1. primary_pass_kernel: the lean kernel's camera-ray march; a miss stores its sky pixel, a hit writes {normal, t} and its
  *      instance (hit_rec / hit_aux) and the wave its lane mask (hit_mask);
- *   2. shadow_pass_kernel (frames with shadows): per hit, one any-hit march per light that the one-kernel form would cast,
- *      in its order and by its rules; the verdicts go into hit_aux as bits;
- *   3. march_kernel_full<.., SHADE_PASS>: shading from the record and the bits; a mirror bounce continues inside this pass.
+ *   2. light_pass_kernel: per hit, one any-hit march per light that the one-kernel form would cast, in its order and by its
+ *      rules, the verdicts collected as bits; then the hit's shading from the record and the bits, and the pixel — unless the
+ *      material mirrors: that lane's bits go to hit_aux, and the wave's mask becomes the mask of its bouncing lanes;
+ *   3. march_kernel_full<.., SHADE_PASS> (only frames that can bounce): level 1 from the record and the bits, everything behind
+ *      the mirror as in the one-kernel form.
  * Waves whose mask is zero (four out of five) end after one scalar load in passes 2 and 3.  Same rays, same arithmetic, same
  * counters (passes 2 and 3 add to the per-wave record pass 1 wrote): bit-identical to the one-kernel form, which the tests check.
  */
@@ -1614,7 +1651,7 @@ void primary_pass_kernel(const DBlock B) {
 }
 
 template <int PATH, bool SINGLE>
-__global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(VRT_SHADOW_PASS_WAVES))) void shadow_pass_kernel(const DBlock B) {
+__global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(VRT_SHADOW_PASS_WAVES))) void light_pass_kernel(const DBlock B) {
     const DFrame& F = B.f;
     const int frame = (int)blockIdx.y;
     int b, wave;
@@ -1626,22 +1663,77 @@ __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(V
     int tile_x, tile_y;
     tile_of_block(F, b, (int)gridDim.x / kMarchGridMul, tile_x, tile_y);
     const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int py = frame_row(F, tile_y * 16 + (wave >> 1) * 8 + (lane >> 3));
+    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int py = frame_row(F, pyl);
     Counters k;
     DiagAcc dg;
+    bool bounces = false;
     if (((m >> lane) & 1ull) != 0ull) {
         F3 o, d;
         camera_ray(F, C, px, py, o, d);
         const size_t r = pass_record(F, frame, b, wave, lane);
-        const HitRecord h = F.hit_rec[r];
-        const unsigned aux = F.hit_aux[r];
-        const F3 so = shadow_origin(F, o, d, h.t);
-        const float tb = 0.0f + h.t;
-        const F3 sun = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
-        /* the directional light's ray is left out where the one-kernel form leaves it out: it is this hit's only term and the
-           surface (with its material's normal map, if any) faces away from the light */
-        bool cast_sun = true;
-        if (F.n_point == 0 && F.n_spot == 0) {
+        unsigned bits = 0u;
+        if (F.shadow && !F.unlit) {
+            const HitRecord h = F.hit_rec[r];
+            const F3 so = shadow_origin(F, o, d, h.t);
+            const float tb = 0.0f + h.t;
+            const F3 sun = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
+            /* the directional light's ray is left out where the one-kernel form leaves it out: it is this hit's only term and the
+               surface (with its material's normal map, if any) faces away from the light */
+            bool cast_sun = true;
+            if (F.n_point == 0 && F.n_spot == 0) {
+                const int inst = (int)F.hit_aux[r];
+                const DVolume* V = SINGLE ? F.vol0 : F.vols + F.inst[inst].slot;
+                F3 n = f3(h.nx, h.ny, h.nz);
+                F3 albedo = f3(V->tint[0], V->tint[1], V->tint[2]);
+                float rough = V->roughness, metal = V->metallic;
+                if (F.textured) {
+                    const F3 hp = f3(__builtin_fmaf(d.x, h.t, o.x), __builtin_fmaf(d.y, h.t, o.y), __builtin_fmaf(d.z, h.t, o.z));
+                    textured_surface(V, SINGLE ? F.inst : F.inst + inst, hp, albedo, n, rough, metal);
+                }
+                const bool bounce = rough < 0.3f && 1 <= F.max_bounces;
+                cast_sun = bounce || dot3(n, sun) > 0.0f;
+            }
+            if (cast_sun) {
+                k.n_shadow++;
+                if (trace_any<PATH, SINGLE, false, true>(F, so, sun, 5000.0f, tb, k.s_shadow, k.n_hits)) bits |= kShadowBitDir;
+            }
+            const int n_lights = F.n_point + F.n_spot;
+#pragma unroll 1
+            for (int i = 0; i < n_lights; i++) {
+                const bool is_point = i < F.n_point;
+                const float* pos = is_point ? F.point[i].pos : F.spot[i - F.n_point].pos;
+                const F3 dl = f3(pos[0] - so.x, pos[1] - so.y, pos[2] - so.z);
+                const float dist = sqrtf(dot3(dl, dl));
+                float inten, least;
+                if (is_point) { /* ComputePointLightIntensity, Lighting.hlsli:17-20 */
+                    const DPointLight L = F.point[i];
+                    inten = L.intensity / ((1.0f + L.att_linear * dist) + (L.att_exp * dist) * dist);
+                    least = 0.005f;
+                } else {        /* ComputeSpotLightIntensity, Lighting.hlsli:30-48 */
+                    const DSpotLight L = F.spot[i - F.n_point];
+                    const F3 sd = f3(-dl.x, -dl.y, -dl.z) * (1.0f / dist);
+                    const float cs = dot3(f3(L.fwd[0], L.fwd[1], L.fwd[2]), sd);
+                    inten = 0.0f;
+                    if (cs >= 0.0f && cs > L.cos_angle) {
+                        const float delta = (cs - L.cos_angle) / (L.cos_falloff - L.cos_angle);
+                        const float base = L.intensity * minf_(delta, 1.0f);
+                        inten = base / ((1.0f + L.att_linear * dist) + (L.att_exp * dist) * dist);
+                    }
+                    least = 0.01f;
+                }
+                if (inten > least) {
+                    k.n_shadow++;
+                    if (trace_any<PATH, SINGLE>(F, so, dl * (1.0f / dist), dist, tb, k.s_shadow, k.n_hits))
+                        bits |= is_point ? (kShadowBitPoint << i) : (kShadowBitSpot << (i - F.n_point));
+                }
+            }
+        }
+        /* the hit's shading (level 1 of march_kernel_full) from the record, read again behind the marches so that nothing of it
+           is alive across them */
+        {
+            const HitRecord h = F.hit_rec[r];
+            const unsigned aux = F.hit_aux[r];
             const int inst = (int)(aux & 0xffffu);
             const DVolume* V = SINGLE ? F.vol0 : F.vols + F.inst[inst].slot;
             F3 n = f3(h.nx, h.ny, h.nz);
@@ -1651,46 +1743,20 @@ __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(V
                 const F3 hp = f3(__builtin_fmaf(d.x, h.t, o.x), __builtin_fmaf(d.y, h.t, o.y), __builtin_fmaf(d.z, h.t, o.z));
                 textured_surface(V, SINGLE ? F.inst : F.inst + inst, hp, albedo, n, rough, metal);
             }
-            const bool bounce = rough < 0.3f && 1 <= F.max_bounces;
-            cast_sun = bounce || dot3(n, sun) > 0.0f;
-        }
-        unsigned bits = 0u;
-        if (cast_sun) {
-            k.n_shadow++;
-            if (trace_any<PATH, SINGLE, false, true>(F, so, sun, 5000.0f, tb, k.s_shadow, k.n_hits)) bits |= kShadowBitDir;
-        }
-        const int n_lights = F.n_point + F.n_spot;
-#pragma unroll 1
-        for (int i = 0; i < n_lights; i++) {
-            const bool is_point = i < F.n_point;
-            const float* pos = is_point ? F.point[i].pos : F.spot[i - F.n_point].pos;
-            const F3 dl = f3(pos[0] - so.x, pos[1] - so.y, pos[2] - so.z);
-            const float dist = sqrtf(dot3(dl, dl));
-            float inten, least;
-            if (is_point) { /* ComputePointLightIntensity, Lighting.hlsli:17-20 */
-                const DPointLight L = F.point[i];
-                inten = L.intensity / ((1.0f + L.att_linear * dist) + (L.att_exp * dist) * dist);
-                least = 0.005f;
-            } else {        /* ComputeSpotLightIntensity, Lighting.hlsli:30-48 */
-                const DSpotLight L = F.spot[i - F.n_point];
-                const F3 sd = f3(-dl.x, -dl.y, -dl.z) * (1.0f / dist);
-                const float cs = dot3(f3(L.fwd[0], L.fwd[1], L.fwd[2]), sd);
-                inten = 0.0f;
-                if (cs >= 0.0f && cs > L.cos_angle) {
-                    const float delta = (cs - L.cos_angle) / (L.cos_falloff - L.cos_angle);
-                    const float base = L.intensity * minf_(delta, 1.0f);
-                    inten = base / ((1.0f + L.att_linear * dist) + (L.att_exp * dist) * dist);
-                }
-                least = 0.01f;
-            }
-            if (inten > least) {
-                k.n_shadow++;
-                if (trace_any<PATH, SINGLE>(F, so, dl * (1.0f / dist), dist, tb, k.s_shadow, k.n_hits))
-                    bits |= is_point ? (kShadowBitPoint << i) : (kShadowBitSpot << (i - F.n_point));
+            bounces = !F.unlit && rough < 0.3f && 1 <= F.max_bounces;
+            if (bounces) {
+                F.hit_aux[r] = aux | bits; /* the third pass shades this hit and follows its mirror ray */
+            } else {
+                F3 color = albedo;
+                if (!F.unlit)
+                    color = direct_light_from_bits(F, shadow_origin(F, o, d, h.t), f3(-d.x, -d.y, -d.z), n, albedo, rough, metal, V->k, F.shadow != 0, false, bits);
+                store_pixel(F, frame, (unsigned)pyl * (unsigned)F.width + (unsigned)px, color);
             }
         }
-        F.hit_aux[r] = aux | bits;
     }
+    /* the wave's mask now names the lanes that bounce: all the third pass looks at */
+    const unsigned long long bm = __ballot(bounces);
+    if (lane == 0) F.hit_mask[pass_wave(F, frame, b, wave)] = bm;
     write_records<false, false, true>(F, frame, b, wave, lane, k, dg, 0ull);
 }
 
@@ -2286,8 +2352,8 @@ static hipError_t launch_full_t(const DBlock& B, hipStream_t stream) {
     const dim3 g((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), t(kMarchThreads);
     if (F.hit_rec != nullptr) { /* three passes, see primary_pass_kernel */
         hipLaunchKernelGGL((primary_pass_kernel<PATH, SINGLE>), g, t, ab_lds_bytes(), stream, B);
-        if (F.shadow && !F.unlit) hipLaunchKernelGGL((shadow_pass_kernel<PATH, SINGLE>), g, t, ab_lds_bytes(), stream, B);
-        hipLaunchKernelGGL((march_kernel_full<PATH, false, true>), g, t, ab_lds_bytes(), stream, B);
+        hipLaunchKernelGGL((light_pass_kernel<PATH, SINGLE>), g, t, ab_lds_bytes(), stream, B);
+        if (F.may_bounce) hipLaunchKernelGGL((march_kernel_full<PATH, false, true>), g, t, ab_lds_bytes(), stream, B);
         return hipGetLastError();
     }
     hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE>), g, t, ab_lds_bytes(), stream, B);
