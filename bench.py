@@ -35,6 +35,7 @@ Prints ONE JSON line on rank 0 (driver contract) extended with:
   end_to_end      vrt_render_begin/_end: march + copy of the frame to pinned host memory, pipelined
   config4         the same scene at 3840x2160 split the same N ways (BASELINE config 4), with its own anchor
   reference_texel_format   the same frames with the volume kept as the reference's 16-bit texel (opt-in device format)
+  full_closest_hit         the same frames with one point light in the scene: the full closest hit, in passes and as one kernel
 """
 import argparse
 import hashlib
@@ -724,6 +725,31 @@ def main() -> None:
         for vol in sc.volumes():
             vol.set_device_format(fmt)
 
+    full_leg = None
+    if not args.no_extra_legs and args.steps > 0 and world == 1 and args.workload == "c3":
+        # the same frames with ONE point light in the scene: the full closest hit (the reference's default render mode as soon as a
+        # scene has a point / spot light, a mirroring material or a texture, SH/Raytracing_NoTex.hlsl:41-139) instead of the
+        # directional-light kernel.  A block of frames runs it in passes (camera-ray march / light shadow rays + shading / mirror
+        # bounces, vrt_kernels.hip primary_pass_kernel); VRT_FLAG_FULL_ONE_KERNEL: the one kernel a lone frame gets.
+        import copy
+        scl = copy.copy(sc)
+        scl.PointLights = [v.VPointLight(Position=(120.0, 60.0, 140.0), Color=(1.0, 0.9, 0.8), IlluminationStrength=40.0)]
+        r.SetSceneToRender(scl)
+        r.SyncWithScene()
+        sf = max(min(args.steps, 10), 1)
+        cf = batch_counts(p, W, H)
+        full_leg = {"scene": "config 3 + one point light", "frames_per_launch": G, "streams": K, "unit": "Mrays/s"}
+        for name, flag in (("passes", 0), ("one_kernel", _abi.FLAG_FULL_ONE_KERNEL)):
+            pf = params(W, H)
+            pf.flags |= flag
+            pipef = pipeline(pf, W, H, K, False)
+            ef = timed_run(pipef, sf, min(args.warmup, 3), world, cdev, B)
+            full_leg[name] = {"ms_per_frame": round(ef / (sf * B) * 1e3, 4),
+                              "value": round((cf["primary_rays"] + cf["shadow_rays"] + cf["bounce_rays"]) * sf / ef / 1e6, 2)}
+            del pipef
+        r.SetSceneToRender(sc)
+        r.SyncWithScene()
+
     if rank == 0:
         alg_bytes = v.algorithmic_bytes(t, 4 if rgba8 else 16) * fpl  # of ONE launch: fpl frames
         k_ms = float(np.mean(kms)) if kms else float("nan")
@@ -797,7 +823,7 @@ def main() -> None:
                        "marching": marching,
                        "samples_per_ray": round((psteps + ssteps) / max(rays_per_step, 1), 2)},
             "roofline": roofline, "cpu_baseline": cpu,
-            "latency": latency, "scale_anchor": scale_anchor, "end_to_end": end_to_end, "config4": config4, "reference_texel_format": texel_leg,
+            "latency": latency, "scale_anchor": scale_anchor, "end_to_end": end_to_end, "config4": config4, "reference_texel_format": texel_leg, "full_closest_hit": full_leg,
             "no_cull_rect": no_cull,
         }
         if world > 1:

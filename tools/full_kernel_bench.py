@@ -31,4 +31,13 @@ for name, sc, bounces in (("config 3 volume, Cube mode (exact voxel walk, lean k
         t=r.last_timing()
         rays=t["primary_rays"]+t["shadow_rays"]+t["bounce_rays"]
         print(f"{name} [{form}]: {dt*1e3:.4f} ms/frame, {rays/dt/1e9:.2f} Grays/s, rays/frame {rays}, samples/ray {(t['primary_steps']+t['shadow_steps'])/rays:.2f}, hits {t['hits']}")
+    if "full kernel" in name or "lights" in name:  # a lone frame, waited for: which form should a single-frame launch take?
+        for form, flag in (("passes", _abi.FLAG_FULL_THREE_PASS), ("one kernel", 0)):
+            q=_abi.vrt_params.from_buffer_copy(p); q.flags |= flag
+            def lone(n):
+                for i in range(n):
+                    r.render_block(q,1,buf.data_ptr(),H*W*16,0); torch.cuda.synchronize()
+            lone(50)
+            t0=time.perf_counter(); lone(200); dt=(time.perf_counter()-t0)/200
+            print(f"    lone frame, host waits for each [{form}]: {dt*1e3:.4f} ms/frame")
     r.Stop()

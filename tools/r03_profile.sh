@@ -19,4 +19,8 @@ timeout -k 10 300 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_I
 # hardware collects at once, and rocprofv3 then aborts and hangs — hence the time limits)
 timeout -k 10 200 rocprofv3 --pmc TD_TD_BUSY_sum TA_TA_BUSY_sum --output-format csv -d "$out/pmc_tatd" -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --no-extra-legs "$@" > "$out/bench_tatd.json" 2> "$out/tatd.err" || echo "ta/td run failed"
 timeout -k 10 200 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum --output-format csv -d "$out/pmc_tcp" -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --no-extra-legs "$@" > "$out/bench_tcp.json" 2> "$out/tcp.err" || echo "tcp run failed"
-python3 tools/r03_summarize.py "$out" "$tag" || true
+if [ -n "${VRT_PROFILE_KERNELS:-}" ]; then  # one summary per named kernel (the passes of the full closest hit)
+  for kn in $VRT_PROFILE_KERNELS; do python3 tools/r03_summarize.py "$out" "${tag}_${kn}" "$kn" || true; done
+else
+  python3 tools/r03_summarize.py "$out" "$tag" || true
+fi

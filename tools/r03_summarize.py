@@ -14,6 +14,7 @@ import sys
 from collections import defaultdict
 
 out, tag = sys.argv[1], sys.argv[2]
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "march_kernel"  # substring of the kernel's name (the passes of the full closest hit: primary_pass_kernel / light_pass_kernel)
 summary = {"tag": tag}
 lines = []
 
@@ -36,7 +37,7 @@ if stats:
         lines.append("  ".join(f"{k}={r[k]}" for k in r))
 trace = glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True)
 if trace:
-    rows = [r for r in csv.DictReader(open(trace[0])) if "march_kernel" in r.get("Kernel_Name", "")]
+    rows = [r for r in csv.DictReader(open(trace[0])) if KERNEL in r.get("Kernel_Name", "")]
     if rows:
         gmax = max(grid_total(r) for r in rows)
         full = [r for r in rows if grid_total(r) == gmax]
@@ -55,7 +56,7 @@ def counters(dirname):
     grid, span = {}, {}
     for f in files:
         for r in csv.DictReader(open(f)):
-            if "march_kernel" not in r.get("Kernel_Name", ""):
+            if KERNEL not in r.get("Kernel_Name", ""):
                 continue
             d = r["Dispatch_Id"]
             per[r["Counter_Name"]][d] += float(r["Counter_Value"])

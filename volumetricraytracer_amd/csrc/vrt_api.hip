@@ -141,6 +141,8 @@ struct FrameSlot {
     int ring = 0;       /* event-ring slot of the launch (timing) */
 };
 
+constexpr size_t kPassBytesMax = (size_t)4 << 30; /* hit records of one launch of the full closest hit in passes (1080p: 42 MB per frame) */
+
 struct DeviceState {
     int ordinal = 0;
     hipStream_t stream = nullptr;
@@ -825,6 +827,33 @@ void cull_rect(const vrt_ctx* ctx, const vrt_params* p, DCam& F) {
     F.cull_hi = pack_cull(cx1, cy1);
 }
 
+/* Which closest-hit kernel a frame of this scene needs. */
+struct ClosestHitForm {
+    bool textured, full, may_bounce;
+};
+ClosestHitForm closest_hit_form(const vrt_ctx* ctx, const vrt_params* p) {
+    /* the lean kernel covers directional light + shadow; the full closest hit is only launched when the
+       frame can need it: extra lights, or bounces allowed and some instanced material mirrors (roughness < 0.3) */
+    bool smooth = false;
+    for (int i = 0; i < ctx->scene.n_instances; i++) {
+        const HostVolume& hv = ctx->vol[ctx->scene.instances[i].volume_slot];
+        smooth = smooth || std::min(std::max(hv.mat.roughness, 0.0f), 1.0f) < 0.3f;
+    }
+    /* textured modes read the material textures; a frame needs that code only when a bound texture is in sight */
+    const bool tex_mode = p->mode == VRT_MODE_INTERP || p->mode == VRT_MODE_INTERP_UNLIT || p->mode == VRT_MODE_CUBE ||
+                          p->mode == VRT_MODE_CUBE_UNLIT;
+    bool textured = false;
+    for (int i = 0; tex_mode && i < ctx->scene.n_instances; i++) {
+        const HostVolume& hv = ctx->vol[ctx->scene.instances[i].volume_slot];
+        for (int k = 0; k < 3; k++) textured = textured || (hv.tex[k] >= 0 && ctx->tex[hv.tex[k]].used);
+    }
+    ClosestHitForm f;
+    f.textured = textured;
+    f.full = ctx->scene.n_point_lights > 0 || ctx->scene.n_spot_lights > 0 || (p->max_bounces > 0 && smooth) || textured;
+    f.may_bounce = p->max_bounces > 0 && (smooth || textured); /* (a roughness texture can make any material mirror) */
+    return f;
+}
+
 void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, const RowSet& rs, float* out,
                  unsigned* stats, DFrame& F, const SceneArrays* snapshot = nullptr) {
     const int row0 = rs.row0, rows = rs.rows;
@@ -861,24 +890,10 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.strip_rows = rs.strip_rows;
     F.strip_first = rs.strip_first;
     F.strip_stride = rs.strip_stride;
-    /* the lean kernel covers directional light + shadow; the full closest hit is only launched when the
-       frame can need it: extra lights, or bounces allowed and some instanced material mirrors (roughness < 0.3) */
-    bool smooth = false;
-    for (int i = 0; i < ctx->scene.n_instances; i++) {
-        const HostVolume& hv = ctx->vol[ctx->scene.instances[i].volume_slot];
-        smooth = smooth || std::min(std::max(hv.mat.roughness, 0.0f), 1.0f) < 0.3f;
-    }
-    /* textured modes read the material textures; a frame needs that code only when a bound texture is in sight */
-    const bool tex_mode = p->mode == VRT_MODE_INTERP || p->mode == VRT_MODE_INTERP_UNLIT || p->mode == VRT_MODE_CUBE ||
-                          p->mode == VRT_MODE_CUBE_UNLIT;
-    bool textured = false;
-    for (int i = 0; tex_mode && i < ctx->scene.n_instances; i++) {
-        const HostVolume& hv = ctx->vol[ctx->scene.instances[i].volume_slot];
-        for (int k = 0; k < 3; k++) textured = textured || (hv.tex[k] >= 0 && ctx->tex[hv.tex[k]].used);
-    }
-    F.textured = textured ? 1 : 0;
-    F.full = (ctx->scene.n_point_lights > 0 || ctx->scene.n_spot_lights > 0 || (p->max_bounces > 0 && smooth) || textured) ? 1 : 0;
-    F.may_bounce = (p->max_bounces > 0 && (smooth || textured)) ? 1 : 0;
+    const ClosestHitForm form = closest_hit_form(ctx, p);
+    F.textured = form.textured ? 1 : 0;
+    F.full = form.full ? 1 : 0;
+    F.may_bounce = form.may_bounce ? 1 : 0;
     F.n_inst = ctx->scene.n_instances;
     F.n_nodes = ctx->n_nodes;
     F.n_point = std::min(ctx->scene.n_point_lights, VRT_MAX_POINT_LIGHTS);
@@ -1316,7 +1331,12 @@ int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* bl
     /* ONE launch per kMaxBlockFrames frames (grid.y = frame; only the camera differs between the frames, it travels in the
        kernarg): the dispatcher back-fills the wave slots a frame's latency-bound tail leaves empty with the next frame's waves.
        VRT_FLAG_BLOCK_PER_FRAME: one launch per frame, back to back (what this entry point did before; A/B and tests) */
-    const int chunk = (params->flags & VRT_FLAG_BLOCK_PER_FRAME) ? 1 : kMaxBlockFrames;
+    int chunk = (params->flags & VRT_FLAG_BLOCK_PER_FRAME) ? 1 : kMaxBlockFrames;
+    {   /* the full closest hit in passes keeps 20 bytes per pixel of the launch's tiles between its passes: at most kPassBytesMax per launch */
+        const size_t per_frame = (size_t)((params->width + 15) / 16) * (size_t)((rs.rows + 15) / 16) * 256 * (sizeof(HitRecord) + sizeof(unsigned));
+        if (per_frame > 0 && closest_hit_form(ctx, params).full)
+            chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)chunk, kPassBytesMax / per_frame));
+    }
     vrt_params q = *params;
     for (int f = 0; f < block->n_frames; f += chunk) {
         const int n = std::min(chunk, block->n_frames - f);

@@ -2363,9 +2363,10 @@ static hipError_t launch_full_t(const DBlock& B, hipStream_t stream) {
 template <int PATH>
 static hipError_t launch_path(const DBlock& B, bool single, bool diag_build, hipStream_t stream) {
     const DFrame& F = B.f;
-    /* the full closest hit always walks the (wave-uniform) BVH, a one-node tree included: its single-instance specialisation
-       kept every instance / volume field live across the whole kernel (128-153 VGPRs, 3 waves per SIMD, against 108-125 and 4)
-       and measured 7 % slower on a one-instance scene with a point light (profiles/r02_full_closest_hit_kernel.txt) */
+    /* the one-kernel full closest hit always walks the (wave-uniform) BVH, a one-node tree included: its single-instance
+       specialisation kept every instance / volume field live across the whole kernel (128-153 VGPRs, 3 waves per SIMD, against
+       108-125 and 4) and measured 7 % slower on a one-instance scene with a point light (profiles/r02_full_closest_hit_kernel.txt;
+       again in round 3: 29.6 against 34.0 Grays/s).  The march passes of the pass form hold no such state: 58 / 64 VGPRs */
     if (F.full) {
         if (F.hit_rec != nullptr && single) return launch_full_t<PATH, true>(B, stream); /* passes 1 and 2 without the BVH walk */
         return launch_full_t<PATH, false>(B, stream);
