@@ -984,9 +984,24 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
  * Placement only affects speed, never results.
  */
 /* blockIdx → 16x16-pixel tile under F.tile_map (see the kernel comment). */
+/* Which residue class of supertiles an XCD renders moves on by one with every frame of a block (blockIdx.y).  The 8 XCDs work through
+ * a launch independently, each through its own eighth of the workgroups, and the launch ends with the slowest: with a fixed map one
+ * XCD carries 10 % (config 3) to 18 % (config 5) more marching than the mean, frame after frame (an orbiting camera moves the object
+ * slowly); rotated, every XCD has rendered every class after 8 frames.  Config 3: 61.0 -> 64.4 Grays/s (per frame; 63.8 with 8 phases
+ * per block, which keeps more of an XCD's L2 warm — balance matters more).  -DVRT_AB_XCD_ROT=0: the fixed map. */
+#ifndef VRT_AB_XCD_ROT
+#define VRT_AB_XCD_ROT 1
+#endif
 __device__ __forceinline__ void tile_of_block(const DFrame& F, int b, int nblk, int& tile_x, int& tile_y) {
     if (F.tile_map == kMapSupertile) {
-        const int xcd = b & 7, q = b >> 3;
+#if VRT_AB_XCD_ROT == 0
+        const int rot = 0;
+#elif VRT_AB_XCD_ROT == 1
+        const int rot = (int)blockIdx.y;
+#else
+        const int rot = ((int)blockIdx.y * 8) / F.n_frames;
+#endif
+        const int xcd = (b + rot) & 7, q = b >> 3;
         const int st = (q >> 4) * 8 + xcd;      /* supertile index, row-major over st_x columns */
         const int within = q & 15;
         const int st_x = (F.tiles_x + 3) >> 2;
