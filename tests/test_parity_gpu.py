@@ -1247,6 +1247,38 @@ def test_fused_block_launch_equals_per_frame_launches(renderer, oracle_lib, case
             assert np.abs(fused[f].cpu().numpy() - ref).max() <= TOL, (case, f)
 
 
+def test_full_closest_hit_in_passes_on_two_streams_at_once(renderer, oracle_lib):
+    """The passes of the full closest hit hand per-pixel hit records from one kernel to the next; every launch stream has its own
+    (like the counters): two streams marching different blocks of a scene with a point light at the same time give the frames
+    each gives alone, and those are the one-kernel form's (VRT_FLAG_FULL_ONE_KERNEL) bit for bit."""
+    import torch
+
+    sc = scenes.config3_torus(6, 32)
+    sc.PointLights = [v.VPointLight(Position=(150.0, 40.0, 120.0), IlluminationStrength=400.0, Color=(1.0, 0.8, 0.6, 1.0),
+                                    AttenuationLinear=0.05, AttenuationExp=0.002)]
+    n, W, H = 12, 200, 120
+    p = v.default_params(W, H, scenes.min_cell(sc), 255, shadow=True)
+    renderer.SetSceneToRender(sc)
+    renderer.ResizeRenderOutput(W, H)
+    renderer.SyncWithScene()
+    cams = _orbit(sc.Camera, 2 * n)
+    both = torch.zeros((2, n, H, W, 4), dtype=torch.float32, device="cuda:0")
+    alone = torch.zeros_like(both)
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(3):  # several rounds, so that the two streams' launches do overlap
+        for i, st in enumerate(streams):
+            renderer.render_block(p, n, both[i].data_ptr(), H * W * 16, st.cuda_stream, cameras=cams[i * n:(i + 1) * n], rows=(0, H))
+    torch.cuda.synchronize()
+    q = _abi.vrt_params.from_buffer_copy(p)
+    q.flags |= _abi.FLAG_FULL_ONE_KERNEL
+    for i in range(2):
+        renderer.render_block(q, n, alone[i].data_ptr(), H * W * 16, 0, cameras=cams[i * n:(i + 1) * n], rows=(0, H))
+        torch.cuda.synchronize()
+    assert torch.equal(both, alone) and not torch.equal(both[0], both[1])
+    assert float(both[..., :3].max()) > 0.2
+
+
 @pytest.mark.parametrize("seed", range(96))
 def test_random_scenes_parity(oracle_lib, seed):
     """Fuzz: seeded random scenes (instances with arbitrary rotations and anisotropic / mirrored scales, shell and SDF

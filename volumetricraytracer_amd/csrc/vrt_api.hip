@@ -945,6 +945,13 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
             const bool older = D.stats_bound[i] == D.stats_bound[slot] && D.stats_used[i] < D.stats_used[slot];
             if (freer || older) slot = i;
         }
+        /* the slot's previous stream may still be running a full closest hit in passes, whose hit records (unlike the counters)
+           decide pixels: wait for the device once before another stream takes them over (a 17th stream: rare) */
+        if (D.stats_bound[slot] && D.d_pass[slot] != nullptr) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (stream == nullptr || hipStreamIsCapturing(stream, &cs) != hipSuccess || cs == hipStreamCaptureStatusNone)
+                HIP_TRY(hipDeviceSynchronize());
+        }
         D.stats_bound[slot] = true;
         D.stats_stream[slot] = stream;
     }
