@@ -35,6 +35,13 @@ for seed in range(lo, hi):
             vol.set_device_format(fmt)
         what = f" path {p.path} format {fmt} k_relax {p.k_relax}"
     img, t = gpu_render(r, sc, p)
+    # the full closest hit's passes form (what a block of frames runs): the same bits and counters as the one kernel
+    p3 = _abi.vrt_params.from_buffer_copy(p)
+    p3.flags |= _abi.FLAG_FULL_THREE_PASS
+    img3, t3 = gpu_render(r, sc, p3)
+    if not np.array_equal(img, img3) or any(t[k] != t3[k] for k in STAT_KEYS):
+        bad.append(seed)
+        print(f"seed {seed}: passes form differs from the one kernel in {np.count_nonzero(img != img3)} values", {k: (t[k], t3[k]) for k in STAT_KEYS if t[k] != t3[k]}, flush=True)
     ref, st = OracleScene(sc).render(p, threads=16)
     keys = STAT_KEYS if len(sc.Objects) == 1 else ("primary_rays", "shadow_rays", "bounce_rays", "hits")
     err = float(np.abs(img - ref).max())
