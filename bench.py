@@ -5,9 +5,9 @@
 A "step" is one pass of the hot path over one batch of input: a batch of 96 full frames of the workload (default: BASELINE
 config 3 — 1920x1080, 256^3 voxelized mesh, shadow ray on), consecutive views of a camera on a short orbit through the
 workload's own view (0.25 degrees apart) — frames of a moving camera, not copies of one frame; `ms_per_frame` =
-`ms_per_step` / 96 is in the line too.  The batch is rendered by vrt_render_block: ONE march launch per block of up to 48 frames
+`ms_per_step` / 96 is in the line too.  The batch is rendered by vrt_render_block: ONE march launch per block of frames
 (the kernel's grid has a frame axis; the dispatcher back-fills the wave slots a frame's latency-bound tail leaves empty with the
-next frame's waves).  One GPU: ONE stream, two launches per step.
+next frame's waves).  One GPU: ONE stream, ONE launch per step.
 
 With N ranks (one process per GPU) the SAME frame is split N ways — strong scaling, as the metric and config 4 define it: the
 frame is cut into 8-row strips dealt round-robin to the ranks (contiguous tiles would put every object row on the middle GPUs);
@@ -496,9 +496,10 @@ def main() -> None:
     # One STEP = one batch of B frames: consecutive views of a camera on a short orbit through the workload's own view
     # (frames of a moving camera, not B copies of one frame, so a frame does not find its predecessor's lines in L2).
     B = max(args.frames_per_step, 1)
-    # frames per vrt_render_block call = per march launch: one GPU 48 (the most a launch covers); several GPUs: about 24 (a multiple
-    # of N), exchanged as ONE block per collective
-    G = min(args.block_frames or (_abi.MAX_BLOCK_FRAMES if world == 1 else multi_block_frames(world)), B)
+    # frames per vrt_render_block call = per march launch: one GPU the whole step (96: a launch's latency-bound tail is paid once per
+    # launch; beyond 48 frames the cameras are copied to the device ahead of the launch instead of travelling in the kernarg segment);
+    # several GPUs: about 24 (a multiple of N), exchanged as ONE block per collective
+    G = min(args.block_frames or (_abi.MAX_LAUNCH_FRAMES if world == 1 else multi_block_frames(world)), B)
     if rotate and G % world != 0:
         raise SystemExit(f"[bench] --exchange rotate needs --block-frames to be a multiple of the {world} ranks")
     cams = workloads.orbit_cameras(sc, B)
@@ -538,7 +539,8 @@ def main() -> None:
     pipe = pipeline(p, W, H, K, use_native)
     elapsed = timed_run(pipe, args.steps, args.warmup, world, cdev, B)
     # the event-timed march launches of the timed region: (ms, frames the launch covered); only whole blocks count
-    hist = [(ms, fr) for ms, fr in r.launch_history(200) if ms > 0.0]
+    n_timed = len(list(block_plan(args.steps * B, G, K)))  # launches of the timed region (the warm-up's come before them)
+    hist = [(ms, fr) for ms, fr in r.launch_history(min(max(n_timed, 1), 200)) if ms > 0.0]
     fpl = max((fr for _, fr in hist), default=1)  # frames per launch
     kms = [ms for ms, fr in hist if fr == fpl]
 

@@ -321,15 +321,16 @@ typedef struct vrt_camera {
  * camera for every frame) into device_rgba + f*frame_stride_bytes.  Rows of every frame: strip_rows > 0 -> the strips of
  * vrt_render_strips (first_strip, strip_stride, n_strips); strip_rows == 0 -> rows [row0, row0+rows) like vrt_render_rows. */
 typedef struct vrt_block {
-    int32_t n_frames;                 /* 1 .. 64 */
+    int32_t n_frames;                 /* 1 .. 256 */
     int32_t strip_rows, first_strip, strip_stride, n_strips;
     int32_t row0, rows;
     const vrt_camera* cameras;        /* n_frames cameras, or NULL */
     uint64_t frame_stride_bytes;      /* >= the bytes of one frame's rows, a multiple of the pixel size (16, or 4 with VRT_FLAG_OUTPUT_RGBA8) */
 } vrt_block;
 
-/* n_frames frames with ONE call and ONE march launch per 32 frames (the kernel's grid has a frame axis; the cameras travel in
- * the kernarg segment): the same pixels as n_frames calls of vrt_render_rows / vrt_render_strips with the scene's camera set to
+/* n_frames frames with ONE call and ONE march launch (the kernel's grid has a frame axis; up to 48 frames the cameras travel in
+ * the kernarg segment, for more their 64-byte records are copied to the device ahead of the launch on the same stream; a stream that
+ * is being captured into a graph gets launches of 48): the same pixels as n_frames calls of vrt_render_rows / vrt_render_strips with the scene's camera set to
  * cameras[f] in between, no host synchronisation, no allocation after the stream's first launch of that size.  The reference
  * keeps FrameCount = 3 frames in flight on its swap chain (DXConstants.cpp:23, DXRenderer.cpp:974-989) because a frame's last
  * third is a few latency-bound waves on an otherwise idle GPU; inside one launch the dispatcher back-fills those wave slots
@@ -381,7 +382,7 @@ int vrt_last_timing(vrt_ctx* ctx, vrt_timing* out);
  * returns how many were written (<= n), or a negative status. */
 int vrt_timing_history(vrt_ctx* ctx, int n, float* kernel_ms_out);
 
-/* The same, with the number of frames each launch covered (vrt_render_block: up to 32 per launch; everything else: 1). */
+/* The same, with the number of frames each launch covered (vrt_render_block: up to 256 per launch; everything else: 1). */
 int vrt_launch_history(vrt_ctx* ctx, int n, float* kernel_ms_out, int* frames_out);
 
 /* Diagnostics: per-wave records of the last frame of the last launch on the first device (which = 2, 3: of ALL frames of that

@@ -844,13 +844,13 @@ def test_bench_one_gpu_line_has_the_contract_fields(oracle_lib):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in o, k
     assert o["n_gpus"] == 1 and o["steps"] == 3 and o["warmup"] == 1 and o["unit"] == "Mrays/s" and o["vs_baseline"] is None and o["dtype"] == "f32"
-    assert o["config"]["width"] == 1920 and o["config"]["height"] == 1080 and o["config"]["streams"] == 1 and o["config"]["frames_per_launch"] == 48
+    assert o["config"]["width"] == 1920 and o["config"]["height"] == 1080 and o["config"]["streams"] == 1 and o["config"]["frames_per_launch"] == 96
     r = o["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frames_per_launch"] == 48
-    # one stream: the launches run one after the other, so their durations add up to the step (two launches per 96-frame step)
-    assert 0.85 < 2 * r["kernel_ms"] / o["ms_per_step"] <= 1.02
+    assert r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frames_per_launch"] == 96
+    # one stream, ONE launch per 96-frame step: the launch's duration is the step's
+    assert 0.85 < r["kernel_ms"] / o["ms_per_step"] <= 1.02
     # value = rays of the batch x steps / time
     assert abs(o["value"] - o["config"]["rays_per_step"] / (o["ms_per_step"] * 1e-3) / 1e6) / o["value"] < 0.01
     c = o["cpu_baseline"]
@@ -1184,8 +1184,8 @@ def _orbit(cam0, n):
 
 @pytest.mark.parametrize("case", ["lean", "bvh", "full", "lds", "cells16", "cube", "strips_rgba8"])
 def test_fused_block_launch_equals_per_frame_launches(renderer, oracle_lib, case):
-    """The march kernels' frame axis (vrt_render_block: ONE launch per 32 frames, blockIdx.y = frame, cameras in the kernarg)
-    on every kernel family: a block of MAX_BLOCK_FRAMES + 3 frames (two launches) is bit-equal to as many per-frame launches
+    """The march kernels' frame axis (vrt_render_block: ONE launch, blockIdx.y = frame, cameras in the kernarg segment or — more than
+    MAX_BLOCK_FRAMES — in device memory) on every kernel family: a block of MAX_BLOCK_FRAMES + 3 frames is bit-equal to as many per-frame launches
     (VRT_FLAG_BLOCK_PER_FRAME), frame by frame; the counters vrt_last_timing reports are those of the block's last frame
     rendered alone; three of the frames against the oracle."""
     import copy
@@ -1229,7 +1229,12 @@ def test_fused_block_launch_equals_per_frame_launches(renderer, oracle_lib, case
     renderer.render_block(p, n, fused.data_ptr(), rows * W * bpp, 0, cameras=cams, **kw)
     torch.cuda.synchronize()
     t_fused = renderer.last_timing()
-    assert [fr for _, fr in renderer.launch_history(2)] == [M, 3]
+    assert [fr for _, fr in renderer.launch_history(1)] == [n]  # more frames than the kernarg segment holds cameras: still ONE launch
+    # ... and the block's first MAX_BLOCK_FRAMES frames alone (cameras in the kernarg segment): the same frames
+    part = torch.zeros((M,) + shape[1:], dtype=dt, device="cuda:0")
+    renderer.render_block(p, M, part.data_ptr(), rows * W * bpp, 0, cameras=cams[:M], **kw)
+    torch.cuda.synchronize()
+    assert [fr for _, fr in renderer.launch_history(1)] == [M] and torch.equal(part, fused[:M])
     pf = _abi.vrt_params.from_buffer_copy(p)
     pf.flags |= _abi.FLAG_BLOCK_PER_FRAME
     renderer.render_block(pf, n, single.data_ptr(), rows * W * bpp, 0, cameras=cams, **kw)
@@ -1240,7 +1245,7 @@ def test_fused_block_launch_equals_per_frame_launches(renderer, oracle_lib, case
     assert not torch.equal(fused[0], fused[n - 1])
     assert {k: t_fused[k] for k in STAT_KEYS} == {k: t_single[k] for k in STAT_KEYS} and t_fused["primary_rays"] == (rows if not strips else 24) * W
     if not strips:
-        for f in (0, M - 1, n - 1):  # first launch's first and last frame, second launch's last
+        for f in (0, M - 1, n - 1):
             sf = copy.copy(sc)
             sf.Camera = v.VCamera(Position=cams[f][0], Rotation=cams[f][1], FOVAngle=cams[f][2])
             ref, _ = OracleScene(sf).render(p, threads=8)
@@ -1277,6 +1282,51 @@ def test_full_closest_hit_in_passes_on_two_streams_at_once(renderer, oracle_lib)
         torch.cuda.synchronize()
     assert torch.equal(both, alone) and not torch.equal(both[0], both[1])
     assert float(both[..., :3].max()) > 0.2
+
+
+def test_full_closest_hit_in_passes_can_be_captured_into_a_graph(renderer, oracle_lib):
+    """A block of frames of a scene with lights AND a mirroring material — three kernels per launch: camera-ray pass, light pass,
+    the bouncing lanes' pass — captured into a HIP graph after one warm launch of that size on the stream (which allocates the hit
+    records), replayed: the direct launch's frames; a later, larger launch on the stream retires the records, never frees them."""
+    import torch
+
+    sc = scenes.full_closest_hit_scene(5, 16)
+    n, W, H = 4, 160, 96
+    p = v.default_params(W, H, scenes.min_cell(sc), 255, shadow=True)
+    p.max_bounces = 2
+    renderer.SetSceneToRender(sc)
+    renderer.ResizeRenderOutput(W, H)
+    renderer.SyncWithScene()
+    cams = _orbit(sc.Camera, n)
+    side = torch.cuda.Stream()
+    direct = torch.zeros((n, H, W, 4), dtype=torch.float32, device="cuda:0")
+    with torch.cuda.stream(side):
+        renderer.render_block(p, n, direct.data_ptr(), H * W * 16, side.cuda_stream, cameras=cams, rows=(0, H))
+    torch.cuda.synchronize()
+    t_direct = renderer.last_timing()
+    assert t_direct["bounce_rays"] > 0 and t_direct["shadow_rays"] > 0
+    out = torch.zeros_like(direct)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        renderer.render_block(p, n, out.data_ptr(), H * W * 16, side.cuda_stream, cameras=cams, rows=(0, H))
+    assert float(out.abs().max()) == 0.0
+    for rep in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, direct)
+        if rep == 0:  # a larger block on the same stream: its hit records outgrow the captured launch's
+            bigger = torch.zeros((2 * n, H, W, 4), dtype=torch.float32, device="cuda:0")
+            with torch.cuda.stream(side):
+                renderer.render_block(p, 2 * n, bigger.data_ptr(), H * W * 16, side.cuda_stream, cameras=_orbit(sc.Camera, 2 * n), rows=(0, H))
+            torch.cuda.synchronize()
+            assert torch.equal(bigger[:n], direct)
+    q = _abi.vrt_params.from_buffer_copy(p)
+    q.flags |= _abi.FLAG_FULL_ONE_KERNEL
+    one = torch.zeros_like(direct)
+    renderer.render_block(q, n, one.data_ptr(), H * W * 16, 0, cameras=cams, rows=(0, H))
+    torch.cuda.synchronize()
+    assert torch.equal(one, direct) and {k: renderer.last_timing()[k] for k in STAT_KEYS} == {k: t_direct[k] for k in STAT_KEYS}
 
 
 @pytest.mark.parametrize("seed", range(96))

@@ -45,7 +45,8 @@ FLAG_BLOCK_PER_FRAME = 64
 FLAG_NO_CULL_RECT = 128
 FLAG_FULL_ONE_KERNEL = 256   # full closest hit of a block of frames as ONE kernel (default: three passes)
 FLAG_FULL_THREE_PASS = 512   # ... and three passes even for a lone frame
-MAX_BLOCK_FRAMES = 48  # frames one march launch covers (csrc/vrt_device.h kMaxBlockFrames)
+MAX_BLOCK_FRAMES = 48  # frames one march launch covers with their cameras in the kernarg segment (csrc/vrt_device.h kMaxBlockFrames)
+MAX_LAUNCH_FRAMES = 256  # ... with their cameras copied to device memory ahead of the launch: vrt_block.n_frames' upper bound
 
 FORMAT_F32 = 0
 FORMAT_TEXEL16 = 1

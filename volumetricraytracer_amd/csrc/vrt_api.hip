@@ -169,6 +169,12 @@ struct DeviceState {
     std::vector<unsigned*> stats_retired;
     /* three-pass full closest hit: hit records of a launch (16 + 4 bytes per pixel of the block's tiles + 8 per wave), per launch
        stream like the counters, allocated by the first such launch of that size */
+    /* launches of more than kMaxBlockFrames frames: the frames' camera records, packed into pinned host memory and copied ahead of
+       the launch on its stream (per launch stream, like the counters); `cams_copied` says when the pinned copy may be packed again */
+    DCam* d_cams[kStatSlots] = {};
+    DCam* h_cams[kStatSlots] = {};
+    hipEvent_t cams_copied[kStatSlots] = {};
+    std::vector<DCam*> cams_retired;
     void* d_pass[kStatSlots] = {};
     size_t pass_cap[kStatSlots] = {}; /* records */
     std::vector<void*> pass_retired;
@@ -540,6 +546,12 @@ void destroy_device(DeviceState& D) {
     for (int i = 0; i < kStatSlots; i++)
         if (D.d_stats[i]) (void)hipFree(D.d_stats[i]);
     for (unsigned* r : D.stats_retired) (void)hipFree(r);
+    for (int i = 0; i < kStatSlots; i++) {
+        if (D.d_cams[i]) (void)hipFree(D.d_cams[i]);
+        if (D.h_cams[i]) (void)hipHostFree(D.h_cams[i]);
+        if (D.cams_copied[i]) (void)hipEventDestroy(D.cams_copied[i]);
+    }
+    for (DCam* r : D.cams_retired) (void)hipFree(r);
     for (int i = 0; i < kStatSlots; i++)
         if (D.d_pass[i]) (void)hipFree(D.d_pass[i]);
     for (void* r : D.pass_retired) (void)hipFree(r);
@@ -914,7 +926,8 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
    camera) into out + f * frame_stride bytes.  No allocation after the stream's first launch of that size, no host sync. */
 int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet& rs, float* out, hipStream_t stream,
                  int ring, const SceneArrays* snapshot = nullptr, int n_frames = 1, const vrt_camera* cams = nullptr, size_t frame_stride = 0) {
-    if (n_frames < 1 || n_frames > kMaxBlockFrames) return VRT_ERR_INVALID;
+    if (n_frames < 1 || n_frames > kMaxLaunchFrames) return VRT_ERR_INVALID;
+    const bool device_cams = n_frames > kMaxBlockFrames; /* more cameras than the kernarg segment holds */
     DBlock B;
     memset(B.cam, 0, sizeof B.cam); /* (the whole struct travels as the kernarg: no stale stack bytes behind the block's frames) */
     DFrame& F = B.f;
@@ -930,7 +943,7 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
     F.frame_stride = frame_stride;
     F.stats_stride = (uint32_t)((size_t)D.last_blocks * 4 * kStatRecord);
     const vrt_camera own = scene_camera(ctx->scene);
-    for (int f = 0; f < n_frames; f++) {
+    for (int f = 0; f < n_frames && !device_cams; f++) {
         pack_camera(cams ? cams[f] : own, p->width, p->height, B.cam[f]);
         cull_rect(ctx, p, B.cam[f]);
     }
@@ -945,9 +958,10 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
             const bool older = D.stats_bound[i] == D.stats_bound[slot] && D.stats_used[i] < D.stats_used[slot];
             if (freer || older) slot = i;
         }
-        /* the slot's previous stream may still be running a full closest hit in passes, whose hit records (unlike the counters)
-           decide pixels: wait for the device once before another stream takes them over (a 17th stream: rare) */
-        if (D.stats_bound[slot] && D.d_pass[slot] != nullptr) {
+        /* the slot's previous stream may still be running a full closest hit in passes, or a launch with its cameras in device memory:
+           hit records and camera records (unlike the counters) decide pixels: wait for the device once before another stream takes
+           them over (a 17th stream: rare) */
+        if (D.stats_bound[slot] && (D.d_pass[slot] != nullptr || D.d_cams[slot] != nullptr)) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (stream == nullptr || hipStreamIsCapturing(stream, &cs) != hipSuccess || cs == hipStreamCaptureStatusNone)
                 HIP_TRY(hipDeviceSynchronize());
@@ -965,6 +979,25 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
     }
     D.last_slot = slot;
     F.stats = D.d_stats[slot];
+    if (device_cams) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream != nullptr && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return VRT_ERR_INVALID; /* (a replay would copy whatever the pinned records hold by then; vrt_render_block captures in kernarg-sized launches) */
+        if (!D.d_cams[slot]) {
+            HIP_TRY(hipMalloc(&D.d_cams[slot], sizeof(DCam) * kMaxLaunchFrames));
+            HIP_TRY(hipHostMalloc(&D.h_cams[slot], sizeof(DCam) * kMaxLaunchFrames));
+            HIP_TRY(hipEventCreateWithFlags(&D.cams_copied[slot], hipEventDisableTiming));
+        } else {
+            HIP_TRY(hipEventSynchronize(D.cams_copied[slot])); /* the previous launch's copy has read the pinned records (long ago, normally) */
+        }
+        for (int f = 0; f < n_frames; f++) {
+            pack_camera(cams ? cams[f] : own, p->width, p->height, D.h_cams[slot][f]);
+            cull_rect(ctx, p, D.h_cams[slot][f]);
+        }
+        HIP_TRY(hipMemcpyAsync(D.d_cams[slot], D.h_cams[slot], sizeof(DCam) * (size_t)n_frames, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(D.cams_copied[slot], stream));
+        F.cams = D.d_cams[slot];
+    }
     /* the full closest hit of a block of frames runs as three passes (vrt_kernels.hip, primary_pass_kernel); a lone frame as one
        kernel: three launches would pay a launch's latency-bound tail three times */
     const bool passes = F.full && !F.diag && ((n_frames > 1 && !(p->flags & VRT_FLAG_FULL_ONE_KERNEL)) || (p->flags & VRT_FLAG_FULL_THREE_PASS));
@@ -1314,7 +1347,7 @@ int vrt_render_strips(vrt_ctx* ctx, const vrt_params* params, int strip_rows, in
 int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* block, void* device_rgba, void* hip_stream) {
     int rc = check_params(ctx, params);
     if (rc != VRT_OK) return rc;
-    if (!block || block->n_frames < 1 || block->n_frames > 64 || !device_rgba) return VRT_ERR_INVALID;
+    if (!block || block->n_frames < 1 || block->n_frames > kMaxLaunchFrames || !device_rgba) return VRT_ERR_INVALID;
     RowSet rs;
     if (block->strip_rows > 0) {
         if (block->strip_stride < 1 || block->first_strip < 0 || block->first_strip >= block->strip_stride || block->n_strips < 0 ||
@@ -1338,7 +1371,12 @@ int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* bl
     /* ONE launch per kMaxBlockFrames frames (grid.y = frame; only the camera differs between the frames, it travels in the
        kernarg): the dispatcher back-fills the wave slots a frame's latency-bound tail leaves empty with the next frame's waves.
        VRT_FLAG_BLOCK_PER_FRAME: one launch per frame, back to back (what this entry point did before; A/B and tests) */
-    int chunk = (params->flags & VRT_FLAG_BLOCK_PER_FRAME) ? 1 : kMaxBlockFrames;
+    /* up to kMaxBlockFrames frames the cameras travel in the kernarg segment; a larger block is still ONE launch, its camera records
+       copied to the device ahead of it on the stream (a launch's latency-bound tail is paid once per launch) — unless the stream is
+       being captured into a graph: then launches of kernarg size */
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (stream != nullptr && hipStreamIsCapturing(stream, &capture) != hipSuccess) capture = hipStreamCaptureStatusNone;
+    int chunk = (params->flags & VRT_FLAG_BLOCK_PER_FRAME) ? 1 : (capture != hipStreamCaptureStatusNone || block->n_frames <= kMaxBlockFrames) ? kMaxBlockFrames : kMaxLaunchFrames;
     {   /* the full closest hit in passes keeps 20 bytes per pixel of the launch's tiles between its passes: at most kPassBytesMax per launch */
         const size_t per_frame = (size_t)((params->width + 15) / 16) * (size_t)((rs.rows + 15) / 16) * 256 * (sizeof(HitRecord) + sizeof(unsigned));
         if (per_frame > 0 && closest_hit_form(ctx, params).full)

@@ -29,7 +29,8 @@ constexpr int kMaxBlocks = 1 << 20;            /* 16x16-pixel workgroups per fra
 #ifndef VRT_MAX_BLOCK_FRAMES
 #define VRT_MAX_BLOCK_FRAMES 48
 #endif
-constexpr int kMaxBlockFrames = VRT_MAX_BLOCK_FRAMES;            /* frames ONE march launch covers (grid.y): their cameras travel in the kernarg segment */
+constexpr int kMaxBlockFrames = VRT_MAX_BLOCK_FRAMES;            /* frames ONE march launch covers (grid.y) with their cameras in the kernarg segment */
+constexpr int kMaxLaunchFrames = 256;                            /* ... with their cameras in device memory (DFrame::cams): one small copy ahead of the launch */
 
 /* blockIdx → tile maps of the march kernel (vrt_params.flags bits 0-1; speed only). */
 constexpr int kMapSupertile = 0;
@@ -186,7 +187,7 @@ struct DFrame {
                                   longest sample chain, load+lerp cycles, loop cycles, loop iterations}, frames like stats */
     uint64_t frame_stride;     /* bytes between the frames of a launch in `out` */
     uint32_t stats_stride;     /* words between the frames of a launch in `stats` (and diag_buf) */
-    int32_t n_frames;          /* = gridDim.y, 1 .. kMaxBlockFrames */
+    int32_t n_frames;          /* = gridDim.y, 1 .. kMaxBlockFrames (kMaxLaunchFrames with cams) */
     const DVolume* vol0;       /* single-instance scenes: vols + inst[0].slot, resolved on the host so that a wave loads its instance
                                   and its volume record side by side instead of one after the other (four out of five waves of
                                   a frame only need them to find out that their rays miss) */
@@ -195,6 +196,7 @@ struct DFrame {
     HitRecord* hit_rec;        /* {world normal, t} of the camera ray's closest hit (hit lanes only) */
     unsigned* hit_aux;         /* instance | shadowed-by-light bits << 16 (bit 0 directional, 1.. point, 6.. spot lights) */
     unsigned long long* hit_mask; /* per (frame, wave): the lanes whose camera ray hit */
+    const DCam* cams;          /* launches of more than kMaxBlockFrames frames: the frames' camera records in device memory (null: DBlock::cam) */
     uint32_t rec_stride;       /* records between the frames of a launch (= workgroups per frame * 64) */
     int32_t may_bounce;        /* 1: bounces allowed and some material can mirror (smooth, or roughness from a texture) */
 };

@@ -1049,11 +1049,13 @@ __device__ __forceinline__ bool wave_can_reach(const DCam& C, bool valid, int px
     return __ballot(valid && inside) != 0ull;
 }
 
-/* The frame of the launch this workgroup belongs to (blockIdx.y) and its camera record: one scalar load of 64 bytes from the
- * kernarg segment at a wave-uniform offset. */
+/* The frame of the launch this workgroup belongs to (blockIdx.y) and its camera record: one scalar load of 64 bytes at a
+ * wave-uniform offset, from the kernarg segment or — launches of more than kMaxBlockFrames frames — from device memory. */
 __device__ __forceinline__ DCam load_cam(const DBlock& B, int frame) {
     typedef unsigned u16v __attribute__((ext_vector_type(16)));
-    const u16v w = *reinterpret_cast<const u16v*>(&B.cam[frame]);
+    u16v w;
+    if (B.f.cams != nullptr) w = *reinterpret_cast<const u16v __attribute__((address_space(4)))*>((const __attribute__((address_space(4))) DCam*)B.f.cams + frame);
+    else w = *reinterpret_cast<const u16v*>(&B.cam[frame]);
     DCam C;
     C.cam_o[0] = __uint_as_float(w[0]); C.cam_o[1] = __uint_as_float(w[1]); C.cam_o[2] = __uint_as_float(w[2]);
     C.r0[0] = __uint_as_float(w[3]); C.r0[1] = __uint_as_float(w[4]); C.r0[2] = __uint_as_float(w[5]);
@@ -2394,7 +2396,7 @@ static hipError_t launch_path(const DBlock& B, bool single, bool diag_build, hip
 
 hipError_t launch_march(const DBlock& B, int path, bool single, hipStream_t stream) {
     const DFrame& F = B.f;
-    if (F.n_frames < 1 || F.n_frames > kMaxBlockFrames) return hipErrorInvalidValue;
+    if (F.n_frames < 1 || F.n_frames > (F.cams != nullptr ? kMaxLaunchFrames : kMaxBlockFrames)) return hipErrorInvalidValue;
     switch (path) {
         case kPathCube: return launch_path<kPathCube>(B, single, false, stream);
         case kPathCube16: return launch_path<kPathCube16>(B, single, false, stream);
