@@ -11,7 +11,7 @@ next frame's waves).  One GPU: ONE stream, ONE launch per step.
 
 With N ranks (one process per GPU) the SAME frame is split N ways — strong scaling, as the metric and config 4 define it: the
 frame is cut into 8-row strips dealt round-robin to the ranks (contiguous tiles would put every object row on the middle GPUs);
-every rank marches its strips of a block of 24 frames into compact device tiles with ONE launch, then ONE RCCL collective per
+every rank marches its strips of a block of 48 frames into compact device tiles with ONE launch, then ONE RCCL collective per
 block (torch.distributed backend "nccl") assembles the frames, overlapping the next block's march on a second stream; the
 assembling rank un-shuffles the strips into frame order.  `--exchange rotate` (default): frame g of a block is assembled on rank
 g // (24 / N) — one all-to-all per block, every xGMI link of the node in use; `--exchange gather`: every frame on rank 0
@@ -30,7 +30,7 @@ Prints ONE JSON line on rank 0 (driver contract) extended with:
                   the HBM floor of a frame, and the lone frame's latency model (longest dependent chain x time per position)
   cpu_baseline    the scalar oracle on this host's cores (a reported baseline)
   latency         one frame per launch, one launch in flight: ms per frame as an application waiting for each frame sees it
-  scale_anchor    the ONE-GPU rate with the settings an N-GPU run uses (RGBA8 tiles, 2 streams x 24 frames per launch): the
+  scale_anchor    the ONE-GPU rate with the settings an N-GPU run uses (RGBA8 tiles, 2 streams x 48 frames per launch): the
                   like-for-like base of the scaling curve; N > 1 lines carry speedup_vs_anchor (anchor re-measured on rank 0)
   end_to_end      vrt_render_begin/_end: march + copy of the frame to pinned host memory, pipelined
   config4         the same scene at 3840x2160 split the same N ways (BASELINE config 4), with its own anchor
@@ -498,7 +498,7 @@ def main() -> None:
     B = max(args.frames_per_step, 1)
     # frames per vrt_render_block call = per march launch: one GPU the whole step (96: a launch's latency-bound tail is paid once per
     # launch; beyond 48 frames the cameras are copied to the device ahead of the launch instead of travelling in the kernarg segment);
-    # several GPUs: about 24 (a multiple of N), exchanged as ONE block per collective
+    # several GPUs: about 48 (a multiple of N), exchanged as ONE block per collective
     G = min(args.block_frames or (_abi.MAX_LAUNCH_FRAMES if world == 1 else multi_block_frames(world)), B)
     if rotate and G % world != 0:
         raise SystemExit(f"[bench] --exchange rotate needs --block-frames to be a multiple of the {world} ranks")
@@ -599,7 +599,7 @@ def main() -> None:
 
     def anchor_leg(w, h):
         """The like-for-like base of the scaling curve: ONE GPU renders the whole w x h frame alone with the settings an N-GPU run
-        uses — RGBA8 tiles, MULTI_STREAMS streams x 24 frames per launch — and no exchange.  N > 1: measured on rank 0 while the
+        uses — RGBA8 tiles, MULTI_STREAMS streams x 48 frames per launch — and no exchange.  N > 1: measured on rank 0 while the
         other ranks wait, in the same run on the same hardware as the N-GPU figure."""
         out = None
         if rank == 0:
@@ -846,13 +846,14 @@ def main() -> None:
 
 
 MULTI_STREAMS = 2          # N > 1: streams per rank (a block's collective overlaps the next block's march)
-ANCHOR_BLOCK_FRAMES = 24   # frames per launch of the one-GPU scale anchor (= the N-GPU block for N = 2, 4, 8)
+ANCHOR_BLOCK_FRAMES = 48   # frames per launch of the one-GPU scale anchor (= the N-GPU block for N = 2, 4, 8)
 
 
 def multi_block_frames(world: int) -> int:
-    """Frames per block (= per march launch and per collective) of an N-GPU run: about 24, a multiple of N (rotating roots deal
-    whole frames to the ranks)."""
-    return world * max(1, round(24 / world))
+    """Frames per block (= per march launch and per collective) of an N-GPU run: about 48, a multiple of N (rotating roots deal
+    whole frames to the ranks).  A rank's eighth of 24 frames is 130 us of march with a 60-us tail behind it; per-rank probe
+    (profiles/r03_strong_scaling_probe.txt, N = 8, 2 streams): 24 frames per launch 0.0055 ms/frame, 48 0.0053, 96 0.0051."""
+    return world * max(1, round(48 / world))
 
 
 def exchange_label(rotate: bool, world: int, G: int, rehearsal: bool) -> str:

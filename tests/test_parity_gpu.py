@@ -813,9 +813,9 @@ def test_bench_two_rank_rehearsal(oracle_lib):
     assert out["config"]["rays_per_frame"] == 1280 * 720  # config 2 has no shadow rays; every pixel rendered exactly once
     assert out["assembled_frame_equals_single_gpu_frame"] is True
     assert out["value"] > 0 and out["roofline"]["frac"] > 0 and out["latency"]["ms_per_frame"] > 0
-    # the default exchange assembles frame g of a block on rank g // 12 (one all-to-all per block of 24); the gather onto rank 0
+    # the default exchange assembles frame g of a block on rank g // 24 (one all-to-all per block of 48); the gather onto rank 0
     # ran as a leg of the same job, and both hold the single-GPU frame; the one-GPU anchor of the curve was measured on rank 0
-    assert "all-to-all" in out["config"]["parallelism"] and out["config"]["frames_per_launch"] == 24 and out["config"]["streams"] == 2
+    assert "all-to-all" in out["config"]["parallelism"] and out["config"]["frames_per_launch"] == 48 and out["config"]["streams"] == 2
     assert "gather" in out["other_exchange"]["exchange"] and out["other_exchange"]["last_frame_equals_single_gpu_frame"] is True
     assert out["scale_anchor"]["value"] > 0 and out["scale_anchor"]["n_gpus"] == 1 and out["speedup_vs_anchor"] > 0
     # a rank count that does not match --gpus is refused, not silently measured

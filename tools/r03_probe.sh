@@ -2,7 +2,7 @@
 mkdir -p gpurun_out
 out=gpurun_out/r03_strong_scaling_probe.txt
 : > $out
-for G in 8 24 48; do
+for G in 24 48 96; do
   echo "### frames per launch G=$G, 8-row strips" >> $out
   PROBE_STRIP_ROWS=8 PROBE_BLOCK_FRAMES=$G PROBE_FRAMES_IN_FLIGHT=1,2,3 python tools/strong_scaling_probe.py c3 >> $out 2>gpurun_out/r03_probe.err
 done
