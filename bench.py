@@ -774,7 +774,7 @@ def main() -> None:
                      "per SIMD, ahead of vector issue (valu_issue_frac) -- PMC counters; not hbm (hbm_measured_frac), not mfma (unused)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_key": key,
-            "kernel": "march_kernel_full" if args.workload == "c3light" else "march_kernel", "kernel_ms": round(k_ms, 4), "frames_per_launch": fpl, "algorithmic_bytes_per_launch": int(alg_bytes),
+            "kernel": "primary_pass_kernel + light_pass_kernel (the full closest hit of a block of frames in passes; one duration per launch = both)" if args.workload == "c3light" else "march_kernel", "kernel_ms": round(k_ms, 4), "frames_per_launch": fpl, "algorithmic_bytes_per_launch": int(alg_bytes),
             "samples_per_launch": samples,
             "gsamples_per_s": round(samples / (k_ms * 1e-3) / 1e9, 2) if kms else None,
             "gather_ceiling_gsamples_per_s": GATHER_CEILING_GSAMPLES,

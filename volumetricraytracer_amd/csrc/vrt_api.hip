@@ -174,7 +174,6 @@ struct DeviceState {
     DCam* d_cams[kStatSlots] = {};
     DCam* h_cams[kStatSlots] = {};
     hipEvent_t cams_copied[kStatSlots] = {};
-    std::vector<DCam*> cams_retired;
     void* d_pass[kStatSlots] = {};
     size_t pass_cap[kStatSlots] = {}; /* records */
     std::vector<void*> pass_retired;
@@ -551,7 +550,6 @@ void destroy_device(DeviceState& D) {
         if (D.h_cams[i]) (void)hipHostFree(D.h_cams[i]);
         if (D.cams_copied[i]) (void)hipEventDestroy(D.cams_copied[i]);
     }
-    for (DCam* r : D.cams_retired) (void)hipFree(r);
     for (int i = 0; i < kStatSlots; i++)
         if (D.d_pass[i]) (void)hipFree(D.d_pass[i]);
     for (void* r : D.pass_retired) (void)hipFree(r);
