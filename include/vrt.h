@@ -331,7 +331,10 @@ typedef struct vrt_block {
 /* n_frames frames with ONE call and ONE march launch (the kernel's grid has a frame axis; up to 48 frames the cameras travel in
  * the kernarg segment, for more their 64-byte records are copied to the device ahead of the launch on the same stream; a stream that
  * is being captured into a graph gets launches of 48): the same pixels as n_frames calls of vrt_render_rows / vrt_render_strips with the scene's camera set to
- * cameras[f] in between, no host synchronisation, no allocation after the stream's first launch of that size.  The reference
+ * cameras[f] in between, no host synchronisation, no allocation after the stream's first launch of that size (per launch stream the
+ * context keeps the per-wave counters, for blocks of more than 48 frames the camera records, and — scenes that need the full closest
+ * hit: point / spot lights, mirroring materials, textures — 20 bytes per pixel of the block's tiles of hit records between the passes
+ * it then runs in, at most 4 GB per launch: larger blocks are cut into several launches).  The reference
  * keeps FrameCount = 3 frames in flight on its swap chain (DXConstants.cpp:23, DXRenderer.cpp:974-989) because a frame's last
  * third is a few latency-bound waves on an otherwise idle GPU; inside one launch the dispatcher back-fills those wave slots
  * with the next frame's waves, so the tail is paid once per launch instead of once per frame, whatever the number of streams
