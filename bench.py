@@ -604,10 +604,10 @@ def main() -> None:
         out = None
         if rank == 0:
             pa = params(w, h, as_rgba8=True)
-            asteps = max(min(args.steps, 4), 1)
+            asteps = max(min(args.steps, 10), 1)  # (a few tens of milliseconds: a shorter run reads several per cent low while the clocks ramp)
             try:
                 pl = Pipeline(r, pa, w, h, 1, 0, dev, True, 0, MULTI_STREAMS, False, block_frames=min(ANCHOR_BLOCK_FRAMES, B), cameras=cam_arr, n_cameras=B)
-                ea = timed_run(pl, asteps, 1, 1, cdev, B)
+                ea = timed_run(pl, asteps, max(min(args.warmup, 3), 1), 1, cdev, B)
                 ca = batch_counts(pa, w, h, alone=True)
                 out = {"value": round((ca["primary_rays"] + ca["shadow_rays"]) * asteps / ea / 1e6, 2), "unit": "Mrays/s",
                        "ms_per_frame": round(ea / (asteps * B) * 1e3, 4), "n_gpus": 1,
