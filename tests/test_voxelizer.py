@@ -371,6 +371,48 @@ def _write_png(path, img, colour, filters=(0, 1, 2, 3, 4), palette=None, idat_sp
         f.write(chunk(b"IEND", b""))
 
 
+def test_jpeg_texture_loader_gives_the_bytes_libjpeg_gives(tmp_path):
+    """VTexture2D::LoadJPEG (csrc/host/JpegDecoder.cpp: sequential Huffman JPEG, the IJG decoder's published arithmetic — accurate
+    integer IDCT, triangle-filter chroma upsampling, fixed-point YCbCr -> RGB): the committed files of tests/golden (4:2:0 at an odd
+    size, 4:2:2, 4:4:4 at quality 30, grey, restart markers, optimised Huffman tables) decode to the bytes Pillow / libjpeg-turbo
+    decoded them to (jpeg_expected.npz, written by tests/golden/make_jpeg_fixtures.py), byte for byte.  With Pillow at hand: a sweep
+    of sizes down to 1x1, qualities, samplings and restart intervals, also byte for byte.  Progressive and damaged files are refused."""
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    exp = np.load(os.path.join(gold, "jpeg_expected.npz"))
+    assert len(exp.files) == 6
+    for name in exp.files:
+        got = vx.load_texture(os.path.join(gold, f"jpeg_{name}.jpg"))
+        assert got.shape == exp[name].shape[:2] + (4,) and (got[..., 3] == 255).all(), name
+        assert np.array_equal(got[..., :3], exp[name]), name
+    # damaged: cut short (the entropy-coded data ends early), and a marker segment that runs past the end
+    raw = open(os.path.join(gold, "jpeg_420_odd.jpg"), "rb").read()
+    bad = str(tmp_path / "bad.jpg")
+    for data in (raw[:200], raw[:2] + b"\xff\xdb\xff\xff" + raw[6:], b"\xff\xd8\xff\xd9", raw[:len(raw) // 2].replace(b"\xff\xc0", b"\xff\xc2", 1)):
+        with open(bad, "wb") as f:
+            f.write(data)
+        with pytest.raises(RuntimeError):
+            vx.load_texture(bad)
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.RandomState(3)
+    p = str(tmp_path / "t.jpg")
+    n = 0
+    for (w, h) in ((64, 48), (130, 77), (8, 8), (3, 5), (64, 40), (2, 2), (1, 1), (100, 10)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = np.clip(np.stack([127 + 120 * np.sin(xx / 9.0 + yy / 17.0), 127 + 120 * np.cos(xx / 5.0), 127 + 100 * np.sin(yy / 7.0)], -1)
+                    + rng.randn(h, w, 3) * 12, 0, 255).astype(np.uint8)
+        for q in (30, 95):
+            for sub in (0, 1, 2):
+                for extra in ({}, {"restart_marker_blocks": 3}):
+                    Image.fromarray(a, "RGB").save(p, quality=q, subsampling=sub, **extra)
+                    got = vx.load_texture(p)
+                    assert np.array_equal(got[..., :3], np.asarray(Image.open(p).convert("RGB"))), (w, h, q, sub, extra)
+                    n += 1
+    assert n == 96
+    Image.fromarray(a, "RGB").save(p, progressive=True)
+    with pytest.raises(RuntimeError):
+        vx.load_texture(p)
+
+
 def test_png_and_ppm_texture_loader(tmp_path):
     """The C++ host's material-texture decoder (VTexture2D::LoadFromFile: PNG via zlib, binary PPM): every colour type
     and every row filter, split IDAT chunks, ancillary chunks; rejects what it does not support."""

@@ -289,6 +289,7 @@ VObjectPtr<VTextureCube> VTextureCube::LoadFromDDSFile(const std::string& path) 
 
 VObjectPtr<VTexture2D> VTexture2D::LoadFromFile(const std::string& path) {
     if (VObjectPtr<VTexture2D> t = LoadPNG(path)) return t;
+    if (VObjectPtr<VTexture2D> t = LoadJPEG(path)) return t;
     return LoadPPM(path);
 }
 
