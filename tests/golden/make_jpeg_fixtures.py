@@ -23,6 +23,8 @@ CASES = {
     "grey": dict(size=(29, 31), mode="L", quality=80),
     "420_restart": dict(size=(64, 40), mode="RGB", quality=85, subsampling=2, restart_marker_blocks=3),
     "420_optimized": dict(size=(50, 50), mode="RGB", quality=60, subsampling=2, optimize=True),
+    "420_progressive": dict(size=(45, 35), mode="RGB", quality=80, subsampling=2, progressive=True),
+    "grey_progressive_restart": dict(size=(40, 33), mode="L", quality=70, progressive=True, restart_marker_blocks=4),
 }
 expected = {}
 for name, c in CASES.items():

@@ -374,12 +374,13 @@ def _write_png(path, img, colour, filters=(0, 1, 2, 3, 4), palette=None, idat_sp
 def test_jpeg_texture_loader_gives_the_bytes_libjpeg_gives(tmp_path):
     """VTexture2D::LoadJPEG (csrc/host/JpegDecoder.cpp: sequential Huffman JPEG, the IJG decoder's published arithmetic — accurate
     integer IDCT, triangle-filter chroma upsampling, fixed-point YCbCr -> RGB): the committed files of tests/golden (4:2:0 at an odd
-    size, 4:2:2, 4:4:4 at quality 30, grey, restart markers, optimised Huffman tables) decode to the bytes Pillow / libjpeg-turbo
-    decoded them to (jpeg_expected.npz, written by tests/golden/make_jpeg_fixtures.py), byte for byte.  With Pillow at hand: a sweep
-    of sizes down to 1x1, qualities, samplings and restart intervals, also byte for byte.  Progressive and damaged files are refused."""
+    size, 4:2:2, 4:4:4 at quality 30, grey, restart markers, optimised Huffman tables, progressive with and without restart markers)
+    decode to the bytes Pillow / libjpeg-turbo decoded them to (jpeg_expected.npz, written by tests/golden/make_jpeg_fixtures.py),
+    byte for byte.  With Pillow at hand: a sweep of sizes down to 1x1, qualities, samplings, restart intervals, sequential and
+    progressive, also byte for byte.  Damaged files are refused."""
     gold = os.path.join(os.path.dirname(__file__), "golden")
     exp = np.load(os.path.join(gold, "jpeg_expected.npz"))
-    assert len(exp.files) == 6
+    assert len(exp.files) == 8
     for name in exp.files:
         got = vx.load_texture(os.path.join(gold, f"jpeg_{name}.jpg"))
         assert got.shape == exp[name].shape[:2] + (4,) and (got[..., 3] == 255).all(), name
@@ -402,15 +403,12 @@ def test_jpeg_texture_loader_gives_the_bytes_libjpeg_gives(tmp_path):
                     + rng.randn(h, w, 3) * 12, 0, 255).astype(np.uint8)
         for q in (30, 95):
             for sub in (0, 1, 2):
-                for extra in ({}, {"restart_marker_blocks": 3}):
+                for extra in ({}, {"restart_marker_blocks": 3}, {"progressive": True}):
                     Image.fromarray(a, "RGB").save(p, quality=q, subsampling=sub, **extra)
                     got = vx.load_texture(p)
                     assert np.array_equal(got[..., :3], np.asarray(Image.open(p).convert("RGB"))), (w, h, q, sub, extra)
                     n += 1
-    assert n == 96
-    Image.fromarray(a, "RGB").save(p, progressive=True)
-    with pytest.raises(RuntimeError):
-        vx.load_texture(p)
+    assert n == 144
 
 
 def test_png_and_ppm_texture_loader(tmp_path):

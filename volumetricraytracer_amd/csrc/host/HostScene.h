@@ -54,7 +54,7 @@ private:
 
 /* VTexture2D reduced to what the closest-hit shader samples: one mip of R8G8B8A8_UNORM, row-major
    (Renderer/DX/Private/DXTexture2D.cpp:63-81).  The reference decodes image files with WIC/DDS
-   (Renderer/Private/TextureFactory.cpp:58-125); here PNG (zlib), sequential JPEG and binary PPM are read directly,
+   (Renderer/Private/TextureFactory.cpp:58-125); here PNG (zlib), JPEG and binary PPM are read directly,
    anything else is the application's job (RegisterTexture). */
 class VTexture2D {
 public:
@@ -66,7 +66,7 @@ public:
     static VObjectPtr<VTexture2D> LoadPPM(const std::string& path);
     /* 8-bit, non-interlaced PNG (grey, grey+alpha, RGB, RGBA, palette); nullptr otherwise */
     static VObjectPtr<VTexture2D> LoadPNG(const std::string& path);
-    /* baseline / extended-sequential Huffman JPEG, 8-bit, grey or three components (JpegDecoder.cpp); nullptr otherwise */
+    /* baseline / extended-sequential / progressive Huffman JPEG, 8-bit, grey or three components (JpegDecoder.cpp); nullptr otherwise */
     static VObjectPtr<VTexture2D> LoadJPEG(const std::string& path);
     /* by content: PNG, then JPEG, then PPM */
     static VObjectPtr<VTexture2D> LoadFromFile(const std::string& path);

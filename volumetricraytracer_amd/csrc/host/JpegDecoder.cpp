@@ -1,7 +1,8 @@
-/* JpegDecoder.cpp — baseline / extended-sequential JPEG (ITU-T T.81: Huffman, 8-bit samples, 1 or 3 components, any sampling
- * factors up to 2x2 per component, restart intervals) to RGBA8, for material textures and sky-box faces.  The reference decodes
- * image files through WIC (Renderer/Private/TextureFactory.cpp:58-125, DirectXTex: a Windows codec); this is the part of that a
- * material texture needs.  Progressive, arithmetic-coded, 12-bit and four-component files are refused (nullptr), like a damaged file.
+/* JpegDecoder.cpp — baseline, extended-sequential and progressive JPEG (ITU-T T.81: Huffman, 8-bit samples, 1 or 3 components,
+ * sampling factors up to 2x2 per component, any number of scans, restart intervals) to RGBA8, for material textures and sky-box
+ * faces.  The reference decodes image files through WIC (Renderer/Private/TextureFactory.cpp:58-125, DirectXTex: a Windows codec);
+ * this is the part of that a material texture needs.  Arithmetic-coded, lossless, 12-bit and four-component files are refused
+ * (nullptr), like a damaged file.
  *
  * The arithmetic is the published one of the Independent JPEG Group's decoder with its default settings — the accurate integer
  * inverse DCT (13-bit constants, two passes), "fancy" triangle-filter chroma upsampling for 2:1 horizontal and 2x2 subsampling,
@@ -45,6 +46,7 @@ struct Component {
     int blocks_w = 0, blocks_h = 0;   /* blocks in the padded (MCU-aligned) plane */
     int width = 0, height = 0;        /* downsampled size of the real image */
     int pred = 0;
+    std::vector<int16_t> coef;        /* blocks_w x blocks_h blocks of 64 coefficients, natural order, as the scans leave them */
     std::vector<uint8_t> plane;       /* blocks_w*8 x blocks_h*8 samples */
 };
 
@@ -216,70 +218,148 @@ struct Decoder {
     Component comp[3];
     int ncomp = 0, width = 0, height = 0, hmax = 1, vmax = 1, restart_interval = 0;
     int adobe_transform = -1;
-    bool have_frame = false;
+    bool have_frame = false, progressive = false;
 
-    bool decode_block(BitReader& br, Component& c, int* blk) {
-        memset(blk, 0, 64 * sizeof(int));
-        const HuffTable& hd = dc[c.td];
-        const HuffTable& ha = ac[c.ta];
-        int s = decode_symbol(br, hd);
-        if (s < 0 || s > 11) return false;
-        int diff = s ? extend(br.bits(s), s) : 0;
-        c.pred += diff;
-        const uint16_t* q = qt[c.tq];
-        blk[0] = c.pred * q[0];
-        for (int k = 1; k < 64;) {
-            const int rs = decode_symbol(br, ha);
-            if (rs < 0) return false;
-            const int r = rs >> 4, sz = rs & 15;
-            if (sz == 0) {
-                if (r == 15) {
-                    k += 16;
-                    continue;
-                }
-                break; /* end of block */
+    /* One block of a scan.  Sequential (Ss = 0, Se = 63, Ah = Al = 0): DC difference and the AC run-lengths; progressive: the DC
+       first / refinement bit, or a band of AC coefficients first / refined (T.81 G.1.2; end-of-band runs span blocks). */
+    bool decode_block(BitReader& br, Component& c, int16_t* blk, int Ss, int Se, int Ah, int Al, int& eobrun) {
+        if (Ss == 0) {
+            if (Ah == 0) {
+                const int s = decode_symbol(br, dc[c.td]);
+                if (s < 0 || s > 11) return false;
+                c.pred += s ? extend(br.bits(s), s) : 0;
+                blk[0] = (int16_t)(c.pred * (1 << Al));
+            } else if (br.bits(1)) {
+                blk[0] = (int16_t)(blk[0] | (1 << Al));
             }
-            k += r;
-            if (k > 63) return false;
-            blk[kZigzag[k]] = extend(br.bits(sz), sz) * q[k];
-            k++;
+            if (Se == 0) return true;
+        }
+        const HuffTable& ha = ac[c.ta];
+        int k = Ss == 0 ? 1 : Ss;
+        if (Ah == 0) {
+            if (eobrun > 0) {
+                eobrun--;
+                return true;
+            }
+            for (; k <= Se; k++) {
+                const int rs = decode_symbol(br, ha);
+                if (rs < 0) return false;
+                const int r = rs >> 4, sz = rs & 15;
+                if (sz) {
+                    k += r;
+                    if (k > Se) return false;
+                    blk[kZigzag[k]] = (int16_t)(extend(br.bits(sz), sz) * (1 << Al));
+                } else if (r == 15) {
+                    k += 15;
+                } else {
+                    eobrun = (1 << r) - 1;
+                    if (r) eobrun += br.bits(r);
+                    break;
+                }
+            }
+            return true;
+        }
+        /* refinement of a band */
+        const int p1 = 1 << Al, m1 = -(1 << Al);
+        auto correct = [&](int16_t& v) {
+            if (br.bits(1) && (v & p1) == 0) v = (int16_t)(v >= 0 ? v + p1 : v + m1);
+        };
+        if (eobrun == 0) {
+            for (; k <= Se; k++) {
+                const int rs = decode_symbol(br, ha);
+                if (rs < 0) return false;
+                int r = rs >> 4, sz = rs & 15;
+                if (sz) {
+                    if (sz != 1) return false;
+                    sz = br.bits(1) ? p1 : m1;
+                } else if (r != 15) {
+                    eobrun = 1 << r;
+                    if (r) eobrun += br.bits(r);
+                    break;
+                }
+                do { /* over the already non-zero coefficients (a correction bit each) and r still-zero ones */
+                    int16_t& v = blk[kZigzag[k]];
+                    if (v != 0) {
+                        correct(v);
+                    } else if (--r < 0) {
+                        break;
+                    }
+                    k++;
+                } while (k <= Se);
+                if (sz) {
+                    if (k > Se) return false;
+                    blk[kZigzag[k]] = (int16_t)sz;
+                }
+            }
+        }
+        if (eobrun > 0) {
+            for (; k <= Se; k++) {
+                int16_t& v = blk[kZigzag[k]];
+                if (v != 0) correct(v);
+            }
+            eobrun--;
         }
         return true;
     }
 
-    bool decode_scan(const uint8_t* p, const uint8_t* end) {
-        const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
-        const int mcus_x = (width + mcu_w - 1) / mcu_w, mcus_y = (height + mcu_h - 1) / mcu_h;
+    bool decode_scan(const uint8_t* p, const uint8_t* end, const int* sel, int nsel, int Ss, int Se, int Ah, int Al) {
         BitReader br{p, end};
-        int blk[64];
-        int until_restart = restart_interval, next_rst = 0;
+        int until_restart = restart_interval, next_rst = 0, eobrun = 0;
+        for (int i = 0; i < nsel; i++) comp[sel[i]].pred = 0;
+        auto restart = [&]() -> bool {
+            br.reset();
+            const uint8_t* q = br.p;
+            while (q + 1 < end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
+            if (q + 1 >= end || q[1] != 0xD0 + next_rst) return false;
+            br.p = q + 2;
+            next_rst = (next_rst + 1) & 7;
+            until_restart = restart_interval;
+            eobrun = 0;
+            for (int i = 0; i < nsel; i++) comp[sel[i]].pred = 0;
+            return true;
+        };
+        if (nsel == 1) { /* not interleaved: the component's own blocks, row by row (those that hold image samples) */
+            Component& c = comp[sel[0]];
+            const int bw = (c.width + 7) / 8, bh = (c.height + 7) / 8;
+            for (int by = 0; by < bh; by++)
+                for (int bx = 0; bx < bw; bx++) {
+                    if (restart_interval > 0 && until_restart == 0 && !restart()) return false;
+                    if (!decode_block(br, c, c.coef.data() + ((size_t)by * c.blocks_w + bx) * 64, Ss, Se, Ah, Al, eobrun)) return false;
+                    if (restart_interval > 0) until_restart--;
+                }
+            return true;
+        }
+        const int mcus_x = (width + 8 * hmax - 1) / (8 * hmax), mcus_y = (height + 8 * vmax - 1) / (8 * vmax);
         for (int my = 0; my < mcus_y; my++)
             for (int mx = 0; mx < mcus_x; mx++) {
-                if (restart_interval > 0 && until_restart == 0) {
-                    /* byte-align, expect RSTn */
-                    br.reset();
-                    const uint8_t* q = br.p;
-                    while (q + 1 < end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
-                    if (q + 1 >= end || q[1] != 0xD0 + next_rst) return false;
-                    br.p = q + 2;
-                    next_rst = (next_rst + 1) & 7;
-                    until_restart = restart_interval;
-                    for (int i = 0; i < ncomp; i++) comp[i].pred = 0;
-                }
-                for (int i = 0; i < ncomp; i++) {
-                    Component& c = comp[i];
-                    const int bh = ncomp == 1 ? 1 : c.h, bv = ncomp == 1 ? 1 : c.v;
-                    for (int by = 0; by < bv; by++)
-                        for (int bx = 0; bx < bh; bx++) {
-                            if (!decode_block(br, c, blk)) return false;
-                            const int X = (mx * bh + bx) * 8, Y = (my * bv + by) * 8;
-                            if (X + 8 > c.blocks_w * 8 || Y + 8 > c.blocks_h * 8) continue; /* (non-interleaved single component: never) */
-                            idct_block(blk, c.plane.data() + (size_t)Y * (c.blocks_w * 8) + X, c.blocks_w * 8);
+                if (restart_interval > 0 && until_restart == 0 && !restart()) return false;
+                for (int i = 0; i < nsel; i++) {
+                    Component& c = comp[sel[i]];
+                    for (int by = 0; by < c.v; by++)
+                        for (int bx = 0; bx < c.h; bx++) {
+                            const size_t blk = (size_t)(my * c.v + by) * c.blocks_w + (size_t)(mx * c.h + bx);
+                            if (!decode_block(br, c, c.coef.data() + blk * 64, Ss, Se, Ah, Al, eobrun)) return false;
                         }
                 }
                 if (restart_interval > 0) until_restart--;
             }
         return true;
+    }
+
+    /* After the last scan: dequantise and inverse-transform every block. */
+    void reconstruct() {
+        int blk[64];
+        for (int i = 0; i < ncomp; i++) {
+            Component& c = comp[i];
+            int q[64];
+            for (int k = 0; k < 64; k++) q[kZigzag[k]] = qt[c.tq][k];
+            for (int by = 0; by < c.blocks_h; by++)
+                for (int bx = 0; bx < c.blocks_w; bx++) {
+                    const int16_t* src = c.coef.data() + ((size_t)by * c.blocks_w + bx) * 64;
+                    for (int k = 0; k < 64; k++) blk[k] = src[k] * q[k];
+                    idct_block(blk, c.plane.data() + (size_t)by * 8 * (c.blocks_w * 8) + (size_t)bx * 8, c.blocks_w * 8);
+                }
+        }
     }
 
     /* One component as a full-resolution plane (width x height): replication, or the triangle filters for 2:1 / 2x2. */
@@ -343,11 +423,14 @@ struct Decoder {
     bool run(size_t& w_out, size_t& h_out, std::vector<uint8_t>& rgba) {
         if (size < 4 || data[0] != 0xFF || data[1] != 0xD8) return false;
         size_t pos = 2;
-        bool done = false;
-        while (!done) {
+        int scans = 0;
+        for (;;) {
             while (pos < size && data[pos] != 0xFF) pos++; /* (garbage between segments is skipped) */
             while (pos < size && data[pos] == 0xFF) pos++;
-            if (pos >= size) return false;
+            if (pos >= size) {
+                if (scans > 0) break; /* no EOI marker: what the scans gave is the image */
+                return false;
+            }
             const int m = data[pos++];
             if (m == 0xD9) break;
             if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
@@ -394,7 +477,9 @@ struct Decoder {
                     break;
                 }
                 case 0xC0:
-                case 0xC1: { /* baseline / extended sequential, Huffman */
+                case 0xC1:
+                case 0xC2: { /* baseline / extended sequential / progressive, Huffman */
+                    progressive = m == 0xC2;
                     if (have_frame || n < 6 || seg[0] != 8) return false;
                     height = seg[1] << 8 | seg[2];
                     width = seg[3] << 8 | seg[4];
@@ -419,12 +504,13 @@ struct Decoder {
                         c.width = (width * c.h + hmax - 1) / hmax;
                         c.height = (height * c.v + vmax - 1) / vmax;
                         c.plane.assign((size_t)c.blocks_w * 8 * c.blocks_h * 8, 0);
+                        c.coef.assign((size_t)c.blocks_w * c.blocks_h * 64, 0);
                     }
                     have_frame = true;
                     break;
                 }
-                case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
-                    return false; /* progressive, lossless, differential, arithmetic: not read */
+                case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+                    return false; /* lossless, differential, arithmetic: not read */
                 case 0xDD:
                     if (n < 2) return false;
                     restart_interval = seg[0] << 8 | seg[1];
@@ -432,24 +518,49 @@ struct Decoder {
                 case 0xEE: /* Adobe: the colour transform flag */
                     if (n >= 12 && memcmp(seg, "Adobe", 5) == 0) adobe_transform = seg[11];
                     break;
-                case 0xDA: { /* SOS: one interleaved scan with every component */
-                    if (!have_frame || n < (size_t)1 + 2 * ncomp + 3 || seg[0] != ncomp) return false;
-                    for (int i = 0; i < ncomp; i++) {
-                        if (seg[1 + 2 * i] != comp[i].id) return false;
-                        comp[i].td = seg[2 + 2 * i] >> 4;
-                        comp[i].ta = seg[2 + 2 * i] & 15;
-                        if (comp[i].td > 3 || comp[i].ta > 3 || !dc[comp[i].td].present || !ac[comp[i].ta].present || !have_qt[comp[i].tq]) return false;
-                        comp[i].pred = 0;
+                case 0xDA: { /* SOS: a scan of one or several components; the entropy-coded data follows the header */
+                    if (!have_frame || n < 1) return false;
+                    const int nsel = seg[0];
+                    if (nsel < 1 || nsel > ncomp || n < (size_t)1 + 2 * nsel + 3) return false;
+                    int sel[3];
+                    for (int i = 0; i < nsel; i++) {
+                        int ci = -1;
+                        for (int j = 0; j < ncomp; j++)
+                            if (comp[j].id == seg[1 + 2 * i]) ci = j;
+                        if (ci < 0) return false;
+                        for (int j = 0; j < i; j++)
+                            if (sel[j] == ci) return false;
+                        sel[i] = ci;
+                        comp[ci].td = seg[2 + 2 * i] >> 4;
+                        comp[ci].ta = seg[2 + 2 * i] & 15;
+                        if (comp[ci].td > 3 || comp[ci].ta > 3 || !have_qt[comp[ci].tq]) return false;
                     }
-                    if (!decode_scan(data + pos + len, data + size)) return false;
-                    done = true;
-                    break;
+                    int Ss = seg[1 + 2 * nsel], Se = seg[2 + 2 * nsel], Ah = seg[3 + 2 * nsel] >> 4, Al = seg[3 + 2 * nsel] & 15;
+                    if (!progressive) {
+                        Ss = 0;
+                        Se = 63;
+                        Ah = Al = 0;
+                    } else if (Ss > Se || Se > 63 || Al > 13 || Ah > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && nsel != 1)) {
+                        return false;
+                    }
+                    for (int i = 0; i < nsel; i++) {
+                        if (Ss == 0 && Ah == 0 && !dc[comp[sel[i]].td].present) return false;
+                        if (Se > 0 && !ac[comp[sel[i]].ta].present) return false;
+                    }
+                    if (!decode_scan(data + pos + len, data + size, sel, nsel, Ss, Se, Ah, Al)) return false;
+                    scans++;
+                    /* on to the next marker behind the entropy-coded data (stuffed 0xFF00 and restart markers are part of it) */
+                    size_t q = pos + len;
+                    while (q + 1 < size && !(data[q] == 0xFF && data[q + 1] != 0x00 && !(data[q + 1] >= 0xD0 && data[q + 1] <= 0xD7))) q++;
+                    pos = q;
+                    continue;
                 }
                 default: break; /* APPn, COM, ...: skipped */
             }
             pos += len;
         }
-        if (!done) return false;
+        if (!have_frame || scans == 0) return false;
+        reconstruct();
         w_out = (size_t)width;
         h_out = (size_t)height;
         rgba.resize((size_t)width * height * 4);
