@@ -111,27 +111,30 @@ inline uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v))
 /* The accurate integer inverse DCT (Loeffler / Ligtenberg / Moschytz, 13-bit constants): columns, then rows; +128 and clamp. */
 void idct_block(const int* coef /* dequantised, natural order */, uint8_t* out, int stride) {
     constexpr int CB = 13, P1 = 2;
-    constexpr int32_t F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633,
+    constexpr int64_t F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633,
                       F_1_501 = 12299, F_1_847 = 15137, F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995, F_3_072 = 25172;
-    auto descale = [](int32_t x, int n) { return (x + ((int32_t)1 << (n - 1))) >> n; };
-    int32_t ws[64];
+    /* (64-bit intermediates: a damaged file can hold coefficients far beyond what 8-bit samples produce; valid files give the
+       32-bit results) */
+    auto descale = [](int64_t x, int n) { return (x + ((int64_t)1 << (n - 1))) >> n; };
+    auto pix = [](int64_t v) { return clamp8((int)(v < -1024 ? -1024 : (v > 1024 ? 1024 : v))); };
+    int64_t ws[64];
     for (int c = 0; c < 8; c++) {
         const int* in = coef + c;
-        int32_t* w = ws + c;
+        int64_t* w = ws + c;
         if (in[8] == 0 && in[16] == 0 && in[24] == 0 && in[32] == 0 && in[40] == 0 && in[48] == 0 && in[56] == 0) {
-            const int32_t dc = (int32_t)in[0] * (1 << P1);
+            const int64_t dc = (int64_t)in[0] * (1 << P1);
             for (int r = 0; r < 8; r++) w[8 * r] = dc;
             continue;
         }
-        int32_t z2 = in[16], z3 = in[48];
-        int32_t z1 = (z2 + z3) * F_0_541;
-        int32_t tmp2 = z1 + z3 * (-F_1_847);
-        int32_t tmp3 = z1 + z2 * F_0_765;
+        int64_t z2 = in[16], z3 = in[48];
+        int64_t z1 = (z2 + z3) * F_0_541;
+        int64_t tmp2 = z1 + z3 * (-F_1_847);
+        int64_t tmp3 = z1 + z2 * F_0_765;
         z2 = in[0];
         z3 = in[32];
-        int32_t tmp0 = (z2 + z3) * (1 << CB);
-        int32_t tmp1 = (z2 - z3) * (1 << CB);
-        const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        int64_t tmp0 = (z2 + z3) * (1 << CB);
+        int64_t tmp1 = (z2 - z3) * (1 << CB);
+        const int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = in[56];
         tmp1 = in[40];
         tmp2 = in[24];
@@ -139,8 +142,8 @@ void idct_block(const int* coef /* dequantised, natural order */, uint8_t* out, 
         z1 = tmp0 + tmp3;
         z2 = tmp1 + tmp2;
         z3 = tmp0 + tmp2;
-        int32_t z4 = tmp1 + tmp3;
-        const int32_t z5 = (z3 + z4) * F_1_175;
+        int64_t z4 = tmp1 + tmp3;
+        const int64_t z5 = (z3 + z4) * F_1_175;
         tmp0 *= F_0_298;
         tmp1 *= F_2_053;
         tmp2 *= F_3_072;
@@ -165,15 +168,15 @@ void idct_block(const int* coef /* dequantised, natural order */, uint8_t* out, 
         w[32] = descale(tmp13 - tmp0, CB - P1);
     }
     for (int r = 0; r < 8; r++) {
-        const int32_t* w = ws + 8 * r;
+        const int64_t* w = ws + 8 * r;
         uint8_t* o = out + (size_t)r * stride;
-        int32_t z2 = w[2], z3 = w[6];
-        int32_t z1 = (z2 + z3) * F_0_541;
-        int32_t tmp2 = z1 + z3 * (-F_1_847);
-        int32_t tmp3 = z1 + z2 * F_0_765;
-        int32_t tmp0 = (w[0] + w[4]) * (1 << CB);
-        int32_t tmp1 = (w[0] - w[4]) * (1 << CB);
-        const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        int64_t z2 = w[2], z3 = w[6];
+        int64_t z1 = (z2 + z3) * F_0_541;
+        int64_t tmp2 = z1 + z3 * (-F_1_847);
+        int64_t tmp3 = z1 + z2 * F_0_765;
+        int64_t tmp0 = (w[0] + w[4]) * (1 << CB);
+        int64_t tmp1 = (w[0] - w[4]) * (1 << CB);
+        const int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = w[7];
         tmp1 = w[5];
         tmp2 = w[3];
@@ -181,8 +184,8 @@ void idct_block(const int* coef /* dequantised, natural order */, uint8_t* out, 
         z1 = tmp0 + tmp3;
         z2 = tmp1 + tmp2;
         z3 = tmp0 + tmp2;
-        int32_t z4 = tmp1 + tmp3;
-        const int32_t z5 = (z3 + z4) * F_1_175;
+        int64_t z4 = tmp1 + tmp3;
+        const int64_t z5 = (z3 + z4) * F_1_175;
         tmp0 *= F_0_298;
         tmp1 *= F_2_053;
         tmp2 *= F_3_072;
@@ -198,14 +201,14 @@ void idct_block(const int* coef /* dequantised, natural order */, uint8_t* out, 
         tmp2 += z2 + z3;
         tmp3 += z1 + z4;
         constexpr int S = CB + P1 + 3;
-        o[0] = clamp8(descale(tmp10 + tmp3, S) + 128);
-        o[7] = clamp8(descale(tmp10 - tmp3, S) + 128);
-        o[1] = clamp8(descale(tmp11 + tmp2, S) + 128);
-        o[6] = clamp8(descale(tmp11 - tmp2, S) + 128);
-        o[2] = clamp8(descale(tmp12 + tmp1, S) + 128);
-        o[5] = clamp8(descale(tmp12 - tmp1, S) + 128);
-        o[3] = clamp8(descale(tmp13 + tmp0, S) + 128);
-        o[4] = clamp8(descale(tmp13 - tmp0, S) + 128);
+        o[0] = pix(descale(tmp10 + tmp3, S) + 128);
+        o[7] = pix(descale(tmp10 - tmp3, S) + 128);
+        o[1] = pix(descale(tmp11 + tmp2, S) + 128);
+        o[6] = pix(descale(tmp11 - tmp2, S) + 128);
+        o[2] = pix(descale(tmp12 + tmp1, S) + 128);
+        o[5] = pix(descale(tmp12 - tmp1, S) + 128);
+        o[3] = pix(descale(tmp13 + tmp0, S) + 128);
+        o[4] = pix(descale(tmp13 - tmp0, S) + 128);
     }
 }
 
@@ -484,7 +487,7 @@ struct Decoder {
                     height = seg[1] << 8 | seg[2];
                     width = seg[3] << 8 | seg[4];
                     ncomp = seg[5];
-                    if ((ncomp != 1 && ncomp != 3) || width < 1 || height < 1 || width > 16384 || height > 16384 || n < (size_t)6 + 3 * ncomp) return false;
+                    if ((ncomp != 1 && ncomp != 3) || width < 1 || height < 1 || width > 16384 || height > 16384 || (long long)width * height > (64ll << 20) || n < (size_t)6 + 3 * ncomp) return false;
                     for (int i = 0; i < ncomp; i++) {
                         comp[i].id = seg[6 + 3 * i];
                         comp[i].h = seg[7 + 3 * i] >> 4;
