@@ -60,9 +60,9 @@ extern "C" {
 #define VRT_FLAG_NO_CULL_RECT 128 /* the host computes no cull rectangle: every wave looks at the scene and slab-tests its rays
                                     (measurements of what the rectangle saves; same pixels) */
 #define VRT_FLAG_FULL_ONE_KERNEL 256 /* full closest hit (point / spot lights, mirror bounces, material textures): one kernel even for a block
-                                       of frames — vrt_render_block's launches otherwise run it as three passes (camera-ray march /
-                                       light shadow rays / shading + bounces; same pixels and counters, more waves per SIMD).  A lone
-                                       frame is one kernel by default */
+                                       of frames — vrt_render_block's launches otherwise run it in passes (camera-ray march / the hits'
+                                       light shadow rays and their shading / a third pass for the lanes that mirror, in frames that can
+                                       bounce; same pixels and counters, twice the waves per SIMD).  A lone frame is one kernel by default */
 #define VRT_FLAG_FULL_THREE_PASS 512 /* ... and the three passes even for a lone frame (tests, measurements).  Not both */
 #define VRT_FLAG_NO_TIMING 16    /* the launch records no event pair: vrt_last_timing / vrt_timing_history report 0 ms for it.
                                    An event pair costs 5-7 us of queue time per launch (profiles/r02_launch_overhead.txt);
