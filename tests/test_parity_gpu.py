@@ -1252,6 +1252,40 @@ def test_fused_block_launch_equals_per_frame_launches(renderer, oracle_lib, case
             assert np.abs(fused[f].cpu().numpy() - ref).max() <= TOL, (case, f)
 
 
+@pytest.mark.parametrize("full", [False, True])
+def test_a_block_of_many_frames_is_one_launch(renderer, oracle_lib, full):
+    """vrt_render_block with more frames than the kernarg segment holds cameras (here 130 and the maximum, 256): ONE launch with
+    the camera records in device memory — the directional-light kernel and the full closest hit in passes —, bit-equal to per-frame
+    launches; 257 frames are refused."""
+    import torch
+
+    sc = scenes.config3_torus(5, 16)
+    if full:
+        sc.PointLights = [v.VPointLight(Position=(150.0, 40.0, 120.0), IlluminationStrength=400.0, Color=(1.0, 0.8, 0.6, 1.0),
+                                        AttenuationLinear=0.05, AttenuationExp=0.002)]
+    W, H = 72, 40
+    p = v.default_params(W, H, scenes.min_cell(sc), 255, shadow=True)
+    renderer.SetSceneToRender(sc)
+    renderer.ResizeRenderOutput(W, H)
+    renderer.SyncWithScene()
+    for n in (130, _abi.MAX_LAUNCH_FRAMES):
+        cams = _orbit(sc.Camera, n)
+        fused = torch.zeros((n, H, W, 4), dtype=torch.float32, device="cuda:0")
+        single = torch.zeros_like(fused)
+        renderer.render_block(p, n, fused.data_ptr(), H * W * 16, 0, cameras=cams, rows=(0, H))
+        torch.cuda.synchronize()
+        assert [fr for _, fr in renderer.launch_history(1)] == [n]
+        t_fused = renderer.last_timing()
+        pf = _abi.vrt_params.from_buffer_copy(p)
+        pf.flags |= _abi.FLAG_BLOCK_PER_FRAME
+        renderer.render_block(pf, n, single.data_ptr(), H * W * 16, 0, cameras=cams, rows=(0, H))
+        torch.cuda.synchronize()
+        assert torch.equal(fused, single) and not torch.equal(fused[0], fused[n - 1])
+        assert {k: t_fused[k] for k in STAT_KEYS} == {k: renderer.last_timing()[k] for k in STAT_KEYS}
+    with pytest.raises(Exception):
+        renderer.render_block(p, _abi.MAX_LAUNCH_FRAMES + 1, fused.data_ptr(), H * W * 16, 0, rows=(0, H))
+
+
 def test_full_closest_hit_in_passes_on_two_streams_at_once(renderer, oracle_lib):
     """The passes of the full closest hit hand per-pixel hit records from one kernel to the next; every launch stream has its own
     (like the counters): two streams marching different blocks of a scene with a point light at the same time give the frames
