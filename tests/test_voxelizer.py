@@ -572,7 +572,7 @@ def test_skybox_from_a_dds_cube_map(tmp_path, layout):
     """The reference loads its sky box from a .dds cube map (VTextureFactory::LoadTextureCubeFromFile,
     Renderer/Private/TextureFactory.cpp:28-67; Resources/Skybox/Skybox.dds is missing from the checkout).  Uncompressed
     cube maps in the DX10 and the legacy header layouts, with and without a mip chain, decode to the six RGBA faces;
-    a 2D texture, a format the loader does not decode (BC5) or a truncated file is refused."""
+    a 2D texture, a format the loader does not decode (signed BC5) or a truncated file is refused."""
     rng = np.random.default_rng(4)
     faces = rng.integers(0, 256, size=(6, 8, 8, 4), dtype=np.uint8)
     path = str(tmp_path / "sky.dds")
@@ -596,7 +596,7 @@ def test_skybox_from_a_dds_cube_map(tmp_path, layout):
     with pytest.raises(RuntimeError):
         vx.load_skybox_faces(bad)
     bc = bytearray(raw)
-    bc[80:88] = struct.pack("<I4s", 0x4, b"ATI2")  # BC5: a block-compressed format the loader does not decode
+    bc[80:88] = struct.pack("<I4s", 0x4, b"BC5S")  # signed BC5: a block-compressed format the loader does not decode
     open(bad, "wb").write(bc)
     with pytest.raises(RuntimeError):
         vx.load_skybox_faces(bad)
@@ -632,6 +632,26 @@ def _bc_decode_block(b, bc):
     """One 4x4 block of BC1 / BC2 / BC3 by the published rules ("Texture Block Compression in Direct3D 11"), float32 like the
     loader: end points c/31, c/63; palette at 1/3, 2/3 (BC1 with c0 <= c1: midpoint + transparent black); byte = floor(c*255 + 0.5)."""
     f = np.float32
+    if bc in (4, 5):  # one / two interpolated 8-byte blocks: red (and green); blue 0, alpha 255
+        def channel(blk):
+            a0, a1 = int(blk[0]), int(blk[1])
+            al = [a0, a1]
+            for k in range(2, 8):
+                if a0 > a1:
+                    a = (f(8 - k) * f(a0) + f(k - 1) * f(a1)) / f(7)
+                elif k < 6:
+                    a = (f(6 - k) * f(a0) + f(k - 1) * f(a1)) / f(5)
+                else:
+                    a = f(0) if k == 6 else f(255)
+                al.append(int(f(a) + f(0.5)))
+            bits = int.from_bytes(bytes(blk[2:8]), "little")
+            return [al[(bits >> (3 * i)) & 7] for i in range(16)]
+        out = np.zeros((16, 4), np.uint8)
+        out[:, 0] = channel(b[:8])
+        if bc == 5:
+            out[:, 1] = channel(b[8:16])
+        out[:, 3] = 255
+        return out.reshape(4, 4, 4)
     col = b if bc == 1 else b[8:]
     c0, c1 = int(col[0]) | int(col[1]) << 8, int(col[2]) | int(col[3]) << 8
 
@@ -671,14 +691,14 @@ def _bc_decode_block(b, bc):
     return out.reshape(4, 4, 4)
 
 
-@pytest.mark.parametrize("bc,dx10", [(1, False), (2, False), (3, False), (1, True), (3, True)])
+@pytest.mark.parametrize("bc,dx10", [(1, False), (2, False), (3, False), (1, True), (3, True), (4, False), (5, False), (4, True), (5, True)])
 def test_skybox_from_a_block_compressed_dds_cube_map(tmp_path, bc, dx10):
     """SURVEY §8(f)-4's last leftover: the reference's Skybox.dds (missing from the checkout) goes through DirectXTex, which
-    writes BC1 / BC2 / BC3 as readily as RGBA.  Cube maps of random blocks (every palette mode, both BC3 alpha modes, a mip chain)
+    writes BC1 ... BC5 as readily as RGBA.  Cube maps of random blocks (every palette mode, both interpolated-alpha modes, a mip chain)
     in the legacy FourCC and the DX10 header layouts decode to what the published block rules give, texel for texel; a truncated
     file and BC7 are refused."""
     rng = np.random.default_rng(40 + bc)
-    S, block = 12, 8 if bc == 1 else 16
+    S, block = 12, 8 if bc in (1, 4) else 16
     mips = 3
     faces_blocks = []
     body = b""
@@ -698,11 +718,11 @@ def test_skybox_from_a_block_compressed_dds_cube_map(tmp_path, bc, dx10):
                     by, bx = divmod(k, bw)
                     want[f, by * 4:by * 4 + 4, bx * 4:bx * 4 + 4] = tex[: min(4, S - by * 4), : min(4, S - bx * 4)]
             body += blocks.tobytes()
-    fourcc = {1: b"DXT1", 2: b"DXT3", 3: b"DXT5"}[bc]
+    fourcc = {1: b"DXT1", 2: b"DXT3", 3: b"DXT5", 4: b"ATI1", 5: b"ATI2"}[bc]
     hdr = struct.pack("<4s7I44x", b"DDS ", 124, 0x1 | 0x2 | 0x4 | 0x1000 | 0x20000 | 0x80000, S, S, ((S + 3) // 4) ** 2 * block, 0, mips)
     if dx10:
         hdr += struct.pack("<2I4s5I", 32, 0x4, b"DX10", 0, 0, 0, 0, 0)
-        tail = struct.pack("<5I", {1: 71, 2: 74, 3: 77}[bc], 3, 0x4, 1, 0)
+        tail = struct.pack("<5I", {1: 71, 2: 74, 3: 77, 4: 80, 5: 83}[bc], 3, 0x4, 1, 0)
     else:
         hdr += struct.pack("<2I4s5I", 32, 0x4, fourcc, 0, 0, 0, 0, 0)
         tail = b""

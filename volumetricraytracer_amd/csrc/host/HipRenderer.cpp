@@ -151,8 +151,38 @@ VObjectPtr<VTextureCube> VTextureCube::LoadFromFaceDirectory(const std::string& 
  * exported with the reference's toolchain — DirectXTex `texassemble` / `texconv` — is most likely to be in) into 16 RGBA8 texels,
  * row-major.  Colours: two R5G6B5 end points expanded to [0,1] (c/31, c/63), palette entries 2 and 3 at 1/3 and 2/3 (BC1 with
  * c0 <= c1: the midpoint and transparent black); bytes = round(c * 255).  BC2: explicit 4-bit alpha; BC3: two 8-bit alpha end
- * points with six or four interpolated steps. */
-static void decode_bc_block(const uint8_t* b, int bc /* 1, 2, 3 */, uint8_t out[16][4]) {
+ * points with six or four interpolated steps; BC4 / BC5: one / two such blocks as the red / red and green channel. */
+/* One 8-byte interpolated-alpha block (BC3's alpha half, a BC4 block, each half of a BC5 block): two 8-bit end points with six
+ * or four interpolated steps, sixteen 3-bit indices. */
+static void decode_alpha_block(const uint8_t* b, uint8_t out[16]) {
+    uint8_t alpha[8];
+    alpha[0] = b[0];
+    alpha[1] = b[1];
+    for (int k = 2; k < 8; k++) {
+        float a;
+        if (alpha[0] > alpha[1]) a = ((float)(8 - k) * (float)alpha[0] + (float)(k - 1) * (float)alpha[1]) / 7.0f;
+        else if (k < 6) a = ((float)(6 - k) * (float)alpha[0] + (float)(k - 1) * (float)alpha[1]) / 5.0f;
+        else a = k == 6 ? 0.0f : 255.0f;
+        alpha[k] = (uint8_t)(a + 0.5f);
+    }
+    unsigned long long bits = 0;
+    for (int k = 0; k < 6; k++) bits |= (unsigned long long)b[2 + k] << (8 * k);
+    for (int i = 0; i < 16; i++) out[i] = alpha[(bits >> (3 * i)) & 7u];
+}
+
+static void decode_bc_block(const uint8_t* b, int bc /* 1 ... 5 */, uint8_t out[16][4]) {
+    if (bc == 4 || bc == 5) { /* BC4: one channel (red), BC5: two (red, green); the others read 0, alpha 1 */
+        uint8_t r[16], g[16] = {};
+        decode_alpha_block(b, r);
+        if (bc == 5) decode_alpha_block(b + 8, g);
+        for (int i = 0; i < 16; i++) {
+            out[i][0] = r[i];
+            out[i][1] = g[i];
+            out[i][2] = 0;
+            out[i][3] = 255;
+        }
+        return;
+    }
     const uint8_t* col = bc == 1 ? b : b + 8;
     const unsigned c0 = col[0] | col[1] << 8, c1 = col[2] | col[3] << 8;
     float pal[4][4];
@@ -177,26 +207,14 @@ static void decode_bc_block(const uint8_t* b, int bc /* 1, 2, 3 */, uint8_t out[
     pal[2][3] = 1.0f;
     pal[3][3] = four ? 1.0f : 0.0f;
     const unsigned idx = col[4] | col[5] << 8 | col[6] << 16 | (unsigned)col[7] << 24;
-    uint8_t alpha[8];
-    unsigned long long abits = 0;
-    if (bc == 3) {
-        alpha[0] = b[0];
-        alpha[1] = b[1];
-        for (int k = 2; k < 8; k++) {
-            float a;
-            if (alpha[0] > alpha[1]) a = ((float)(8 - k) * (float)alpha[0] + (float)(k - 1) * (float)alpha[1]) / 7.0f;
-            else if (k < 6) a = ((float)(6 - k) * (float)alpha[0] + (float)(k - 1) * (float)alpha[1]) / 5.0f;
-            else a = k == 6 ? 0.0f : 255.0f;
-            alpha[k] = (uint8_t)(a + 0.5f);
-        }
-        for (int k = 0; k < 6; k++) abits |= (unsigned long long)b[2 + k] << (8 * k);
-    }
+    uint8_t alpha3[16] = {};
+    if (bc == 3) decode_alpha_block(b, alpha3);
     for (int i = 0; i < 16; i++) {
         const float* p = pal[(idx >> (2 * i)) & 3u];
         for (int k = 0; k < 3; k++) out[i][k] = (uint8_t)(p[k] * 255.0f + 0.5f);
         if (bc == 1) out[i][3] = (uint8_t)(p[3] * 255.0f + 0.5f);
         else if (bc == 2) out[i][3] = (uint8_t)(((b[i >> 1] >> ((i & 1) * 4)) & 15u) * 17u);
-        else out[i][3] = alpha[(abits >> (3 * i)) & 7u];
+        else out[i][3] = alpha3[i];
     }
 }
 
@@ -221,12 +239,14 @@ VObjectPtr<VTextureCube> VTextureCube::LoadFromDDSFile(const std::string& path) 
     if (mips == 0) mips = 1;
     size_t data = 128;
     int bpp = 0;          /* bytes per pixel in the file */
-    int bc = 0;           /* block-compressed: 1 = BC1 (DXT1), 2 = BC2 (DXT3), 3 = BC3 (DXT5) */
+    int bc = 0;           /* block-compressed: 1 = BC1 (DXT1), 2 = BC2 (DXT3), 3 = BC3 (DXT5), 4 = BC4 (ATI1 / BC4U), 5 = BC5 (ATI2 / BC5U) */
     int ri = 0, gi = 1, bi = 2, ai = 3; /* byte index of each channel; ai < 0: opaque */
     bool cube = false;
-    if ((pf_flags & 0x4u) && (fourcc == 0x31545844u /* "DXT1" */ || fourcc == 0x33545844u /* "DXT3" */ || fourcc == 0x35545844u /* "DXT5" */)) {
+    const bool ati1 = fourcc == 0x31495441u /* "ATI1" */ || fourcc == 0x55344342u /* "BC4U" */;
+    const bool ati2 = fourcc == 0x32495441u /* "ATI2" */ || fourcc == 0x55354342u /* "BC5U" */;
+    if ((pf_flags & 0x4u) && (fourcc == 0x31545844u /* "DXT1" */ || fourcc == 0x33545844u /* "DXT3" */ || fourcc == 0x35545844u /* "DXT5" */ || ati1 || ati2)) {
         cube = (caps2 & 0x200u) && (caps2 & 0xfc00u) == 0xfc00u;
-        bc = fourcc == 0x31545844u ? 1 : fourcc == 0x33545844u ? 2 : 3;
+        bc = fourcc == 0x31545844u ? 1 : fourcc == 0x33545844u ? 2 : fourcc == 0x35545844u ? 3 : ati1 ? 4 : 5;
     } else if ((pf_flags & 0x4u) && fourcc == 0x30315844u /* "DX10" */) {
         if (file.size() < 148) return nullptr;
         const uint32_t dxgi = u32(128), dim = u32(132), misc = u32(136);
@@ -237,6 +257,8 @@ VObjectPtr<VTextureCube> VTextureCube::LoadFromDDSFile(const std::string& path) 
         } else if (dxgi == 87 || dxgi == 91 || dxgi == 90) { ri = 2; bi = 0; /* B8G8R8A8 */
         } else if (dxgi == 88 || dxgi == 93 || dxgi == 92) { ri = 2; bi = 0; ai = -1; /* B8G8R8X8 */
         } else if (dxgi >= 70 && dxgi <= 78) { bc = 1 + (int)(dxgi - 70) / 3; /* BC1 / BC2 / BC3 (typeless, unorm, srgb) */
+        } else if (dxgi == 79 || dxgi == 80) { bc = 4; /* BC4 (typeless, unorm; signed: not read) */
+        } else if (dxgi == 82 || dxgi == 83) { bc = 5; /* BC5 (typeless, unorm) */
         } else return nullptr;
     } else if (pf_flags & 0x40u /* DDPF_RGB */) {
         cube = (caps2 & 0x200u) && (caps2 & 0xfc00u) == 0xfc00u; /* DDSCAPS2_CUBEMAP with all six faces */
@@ -248,14 +270,14 @@ VObjectPtr<VTextureCube> VTextureCube::LoadFromDDSFile(const std::string& path) 
         else return nullptr;
         if (ri < 0 || gi < 0 || bi < 0 || ri >= bpp || gi >= bpp || bi >= bpp) return nullptr;
     } else {
-        return nullptr; /* BC4-BC7, float or exotic formats: not supported */
+        return nullptr; /* BC6H / BC7, signed, float or exotic formats: not supported */
     }
     if (!cube || width == 0 || width != height || width > 16384) return nullptr;
     uint32_t max_mips = 1;
     while ((width >> max_mips) != 0) max_mips++;
     mips = std::min(mips, max_mips);
     size_t face_bytes = 0; /* all mip levels of one face */
-    const size_t block_bytes = bc == 1 ? 8 : 16;
+    const size_t block_bytes = (bc == 1 || bc == 4) ? 8 : 16;
     for (uint32_t m = 0; m < mips; m++) {
         const size_t w = std::max(1u, width >> m), h = std::max(1u, height >> m);
         face_bytes += bc ? ((w + 3) / 4) * ((h + 3) / 4) * block_bytes : w * h * (size_t)bpp;
