@@ -84,6 +84,8 @@ def parse_args(argv=None):
                     help="A/B: vrt_render_block issues one march launch per frame (VRT_FLAG_BLOCK_PER_FRAME) instead of one per block")
     ap.add_argument("--k-relax", type=float, default=0.0,
                     help="over-relaxation factor of the sphere trace (vrt_params.k_relax); 0 = the renderer's default (1.7), 1 = plain")
+    ap.add_argument("--no-hit-polish", action="store_true",
+                    help="A/B: VRT_FLAG_NO_HIT_POLISH — closest hits stay where the cone threshold stopped the ray (rounds 1-3)")
     ap.add_argument("--tile-map", default="supertile", choices=["supertile", "band", "linear"], help="blockIdx -> tile map (speed only)")
     ap.add_argument("--exchange", default="rotate", choices=["rotate", "gather"],
                     help="N>1: where the frames of a block are assembled: rotate = frame g on rank g // (block / N), one all-to-all "
@@ -164,6 +166,7 @@ def kernel_source_hash() -> str:
 def traffic_key(args, world: int, K: int, G: int, rgba8: bool) -> dict:
     return {"workload": args.workload, "n_gpus": world, "path": args.path, "format": args.format, "tile_map": args.tile_map,
             "streams": K, "frames_per_launch": G, "rgba8": bool(rgba8), "k_relax": args.k_relax, "frames_per_step": args.frames_per_step,
+            "hit_polish": not args.no_hit_polish,
             "kernel_source_sha": kernel_source_hash()}
 
 
@@ -462,6 +465,8 @@ def main() -> None:
             q.flags |= _abi.FLAG_OUTPUT_RGBA8
         if args.per_frame_launches:
             q.flags |= _abi.FLAG_BLOCK_PER_FRAME
+        if args.no_hit_polish:
+            q.flags |= _abi.FLAG_NO_HIT_POLISH
         q.flags |= {"supertile": 0, "band": 1, "linear": 2}[args.tile_map]
         return q
 

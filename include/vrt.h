@@ -64,6 +64,9 @@ extern "C" {
                                        light shadow rays and their shading / a third pass for the lanes that mirror, in frames that can
                                        bounce; same pixels and counters, twice the waves per SIMD).  A lone frame is one kernel by default */
 #define VRT_FLAG_FULL_THREE_PASS 512 /* ... and the three passes even for a lone frame (tests, measurements).  Not both */
+#define VRT_FLAG_NO_HIT_POLISH 1024 /* closest hits stay where the cone threshold stopped the ray (rounds 1-3) instead of moving on to the surface's
+                                      zero crossing by VRT_HIT_POLISH_SAMPLES secant samples: A/B measurements, tests */
+#define VRT_HIT_POLISH_SAMPLES 2   /* part of the march contract: samples a closest hit spends on its way from the stop point to the crossing */
 #define VRT_FLAG_NO_TIMING 16    /* the launch records no event pair: vrt_last_timing / vrt_timing_history report 0 ms for it.
                                    An event pair costs 5-7 us of queue time per launch (profiles/r02_launch_overhead.txt);
                                    callers that keep many small launches in flight time a sample of them */
@@ -188,7 +191,7 @@ typedef struct vrt_params {
                              (speed only, never results); bit 2: VRT_FLAG_DIAG_TIMELINE; bit 3:
                              VRT_FLAG_OUTPUT_RGBA8; bit 4: VRT_FLAG_NO_TIMING; bit 5: accepted and ignored (it was round 1's
                              VRT_FLAG_SKIP_EMPTY: the march never samples empty cells now); bit 6: VRT_FLAG_BLOCK_PER_FRAME; bit 7: VRT_FLAG_NO_CULL_RECT;
-                             bit 8: VRT_FLAG_FULL_ONE_KERNEL; bit 9: VRT_FLAG_FULL_THREE_PASS.  Others 0 */
+                             bit 8: VRT_FLAG_FULL_ONE_KERNEL; bit 9: VRT_FLAG_FULL_THREE_PASS; bit 10: VRT_FLAG_NO_HIT_POLISH.  Others 0 */
     float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
     float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
     float step_min;       /* lower bound of one march step (ray-parameter units) */

@@ -79,6 +79,9 @@ def load() -> C.CDLL:
                                          C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         lib.vrto_ref_hit_batch.restype = C.c_int
         lib.vrto_ref_hit_batch.argtypes = [C.POINTER(vrto_volume), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        lib.vrto_ref_render.restype = C.c_int
+        lib.vrto_ref_render.argtypes = [C.POINTER(_abi.vrt_scene), C.POINTER(vrto_volume), C.c_void_p, C.c_int,
+                                        C.POINTER(_abi.vrt_params), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         lib.vrto_debug_tables.restype = C.c_int
         lib.vrto_debug_tables.argtypes = [C.POINTER(vrto_volume), C.c_void_p, C.c_void_p, C.c_void_p]
         lib.vrto_env_lookup.restype = None
@@ -135,6 +138,18 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError(f"vrto_render failed: {rc}")
         return out, {n: getattr(st, n) for n, _ in st._fields_}
+
+    def ref_render(self, params: _abi.vrt_params, row0: int = 0, rows: Optional[int] = None, threads: int = 8):
+        """vrto_ref_render: the frame the REFERENCE's intersection (exact cubic root, normal at the root) would shade.
+        Returns (image [rows, W, 4] float32, t [rows, W] float32 with -1 for camera rays that miss)."""
+        rows = params.height - row0 if rows is None else rows
+        out = np.empty((rows, params.width, 4), dtype=np.float32)
+        t = np.empty((rows, params.width), dtype=np.float32)
+        rc = load().vrto_ref_render(C.byref(self.abi), self.vols, self.env.ctypes.data if self.env is not None else None,
+                                    self.env_size, C.byref(params), row0, rows, out.ctypes.data, t.ctypes.data, threads)
+        if rc != 0:
+            raise RuntimeError(f"vrto_ref_render failed: {rc}")
+        return out, t
 
     def trace(self, params: _abi.vrt_params, origin, direction, t_max: float = 10000.0):
         lib = load()

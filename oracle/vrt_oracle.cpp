@@ -178,6 +178,7 @@ struct Packed {
     float light_strength;
     const vrt_scene* scene;
     vrt_params prm;
+    bool ref_intersection = false; /* vrto_ref_render: every ray is intersected by the REFERENCE's hit search (ref_march_instance) */
     uint32_t* steps_img; /* optional debug output, rows*width: march positions of the primary ray (low 16 bits) and of the rays after it (high 16) */
 };
 
@@ -705,9 +706,12 @@ bool march_cube(const Packed& P, int ii, V3 o, V3 d, float t_cur, bool want_norm
     return false;
 }
 
+bool ref_march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, bool want_normal, float& t_hit, V3& n_world);
+
 /* March one instance.  Returns true on hit with t (ray parameter, shared with world space). */
 bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_base, bool want_normal,
                     float& t_hit, V3& n_world, uint64_t& steps) {
+    if (P.ref_intersection) return ref_march_instance(P, ii, o, d, t_cur, want_normal, t_hit, n_world);
     if (P.prm.mode >= VRT_MODE_CUBE) return march_cube(P, ii, o, d, t_cur, want_normal, t_hit, n_world, steps);
     const Instance& I = P.inst[ii];
     const Volume& V = P.vol[I.slot];
@@ -827,6 +831,41 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
                 czf = minf(maxf(floorf(uz), 0.0f), cmax);
                 fx = ux - cxf; fy = uy - cyf; fz = uz - czf;
                 cx = (int)cxf; cy = (int)cyf; cz = (int)czf;
+            }
+            else if (want_normal && i > 0 && !(P.prm.flags & VRT_FLAG_NO_HIT_POLISH)) {
+                /* Hit polish: the cone threshold stops the ray up to a few pixel footprints IN FRONT of the
+                   surface; the reference reports the zero crossing itself and takes its normal there (Voxel.hlsli:691-804).  The
+                   hit DECISION above stands; its position moves on to the crossing by the secant rule: first estimate from the
+                   march's own last two samples (when the previous one is a real, unclamped sample), else one sphere step;
+                   VRT_HIT_POLISH_SAMPLES samples, each followed by the secant through the last two points; never behind the
+                   stop point, never more than 8 thresholds ahead, never beyond the interval. */
+                const float span = 8.0f * fmaf(t, P.prm.cone_eps, P.prm.eps_hit);
+                const float t_far = t + span;
+                float ta = t, sa = s;
+                float tb = (s_prev > s && s_prev < smax) ? t + (s * (t - t_prev)) / (s_prev - s) : t + s;
+                tb = fminf(fmaxf(tb, t), t_far);
+                for (int r = 0; r < VRT_HIT_POLISH_SAMPLES; r++) {
+                    const float mx = fmaf(ud.x, tb, uo.x), my = fmaf(ud.y, tb, uo.y), mz = fmaf(ud.z, tb, uo.z);
+                    const float mcx = minf(maxf(floorf(mx), 0.0f), cmax);
+                    const float mcy = minf(maxf(floorf(my), 0.0f), cmax);
+                    const float mcz = minf(maxf(floorf(mz), 0.0f), cmax);
+                    const float sb = trilinear(V, (int)mcx, (int)mcy, (int)mcz, mx - mcx, my - mcy, mz - mcz) * ds;
+                    steps++;
+                    /* zero of the line through (ta, sa), (tb, sb); equal samples (the estimate has converged: tb rounds onto ta): stay */
+                    const float tm = sa != sb ? fminf(fmaxf(fmaf(tb - ta, sb / (sa - sb), tb), t), t_far) : tb;
+                    ta = tb;
+                    sa = sb;
+                    tb = tm;
+                }
+                if (tb <= t_end) {
+                    t = tb;
+                    ux = fmaf(ud.x, t, uo.x); uy = fmaf(ud.y, t, uo.y); uz = fmaf(ud.z, t, uo.z);
+                    cxf = minf(maxf(floorf(ux), 0.0f), cmax);
+                    cyf = minf(maxf(floorf(uy), 0.0f), cmax);
+                    czf = minf(maxf(floorf(uz), 0.0f), cmax);
+                    fx = ux - cxf; fy = uy - cyf; fz = uz - czf;
+                    cx = (int)cxf; cy = (int)cyf; cz = (int)czf;
+                }
             }
             t_hit = t;
             if (want_normal) {
@@ -1407,12 +1446,11 @@ void vrto_env_lookup(const uint8_t* env_rgba8, int face_size, const float dir[3]
     env_lookup(env_rgba8, face_size, v3(dir[0], dir[1], dir[2]), rgb_out);
 }
 
+}  // extern "C"
+
 /* ---- reference-algorithm cross-check (double precision) -------------------------------- */
 
 namespace {
-inline double tap(const vrto_volume* vol, int N, int x, int y, int z) {
-    return (double)vol->density[((size_t)x * N + (size_t)z) * N + (size_t)y];
-}
 inline double cubic(double A, double B, double C, double D, double s) { return ((A * s + B) * s + C) * s + D; }
 
 /* first root of the cubic in [s0,1] given f(s0) > 0, or -1 */
@@ -1453,12 +1491,26 @@ double first_root(double A, double B, double C, double D, double s0) {
     }
     return -1.0;
 }
-}  // namespace
 
-int vrto_ref_hit_t(const vrto_volume* vol, const float origin[3], const float dir[3], double* t_out) {
-    const int N = (1 << vol->resolution) + 1;
-    const double E = vol->extent, cell = 2.0 * E / (N - 1);
-    double o[3] = {origin[0], origin[1], origin[2]}, d[3] = {dir[0], dir[1], dir[2]};
+/* The reference's hit search for one OBJECT-space ray through one density grid (den: N^3, index x*N*N + z*N + y), shared by
+   vrto_ref_hit_t and vrto_ref_render.  Cell-by-cell walk (GoToNextVoxel, Voxel.hlsli:80-128, without the +0.1 nudge and
+   without the octree: a merged node holds no surface, so skipping it changes nothing); in every cell with a corner <= 0
+   (HasIsoSurfaceInsideCell / IsSolidCell, :497-538) the trilinear interpolant along the ray as a cubic in s in [0,1]
+   (GetDensityPolynomial, :552-605) and its first root (GetSurfaceIntersectionT, :691-781: the reference splits at the
+   derivative's roots and takes 2 regula-falsi steps + 1 secant; here the bracket is bisected to double precision — the
+   zero the reference approximates).  A cell whose interpolant is <= 0 where the ray enters it reports the entry point
+   (:704-708).  Double precision throughout. */
+struct RefHit {
+    double t = 0.0;       /* ray parameter of the hit */
+    int c[3] = {0, 0, 0}; /* cell that holds it (x, y, z) */
+    bool first = false;   /* the hit is the very first position of the walk (max(tEnter, 0)) */
+    bool solid = false;   /* ... and that cell is solid: all 8 corners < 0 (IsSolidCell) */
+    double t_enter = 0.0; /* slab entry (negative: the origin is inside the volume) */
+};
+inline double tapd(const float* den, int N, int x, int y, int z) { return (double)den[((size_t)x * N + (size_t)z) * N + (size_t)y]; }
+
+int ref_walk(const float* den, int N, double E, const double o[3], const double d[3], RefHit& h) {
+    const double cell = 2.0 * E / (N - 1);
     /* slab (Ray.hlsli:111-134) */
     double t_enter = -1e300, t_exit = 1e300;
     for (int a = 0; a < 3; a++) {
@@ -1472,6 +1524,7 @@ int vrto_ref_hit_t(const vrto_volume* vol, const float origin[3], const float di
         }
     }
     if (!(t_exit > t_enter) || t_exit < 0.0) return 0;
+    h.t_enter = t_enter;
     double t = t_enter > 0.0 ? t_enter : 0.0;
     /* cell walk: at each step find the cell containing the midpoint of the next segment */
     for (int guard = 0; guard < 8 * N; guard++) {
@@ -1498,7 +1551,7 @@ int vrto_ref_hit_t(const vrto_volume* vol, const float origin[3], const float di
         double v[8];
         bool neg = false, pos = false;
         for (int k = 0; k < 8; k++) {
-            v[k] = tap(vol, N, c[0] + (k & 1), c[1] + ((k >> 1) & 1), c[2] + ((k >> 2) & 1));
+            v[k] = tapd(den, N, c[0] + (k & 1), c[1] + ((k >> 1) & 1), c[2] + ((k >> 2) & 1));
             if (v[k] < 0.0) neg = true;
             if (v[k] > 0.0) pos = true;
             if (v[k] == 0.0) { neg = true; pos = true; }
@@ -1528,18 +1581,102 @@ int vrto_ref_hit_t(const vrto_volume* vol, const float origin[3], const float di
                 C += (bx[0] * ay[1] * az[2] + ax[0] * by[1] * az[2] + ax[0] * ay[1] * bz[2]) * v[k];
             }
             if (!pos || D <= 0.0) { /* start inside: reference reports tIn (:704-708) */
-                *t_out = t;
+                h.t = t;
+                h.c[0] = c[0]; h.c[1] = c[1]; h.c[2] = c[2];
+                h.first = guard == 0;
+                h.solid = guard == 0 && !pos;
                 return 1;
             }
             double s = first_root(A, B, C, D, 0.0);
             if (s >= 0.0) {
-                *t_out = t + (t_out_cell - t) * s;
+                h.t = t + (t_out_cell - t) * s;
+                h.c[0] = c[0]; h.c[1] = c[1]; h.c[2] = c[2];
                 return 1;
             }
         }
         t = t_out_cell;
     }
     return 0;
+}
+
+/* GetDensity (Voxel.hlsli:607-684) of cell c at the cell-space position f, on the texels the shader would Load: a texel
+   outside the 3D texture reads as 0 (D3D out-of-bounds Load), density 0. */
+inline double ref_density(const float* den, int N, const int c[3], const double f[3]) {
+    double p = 0.0;
+    for (int k = 0; k < 8; k++) {
+        const int i = k & 1, j = (k >> 1) & 1, l = (k >> 2) & 1;
+        const int x = c[0] + i, y = c[1] + j, z = c[2] + l;
+        const double v = (x < 0 || y < 0 || z < 0 || x >= N || y >= N || z >= N) ? 0.0 : tapd(den, N, x, y, z);
+        p += fabs((1 - i) - f[0]) * fabs((1 - j) - f[1]) * fabs((1 - l) - f[2]) * v;
+    }
+    return p;
+}
+
+/*
+ * VRIntersection / VRIntersectionShadowRay (SH/Raytracing.hlsl:147-442) for one instance: the reference's OWN hit
+ * definition, for vrto_ref_render.  Object-space ray (GetLocalRay, Ray.hlsli:21-29), ref_walk for the hit distance, then
+ *   - GetNormal (Voxel.hlsli:783-804) evaluated AT THE ROOT: central difference of GetDensity in the cells c -+ 1 at the
+ *     root's own cell-space position, NaN -> (0,0,0), normalised — not at a point some footprints in front of it;
+ *   - a ray that enters the volume through a face into a solid cell reports the entry point with the AABB-face normal
+ *     (Raytracing.hlsl:198-226, normalised there);
+ *   - a hit outside [TMin = 0, RayTCurrent] is rejected by ReportHit and the shader returns: a ray that starts inside the
+ *     negative region of a volume does not hit that volume at all.
+ * Idealised where the shader's own numerics are not a definition: no +0.01 / +0.1 nudges (they are in units of the
+ * reference's un-normalised ray direction), no 255-iteration budget, the exact first root instead of three secant steps.
+ * Nothing here depends on the sphere-trace's contract (eps_hit, cone_eps, k_relax, tables, step clamp).
+ */
+bool ref_march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, bool want_normal, float& t_hit, V3& n_world) {
+    const Instance& I = P.inst[ii];
+    const Volume& V = P.vol[I.slot];
+    const V3 oo = mul(I.w2o, o - I.pos);
+    const V3 od = mul(I.w2o, d);
+    const double od3[3] = {od.x, od.y, od.z}, oo3[3] = {oo.x, oo.y, oo.z};
+    const double E = V.extent;
+    RefHit h;
+    if (!ref_walk(V.den, V.N, E, oo3, od3, h)) return false;
+    if (h.t_enter > (double)t_cur) return false;           /* DetermineRayAABBIntersection: tEnter <= TCurrent */
+    if (h.first && h.t_enter < 0.0) return false;          /* origin inside the solid: reported t <= 0, rejected */
+    if (!(h.t > 0.0) || h.t > (double)t_cur) return false; /* ReportHit's interval */
+    t_hit = (float)h.t;
+    if (!want_normal) return true;
+    double n[3] = {0.0, 0.0, 0.0};
+    if (h.solid) {
+        const double tb = h.t_enter - 0.1;
+        for (int a = 0; a < 3; a++) {
+            const double rp = oo3[a] + od3[a] * tb;
+            n[a] = rp > E ? 1.0 : (rp < -E ? -1.0 : 0.0);
+        }
+    } else {
+        const double cell = 2.0 * E / (V.N - 1);
+        double f[3];
+        for (int a = 0; a < 3; a++) f[a] = ((oo3[a] + od3[a] * h.t) - (-E + cell * h.c[a])) / cell;
+        for (int a = 0; a < 3; a++) {
+            int cp[3] = {h.c[0], h.c[1], h.c[2]}, cm[3] = {h.c[0], h.c[1], h.c[2]};
+            cp[a] += 1;
+            cm[a] -= 1;
+            n[a] = ref_density(V.den, V.N, cp, f) - ref_density(V.den, V.N, cm, f);
+        }
+    }
+    const double l2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    V3 nf = v3(0.0f, 0.0f, 0.0f);
+    if (l2 > 0.0) {
+        const double inv = 1.0 / sqrt(l2);
+        nf = v3((float)(n[0] * inv), (float)(n[1] * inv), (float)(n[2] * inv));
+    }
+    n_world = mul(I.o2w, nf);
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+int vrto_ref_hit_t(const vrto_volume* vol, const float origin[3], const float dir[3], double* t_out) {
+    const int N = (1 << vol->resolution) + 1;
+    const double o[3] = {origin[0], origin[1], origin[2]}, d[3] = {dir[0], dir[1], dir[2]};
+    RefHit h;
+    if (!ref_walk(vol->density, N, (double)vol->extent, o, d, h)) return 0;
+    *t_out = h.t;
+    return 1;
 }
 
 /* vrto_ref_hit_t for n object-space rays of one volume. */
@@ -1561,6 +1698,44 @@ int vrto_ref_hit_batch(const vrto_volume* vol, int n, const float* origins, cons
         for (auto& t : th) t.join();
     }
     return 0;
+}
+
+
+/* The frame the REFERENCE's intersection would shade: every ray (camera, shadow, mirror) is intersected by
+   ref_march_instance; camera ray, closest-hit shading, miss and tone-map are the oracle's restatements of the reference's
+   (radiance_ray).  Independent of the sphere-trace contract: params' march fields (eps_hit, cone_eps, k_relax, step_*, max_steps)
+   are not read.  t_out_or_null (rows*width): the camera ray's hit distance, or -1 for a miss. */
+int vrto_ref_render(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env_rgba8, int env_face_size,
+                    const vrt_params* params, int row0, int rows, float* out_rgba, float* t_out_or_null, int threads) {
+    std::unique_ptr<Packed> P(new Packed);
+    if (!pack(scene, volumes, env_rgba8, env_face_size, params, *P) || !out_rgba) return VRT_ERR_INVALID;
+    if (!(params->mode >= VRT_MODE_INTERP && params->mode < VRT_MODE_CUBE)) return VRT_ERR_UNSUPPORTED;
+    if (row0 < 0 || rows < 0 || row0 + rows > params->height) return VRT_ERR_INVALID;
+    P->ref_intersection = true;
+    if (threads < 1) threads = 1;
+    const int W = params->width;
+    auto work = [&](int k) {
+        Stats st;
+        for (int y = row0 + k; y < row0 + rows; y += threads) {
+            render_rows(*P, y, y + 1, row0, out_rgba, st);
+            if (t_out_or_null)
+                for (int x = 0; x < W; x++) {
+                    V3 o, d;
+                    camera_ray(P->cam, W, params->height, x, y, o, d);
+                    HitRec h;
+                    uint64_t steps = 0;
+                    t_out_or_null[(size_t)(y - row0) * W + x] = trace_closest(*P, o, d, 10000.0f, 0.0f, h, steps) ? h.t : -1.0f;
+                }
+        }
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int k = 0; k < threads; k++) th.emplace_back(work, k);
+        for (auto& t : th) t.join();
+    }
+    return VRT_OK;
 }
 
 }  // extern "C"

@@ -90,6 +90,15 @@ int vrto_ref_hit_t(const vrto_volume* vol, const float origin[3], const float di
 /* The same for n rays. */
 int vrto_ref_hit_batch(const vrto_volume* vol, int n, const float* origins, const float* dirs, uint8_t* hit_out, double* t_out, int threads);
 
+/* The frame as the REFERENCE's own intersection would produce it (SH/Raytracing.hlsl:147-442): per ray the exact first root of the
+ * per-cell cubic (Voxel.hlsli:552-605, 691-781), the normal from GetNormal evaluated AT that root (Voxel.hlsli:783-804), the
+ * AABB-face normal for a solid start cell (Raytracing.hlsl:198-226); camera ray, closest-hit shading, miss and tone-map as in
+ * vrto_render.  Reads nothing of the sphere-trace's contract (eps_hit, cone_eps, k_relax, step_*, max_steps, tables), so
+ * fixtures made with it do NOT move when that contract changes (tests/golden/ref_*.npz, tests/golden/make_ref_golden.py).
+ * Interp modes only.  t_out_or_null (rows*width): camera-ray hit distance, -1 = miss. */
+int vrto_ref_render(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env_rgba8, int env_face_size,
+                    const vrt_params* params, int row0, int rows, float* out_rgba, float* t_out_or_null, int threads);
+
 /* Debug: the two-level empty-space table the march uses for `vol` under its metric (step_max > 0) — skip_out: nb^3
  * Chebyshev brick distances D, nib_out: nb^3 words of sub-block nibbles — and (field_out, N^3 floats) the field the march
  * samples (the integer field +-q for VRT_FORMAT_TEXEL16).  Any pointer may be NULL. */

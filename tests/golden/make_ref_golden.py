@@ -1,0 +1,63 @@
+"""Generates tests/golden/ref_*.npz: frames as the REFERENCE's own intersection would shade them.
+
+vrto_ref_render (oracle/vrt_oracle.cpp) intersects every ray — camera, shadow, mirror — the way the reference's
+intersection shaders do (SH/Raytracing.hlsl:147-442): cell walk, per cell the exact first root of the cubic the trilinear
+interpolant is along the ray (SH/Include/Voxel.hlsli:552-605, 691-781), the normal from GetNormal evaluated AT that root
+(Voxel.hlsli:783-804), the AABB-face normal for a solid start cell (Raytracing.hlsl:198-226), in double precision; camera
+ray, closest-hit shading, miss and tone-map are the oracle's restatements of the reference's.  It reads NOTHING of the
+sphere-trace's contract (eps_hit, cone_eps, k_relax, step clamp, empty-space tables, hit polish), so these fixtures do not
+change when that contract changes — unlike tests/golden/config*.npz, which freeze the oracle's own sphere-trace.
+
+The reference cannot run here (HLSL/DXR + D3D12) and holds no image of its own: this is the strongest
+pixel-level pin available without its toolchain.  Run:  python tests/golden/make_ref_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from volumetricraytracer_amd import workloads as scenes  # noqa: E402
+import volumetricraytracer_amd as v  # noqa: E402
+
+TEXEL16, F32 = v._abi.FORMAT_TEXEL16, v._abi.FORMAT_F32
+
+# name: (scene builder, kwargs, width, height, row0, rows, shadow)
+CASES = {
+    # the benched 256^3 Voxelizer shell (bench.py's config 3), whole frame at 320x180, on the field the reference's GPU
+    # sees (its 16-bit texel) and on the unquantised floats
+    "ref_c3vox256_texel16_320x180": (scenes.config3_voxelized, dict(resolution=8, env=64, device_format=TEXEL16), 320, 180, 0, 180, True),
+    "ref_c3vox256_f32_320x180": (scenes.config3_voxelized, dict(resolution=8, env=64, device_format=F32), 320, 180, 0, 180, True),
+    # the same volume at the BENCHED frame size, 1920x1080: a band of 96 rows through the torus
+    "ref_c3vox256_texel16_1080p_rows492": (scenes.config3_voxelized, dict(resolution=8, env=64, device_format=TEXEL16), 1920, 1080, 492, 96, True),
+    # config 2: the demo's 64^3 sphere
+    "ref_c2sphere64_320x180": (scenes.config2_sphere, dict(resolution=6, env=16), 320, 180, 0, 180, False),
+    # config 5 at reduced size: 8 instances (rotated, scaled) of a 32^3 CSG volume, shadow rays between instances
+    "ref_c5inst32_320x180": (scenes.config5_instances, dict(resolution=5, env=16), 320, 180, 0, 180, True),
+}
+
+
+def build_case(case):
+    fn, kw, w, h, row0, rows, shadow = case
+    sc = fn(**kw)
+    p = v.default_params(w, h, scenes.min_cell(sc), 255, shadow=shadow)
+    return sc, p, row0, rows
+
+
+def quantise(img):
+    """The reference's 8-bit render target (B8G8R8A8_UNORM, DXConstants.cpp:21): round(min(c, 1) * 255)."""
+    return np.floor(np.minimum(img[..., :3], 1.0) * 255.0 + 0.5).astype(np.uint8)
+
+
+if __name__ == "__main__":
+    from oracle.binding import OracleScene
+
+    for name, case in CASES.items():
+        sc, p, row0, rows = build_case(case)
+        img, t = OracleScene(sc).ref_render(p, row0, rows, threads=8)
+        # 8-bit colours (what the reference's target holds) + the camera rays' hit distances as float16-safe float32
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), rgb8=quantise(img), t=t.astype(np.float32),
+                            window=np.array([p.width, p.height, row0, rows], np.int32))
+        print(name, img.shape, "hits", int((t > 0).sum()))

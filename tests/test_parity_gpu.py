@@ -411,6 +411,73 @@ def test_hit_mask_is_the_reference_surface_on_the_benched_volume(renderer, oracl
     assert (mask != ref).mean() < 0.01
 
 
+# ---- pixel-level pin to the reference's own intersection -----------------------------------------------
+# tests/golden/ref_*.npz: frames as the reference's intersection shaders would produce them (exact per-cell cubic root, normal at
+# the root; vrto_ref_render, tests/golden/make_ref_golden.py) in the 8-bit colours of its render target.  The fixtures do not
+# depend on the sphere-trace's contract.  Bounds: fraction of the interior of the reference's surfaces whose 8-bit colour differs
+# by more than 1 / 2 steps (tests/ref_pixels.py); measured values in DESIGN.md §5.
+REF_PIXEL_BOUNDS = {
+    "ref_c3vox256_texel16_320x180": (0.002, 0.002),
+    "ref_c3vox256_f32_320x180": (0.002, 0.002),
+    "ref_c3vox256_texel16_1080p_rows492": (0.001, 0.001),
+    "ref_c2sphere64_320x180": (0.0, 0.0),
+    "ref_c5inst32_320x180": (0.0, 0.0),
+}
+_ref_pixel_report = []
+
+
+def _ref_case(name):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_ref_golden", os.path.join(GOLDEN, "make_ref_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.build_case(m.CASES[name])
+
+
+@pytest.mark.parametrize("name", sorted(REF_PIXEL_BOUNDS))
+def test_hip_frame_is_the_reference_frame(renderer, name):
+    """HIP frames (k_relax 1.0 and 1.7; the float target quantised, and the RGBA8 target itself) against the reference-intersection
+    fixtures: the interior of every surface within the bounds above, the whole window (silhouettes included) under 1 %."""
+    from tests import ref_pixels
+
+    sc, p, row0, rows = _ref_case(name)
+    gt1, gt2 = REF_PIXEL_BOUNDS[name]
+    for k_relax in (1.7, 1.0):
+        q = _abi.vrt_params.from_buffer_copy(p)
+        q.k_relax = k_relax
+        img, t = gpu_render(renderer, sc, q)
+        m = ref_pixels.compare(img[row0:row0 + rows], name)
+        _ref_pixel_report.append((name, k_relax, m))
+        print("ref-pixels", name, "k_relax", k_relax, m)
+        assert m["interior_pixels"] > 1000 and t["exhausted_rays"] == 0
+        assert m["gt1"] <= gt1 and m["gt2"] <= gt2, (k_relax, m)
+        assert m["frame_gt1"] <= 0.01, (k_relax, m)
+    # the 8-bit target the reference presents (VRT_FLAG_OUTPUT_RGBA8) holds exactly the quantised float frame
+    q = _abi.vrt_params.from_buffer_copy(p)
+    q.flags |= _abi.FLAG_OUTPUT_RGBA8
+    img8, _ = gpu_render(renderer, sc, q)
+    img, _ = gpu_render(renderer, sc, p)
+    assert np.array_equal(np.asarray(img8)[..., :3], ref_pixels.quantise(img))
+
+
+def test_hip_frame_without_the_hit_polish_is_what_rounds_1_to_3_rendered(renderer):
+    """VRT_FLAG_NO_HIT_POLISH: the normal where the cone threshold stopped the ray.  A quarter of the interior differs from the
+    reference's colours by more than one 8-bit step — the number this round's polish removes."""
+    from tests import ref_pixels
+
+    name = "ref_c3vox256_texel16_320x180"
+    sc, p, row0, rows = _ref_case(name)
+    q = _abi.vrt_params.from_buffer_copy(p)
+    q.flags |= _abi.FLAG_NO_HIT_POLISH
+    img, _ = gpu_render(renderer, sc, q)
+    m = ref_pixels.compare(img[row0:row0 + rows], name)
+    print("ref-pixels (no polish)", name, m)
+    assert m["gt1"] >= 0.10
+    ref, st = OracleScene(sc).render(q, threads=8)
+    assert np.abs(img - ref).max() <= TOL
+
+
 def test_reference_texel_upload_is_the_texel16_format(renderer, oracle_lib):
     """R6: vrt_volume_upload_texels takes the reference's own RGBA8 volume texture (UpdateVolumeTexture,
     RDXVoxelVolume.cpp:294-327).  Same frame, bit for bit, as the fp32 upload in VRT_FORMAT_TEXEL16 (which quantises on the

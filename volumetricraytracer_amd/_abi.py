@@ -45,6 +45,8 @@ FLAG_BLOCK_PER_FRAME = 64
 FLAG_NO_CULL_RECT = 128
 FLAG_FULL_ONE_KERNEL = 256   # full closest hit of a block of frames as ONE kernel (default: three passes)
 FLAG_FULL_THREE_PASS = 512   # ... and three passes even for a lone frame
+FLAG_NO_HIT_POLISH = 1024     # closest hits stay at the cone threshold's stop point (rounds 1-3) instead of moving on to the crossing
+HIT_POLISH_SAMPLES = 2
 MAX_BLOCK_FRAMES = 48  # frames one march launch covers with their cameras in the kernarg segment (csrc/vrt_device.h kMaxBlockFrames)
 MAX_LAUNCH_FRAMES = 256  # ... with their cameras copied to device memory ahead of the launch: vrt_block.n_frames' upper bound
 

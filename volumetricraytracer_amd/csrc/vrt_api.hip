@@ -726,7 +726,7 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_CELLS) return VRT_ERR_INVALID;
     /* (bit 5 was round 1's VRT_FLAG_SKIP_EMPTY: empty-space skipping is always on now; the bit is accepted and ignored) */
     if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_NO_TIMING | 32 | VRT_FLAG_BLOCK_PER_FRAME | VRT_FLAG_NO_CULL_RECT |
-                      VRT_FLAG_FULL_ONE_KERNEL | VRT_FLAG_FULL_THREE_PASS)) != 0 || (p->flags & 3) == 3 ||
+                      VRT_FLAG_FULL_ONE_KERNEL | VRT_FLAG_FULL_THREE_PASS | VRT_FLAG_NO_HIT_POLISH)) != 0 || (p->flags & 3) == 3 ||
         ((p->flags & VRT_FLAG_FULL_ONE_KERNEL) && (p->flags & VRT_FLAG_FULL_THREE_PASS)))
         return VRT_ERR_INVALID;
     if (!ctx->have_scene) return VRT_ERR_NOT_READY;
@@ -897,6 +897,7 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.tile_map = p->flags & 3;
     F.diag = (p->flags & VRT_FLAG_DIAG_TIMELINE) ? 1 : 0;
     F.rgba8 = (p->flags & VRT_FLAG_OUTPUT_RGBA8) ? 1 : 0;
+    F.polish = (p->flags & VRT_FLAG_NO_HIT_POLISH) ? 0 : VRT_HIT_POLISH_SAMPLES;
     F.strip_rows = rs.strip_rows;
     F.strip_first = rs.strip_first;
     F.strip_stride = rs.strip_stride;

@@ -179,7 +179,8 @@ struct DFrame {
     const DSpotLight* spot;
     const uint8_t* env;        /* 6 x S x S RGBA8 or null */
     int32_t env_size;
-    int32_t pad_;
+    int32_t polish;            /* samples a closest hit spends moving from the cone threshold's stop point on to the zero crossing
+                                  (VRT_HIT_POLISH_SAMPLES; 0 with VRT_FLAG_NO_HIT_POLISH) */
     float* out;                /* frame 0: rows x width float4 (or uint32 R8G8B8A8 when rgba8); frame f at out + f * frame_stride bytes */
     unsigned* stats;           /* one 8-word record per wave (4 per workgroup): primary_rays, shadow_rays,
                                   bounce_rays, primary_steps, shadow_steps, hits, exhausted_rays, 0; frame f at stats + f * stats_stride words */

@@ -490,6 +490,36 @@ __device__ __forceinline__ float refine_hit(const VolRef& V, const RaySeg& R, fl
     return tm;
 }
 
+/*
+ * Hit polish.  The cone threshold stops a ray up to a few pixel footprints in FRONT of the surface; the
+ * reference reports the zero crossing itself and takes its normal there (Voxel.hlsli:691-804).  The hit decision stands; a
+ * closest hit's position moves on to the crossing by the secant rule: first estimate from the march's own last two samples
+ * (when the previous one is a real, unclamped sample), else one sphere step; n samples, each followed by the secant through
+ * the last two points (equal samples: converged, stay); never behind the stop point, never more than 8 thresholds ahead,
+ * never beyond the interval.  Restated operation by operation in the oracle's march_instance.
+ */
+template <int PATH>
+__device__ __forceinline__ float polish_hit(const DFrame& F, const VolRef& V, const RaySeg& R, float t, float s, float t_prev,
+                                            float s_prev, int n, Cell& c, unsigned& steps) {
+    const float t_far = t + 8.0f * __builtin_fmaf(t, F.cone_eps, F.eps_hit);
+    float ta = t, sa = s;
+    float tb = (s_prev > s && s_prev < R.smax) ? t + (s * (t - t_prev)) / (s_prev - s) : t + s;
+    tb = vmin(vmax(tb, t), t_far);
+#pragma unroll 1
+    for (int r = 0; r < n; r++) {
+        const Cell cb = cell_at(R, tb);
+        const float sb = trilinear<PATH>(V, cb.cx, cb.cy, cb.cz, cb.fx, cb.fy, cb.fz) * R.ds;
+        steps++;
+        const float tm = sa != sb ? vmin(vmax(__builtin_fmaf(tb - ta, sb / (sa - sb), tb), t), t_far) : tb;
+        ta = tb;
+        sa = sb;
+        tb = tm;
+    }
+    if (!(tb <= R.t_end)) return t;
+    c = cell_at(R, tb);
+    return tb;
+}
+
 /* World-space normal at a hit found in cell c after `iter` march iterations.  Taps always come from
  * global memory here (once per hit, 24 independent loads in flight). */
 template <int PATH, bool EXACT = false>
@@ -788,6 +818,7 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     float t = st.t;
     Cell c = st.c;
     if (st.s_hit < 0.0f && st.i > 0) t = refine_hit<DP>(V, R, st.t_prev, st.s_prev, t, st.s_hit, c, steps);
+    else if (NORMAL != 0 && F.polish > 0 && st.i > 0) t = polish_hit<DP>(F, V, R, t, st.s_hit, st.t_prev, st.s_prev, F.polish, c, steps);
     t_hit = t;
     if constexpr (NORMAL == 1) n_world = hit_normal<DP, false>(I, V, R, c, st.i);
     if constexpr (NORMAL == 2) n_world = hit_normal<DP, true>(I, V, R, c, st.i);
@@ -1911,6 +1942,7 @@ __device__ __forceinline__ void march_tail_lds(const DFrame& F, const VolRef& V,
  * lane with taps from the bricks in global memory (most rays finish here).  Phase 2 (only if some
  * lane is still marching): the LDS tail above.  Returns true on hit with t / cell / iteration.
  */
+template <bool CLOSEST>
 __device__ __forceinline__ bool march_hybrid(const DFrame& F, const VolRef& V, const RaySeg& R, bool act, float* slots,
                                              unsigned* tags, int lane, float& t_hit, Cell& c_hit, int& iter_hit, unsigned& steps, unsigned& ex) {
     MarchState st;
@@ -1932,6 +1964,7 @@ __device__ __forceinline__ bool march_hybrid(const DFrame& F, const VolRef& V, c
     float t = st.t;
     Cell c = st.c;
     if (st.s_hit < 0.0f && st.i > 0) t = refine_hit<VRT_PATH_BRICK>(V, R, st.t_prev, st.s_prev, t, st.s_hit, c, steps);
+    else if (CLOSEST && F.polish > 0 && st.i > 0) t = polish_hit<VRT_PATH_BRICK>(F, V, R, t, st.s_hit, st.t_prev, st.s_prev, F.polish, c, steps);
     t_hit = t;
     c_hit = c;
     iter_hit = st.i;
@@ -1986,7 +2019,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DBlock 
     float t_hit = 0.0f;
     Cell c_hit = {0, 0, 0, 0.0f, 0.0f, 0.0f};
     int iter_hit = 0;
-    const bool hit = march_hybrid(F, V, R, act, slots, tags, lane, t_hit, c_hit, iter_hit, k.s_primary, k.n_hits);
+    const bool hit = march_hybrid<true>(F, V, R, act, slots, tags, lane, t_hit, c_hit, iter_hit, k.s_primary, k.n_hits);
 
     F3 n = f3(0.0f, 0.0f, 0.0f);
     if (hit) {
@@ -2006,7 +2039,7 @@ __global__ __launch_bounds__(kBlockThreads) void march_kernel_coop(const DBlock 
         float ts = 0.0f;
         Cell cs = {0, 0, 0, 0.0f, 0.0f, 0.0f};
         int is = 0;
-        shadowed = march_hybrid(F, V, Rs, act_s, slots, tags, lane, ts, cs, is, k.s_shadow, k.n_hits);
+        shadowed = march_hybrid<false>(F, V, Rs, act_s, slots, tags, lane, ts, cs, is, k.s_shadow, k.n_hits);
     }
     if (valid) {
         F3 color = hit ? shade_hit(F, Vd, d, n, shadowed) : env_lookup(F.env, F.env_size, d);
