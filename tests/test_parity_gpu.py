@@ -1198,7 +1198,7 @@ def test_render_block_is_n_frames_in_flight_with_one_call(renderer, oracle_lib):
     # parameters no launch accepts: a budget beyond the counters' range, a non-positive or NaN relaxation factor, no minimum step
     both_forms = _abi.FLAG_FULL_ONE_KERNEL | _abi.FLAG_FULL_THREE_PASS  # one kernel AND passes: contradictory
     for field, value in (("max_steps", 65536), ("k_relax", 0.0), ("k_relax", float("nan")), ("step_min", 0.0), ("eps_hit", float("nan")),
-                         ("flags", both_forms), ("flags", 1024)):
+                         ("flags", both_forms), ("flags", 1 << 20)):
         q2 = _abi.vrt_params.from_buffer_copy(p)
         setattr(q2, field, value)
         assert lib.vrt_render_rows(renderer._ctx, C.byref(q2), 0, H, C.c_void_p(block.data_ptr()), None) == _abi.VRT_ERR_INVALID, field
