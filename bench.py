@@ -757,6 +757,56 @@ def main() -> None:
         r.SetSceneToRender(sc)
         r.SyncWithScene()
 
+    dynamic_leg = None
+    if not args.no_extra_legs and args.steps > 0 and world == 1 and args.workload == "c3":
+        # Per-frame scene state (vrt_block::scenes): BASELINE config 5's 8 instances ALL moving from frame to frame — the reference moves
+        # objects every frame and rebuilds its TLAS every frame (RendererEngineInstance.cpp:111-130, DXRenderer.cpp:809-825) — still
+        # ONE march launch per batch (instances, BVH, lights, cull rectangle packed per frame on the host, one copy ahead of the
+        # launch), next to the same batch over the standing scene (frame B/2's) with only the camera moving.
+        def run_dynamic(_):
+            sc5 = workloads.config5_instances(7, 256)
+            for vol in sc5.volumes():
+                vol.set_device_format(fmt)
+            r.SetSceneToRender(sc5)
+            r.SyncWithScene()
+            frames5 = workloads.moving_instances(sc5, B)
+            arr5 = r.scene_array(frames5)
+            still = r.scene_array([frames5[B // 2]])
+            cams5 = r.camera_array(workloads.orbit_cameras(sc5, B))
+            p5 = v.default_params(W, H, workloads.min_cell(sc5), max_steps, shadow=shadow, path=path)
+            buf = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev)
+            fb = H * W * 16
+            out5 = {"scene": "config 5 (8 instanced 128^3 volumes + skybox, BVH), 1920x1080", "frames_per_launch": B, "unit": "Mrays/s"}
+            sd = max(min(args.steps, 10), 1)
+            lib = _abi.load()
+            for name in ("static_scene", "per_frame_scenes"):
+                dyn = name == "per_frame_scenes"
+                if not dyn:
+                    _abi.check(lib.vrt_scene_set(r._ctx, still), "vrt_scene_set")
+                rays = 0.0
+                for f in range(B):  # counters of the batch, frame by frame (untimed)
+                    r.render_block(p5, 1, buf.data_ptr(), fb, 0, **({"scenes": (arr5, f)} if dyn else {"cameras": (cams5, f)}))
+                    torch.cuda.synchronize()
+                    tt = r.last_timing()
+                    rays += tt["primary_rays"] + tt["shadow_rays"]
+                kw5 = {"scenes": (arr5, 0)} if dyn else {"cameras": (cams5, 0)}
+                for _ in range(2):
+                    r.render_block(p5, B, buf.data_ptr(), fb, 0, **kw5)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(sd):
+                    r.render_block(p5, B, buf.data_ptr(), fb, 0, **kw5)
+                torch.cuda.synchronize()
+                e5 = time.perf_counter() - t0
+                out5[name] = {"ms_per_frame": round(e5 / (sd * B) * 1e3, 4), "value": round(rays * sd / e5 / 1e6, 2),
+                              "launches_per_batch": len([1 for _, fr in r.launch_history(1) if fr == B])}
+            out5["per_frame_over_static"] = round(out5["per_frame_scenes"]["value"] / out5["static_scene"]["value"], 3)
+            return out5
+
+        dynamic_leg = leg(lambda: None, run_dynamic)
+        r.SetSceneToRender(sc)
+        r.SyncWithScene()
+
     if rank == 0:
         alg_bytes = v.algorithmic_bytes(t, 4 if rgba8 else 16) * fpl  # of ONE launch: fpl frames
         k_ms = float(np.mean(kms)) if kms else float("nan")
@@ -831,7 +881,7 @@ def main() -> None:
                        "samples_per_ray": round((psteps + ssteps) / max(rays_per_step, 1), 2)},
             "roofline": roofline, "cpu_baseline": cpu,
             "latency": latency, "scale_anchor": scale_anchor, "end_to_end": end_to_end, "config4": config4, "reference_texel_format": texel_leg, "full_closest_hit": full_leg,
-            "no_cull_rect": no_cull,
+            "no_cull_rect": no_cull, "dynamic_scene": dynamic_leg,
         }
         if world > 1:
             out["speedup_vs_anchor"] = round(value / scale_anchor["value"], 3) if scale_anchor and scale_anchor.get("value") else None

@@ -322,13 +322,21 @@ typedef struct vrt_camera {
 
 /* What vrt_render_block renders: n_frames frames of the current scene, frame f from cameras[f] (NULL: the scene's own
  * camera for every frame) into device_rgba + f*frame_stride_bytes.  Rows of every frame: strip_rows > 0 -> the strips of
- * vrt_render_strips (first_strip, strip_stride, n_strips); strip_rows == 0 -> rows [row0, row0+rows) like vrt_render_rows. */
+ * vrt_render_strips (first_strip, strip_stride, n_strips); strip_rows == 0 -> rows [row0, row0+rows) like vrt_render_rows.
+ * scenes != NULL: a block of frames of a scene that CHANGES from frame to frame — frame f is rendered exactly as
+ * vrt_scene_set(&scenes[f]) followed by a one-frame launch would render it (camera, directional / point / spot lights, placed
+ * objects: the reference moves objects every frame and rebuilds its TLAS every frame, RendererEngineInstance.cpp:111-130,
+ * DXRenderer.cpp:809-825, RDXScene.cpp:454-545) — still with ONE march launch for the block: per frame the host packs the
+ * instances, builds the instance BVH and the cull rectangle, and the records travel to the device ahead of the launch on its
+ * stream (<= 12 KB per frame).  cameras must then be NULL (every scene carries its camera); the scene set by vrt_scene_set is
+ * neither used nor changed.  Volumes, materials, textures and the sky box are the resident ones, the same for every frame. */
 typedef struct vrt_block {
     int32_t n_frames;                 /* 1 .. 256 */
     int32_t strip_rows, first_strip, strip_stride, n_strips;
     int32_t row0, rows;
     const vrt_camera* cameras;        /* n_frames cameras, or NULL */
     uint64_t frame_stride_bytes;      /* >= the bytes of one frame's rows, a multiple of the pixel size (16, or 4 with VRT_FLAG_OUTPUT_RGBA8) */
+    const vrt_scene* scenes;          /* n_frames scenes (per-frame scene state), or NULL: the scene of vrt_scene_set for every frame */
 } vrt_block;
 
 /* n_frames frames with ONE call and ONE march launch (the kernel's grid has a frame axis; up to 48 frames the cameras travel in

@@ -46,10 +46,10 @@ def test_ctypes_layout_matches_c(tmp_path):
     prog = tmp_path / "sz.c"
     prog.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "vrt.h"\n'
-        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(vrt_voxel), sizeof(vrt_material),"
+        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(vrt_voxel), sizeof(vrt_material),"
         " sizeof(vrt_instance), sizeof(vrt_point_light), sizeof(vrt_spot_light), sizeof(vrt_scene), sizeof(vrt_params),"
         " sizeof(vrt_timing), offsetof(vrt_scene, instances), offsetof(vrt_scene, point_lights), offsetof(vrt_timing, primary_rays), sizeof(vrt_camera), sizeof(vrt_block),"
-        " offsetof(vrt_block, cameras), offsetof(vrt_block, frame_stride_bytes));return 0;}\n"
+        " offsetof(vrt_block, cameras), offsetof(vrt_block, frame_stride_bytes), offsetof(vrt_block, scenes));return 0;}\n"
     )
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
@@ -58,7 +58,7 @@ def test_ctypes_layout_matches_c(tmp_path):
             C.sizeof(_abi.vrt_point_light), C.sizeof(_abi.vrt_spot_light), C.sizeof(_abi.vrt_scene),
             C.sizeof(_abi.vrt_params), C.sizeof(_abi.vrt_timing), _abi.vrt_scene.instances.offset,
             _abi.vrt_scene.point_lights.offset, _abi.vrt_timing.primary_rays.offset, C.sizeof(_abi.vrt_camera),
-            C.sizeof(_abi.vrt_block), _abi.vrt_block.cameras.offset, _abi.vrt_block.frame_stride_bytes.offset]
+            C.sizeof(_abi.vrt_block), _abi.vrt_block.cameras.offset, _abi.vrt_block.frame_stride_bytes.offset, _abi.vrt_block.scenes.offset]
     assert got == want
     assert C.sizeof(_abi.vrt_voxel) == 8  # VVoxel, Voxel.h:23-30
 

@@ -170,6 +170,7 @@ class vrt_block(C.Structure):
         ("rows", C.c_int32),
         ("cameras", C.POINTER(vrt_camera)),
         ("frame_stride_bytes", C.c_uint64),
+        ("scenes", C.POINTER(vrt_scene)),
     ]
 
 

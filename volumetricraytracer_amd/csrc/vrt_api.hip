@@ -141,6 +141,7 @@ struct FrameSlot {
     int ring = 0;       /* event-ring slot of the launch (timing) */
 };
 
+constexpr size_t kStatsBytesMax = (size_t)512 << 20; /* per-wave counters of one launch (1080p: 1.1 MB per frame, 3840x2160: 4.2 MB) */
 constexpr size_t kPassBytesMax = (size_t)4 << 30; /* hit records of one launch of the full closest hit in passes (1080p: 42 MB per frame) */
 
 struct DeviceState {
@@ -174,6 +175,10 @@ struct DeviceState {
     DCam* d_cams[kStatSlots] = {};
     DCam* h_cams[kStatSlots] = {};
     hipEvent_t cams_copied[kStatSlots] = {};
+    /* launches over per-frame scene state (vrt_block::scenes): the frames' sections (DDyn + instances + BVH + lights, kDynStride bytes
+       each), packed into pinned host memory and copied ahead of the launch together with the camera records */
+    char* d_dyn[kStatSlots] = {};
+    char* h_dyn[kStatSlots] = {};
     void* d_pass[kStatSlots] = {};
     size_t pass_cap[kStatSlots] = {}; /* records */
     std::vector<void*> pass_retired;
@@ -548,6 +553,8 @@ void destroy_device(DeviceState& D) {
     for (int i = 0; i < kStatSlots; i++) {
         if (D.d_cams[i]) (void)hipFree(D.d_cams[i]);
         if (D.h_cams[i]) (void)hipHostFree(D.h_cams[i]);
+        if (D.d_dyn[i]) (void)hipFree(D.d_dyn[i]);
+        if (D.h_dyn[i]) (void)hipHostFree(D.h_dyn[i]);
         if (D.cams_copied[i]) (void)hipEventDestroy(D.cams_copied[i]);
     }
     for (int i = 0; i < kStatSlots; i++)
@@ -664,24 +671,27 @@ int upload_volume(vrt_ctx* ctx, int slot, uint8_t resolution, float extent, cons
     return sync_volume_table(ctx);
 }
 
-int pack_scene(vrt_ctx* ctx) {
-    const vrt_scene& s = ctx->scene;
+/* A scene's small arrays as the kernels read them: instances (with the directional light's shadow-ray constants), the threaded
+   instance BVH, point and spot lights.  What VRDXScene::PrepareForRendering re-sends every frame (RDXScene.cpp:150-174, 454-545,
+   726-755). */
+void pack_scene_arrays(const vrt_ctx* ctx, const vrt_scene& s, DInstance* inst, DBvhNode* nodes, int& n_nodes, DPointLight* point,
+                       DSpotLight* spot) {
     std::vector<Box> boxes((size_t)s.n_instances);
     for (int i = 0; i < s.n_instances; i++) {
-        pack_instance(s.instances[i], ctx->inst[i]);
-        pack_shadow_ray(s.light_dir, ctx->inst[i]);
-        boxes[(size_t)i] = instance_box(ctx->inst[i], ctx->vol[s.instances[i].volume_slot].extent);
+        pack_instance(s.instances[i], inst[i]);
+        pack_shadow_ray(s.light_dir, inst[i]);
+        boxes[(size_t)i] = instance_box(inst[i], ctx->vol[s.instances[i].volume_slot].extent);
     }
-    ctx->n_nodes = 0;
+    n_nodes = 0;
     if (s.n_instances > 0) {
         std::vector<int> ids((size_t)s.n_instances);
         for (int i = 0; i < s.n_instances; i++) ids[(size_t)i] = i;
-        build_bvh(ids, 0, s.n_instances, boxes, ctx->nodes, ctx->n_nodes);
+        build_bvh(ids, 0, s.n_instances, boxes, nodes, n_nodes);
     }
     const int npl = std::min(s.n_point_lights, VRT_MAX_POINT_LIGHTS);
     for (int i = 0; i < npl; i++) {
         const vrt_point_light& L = s.point_lights[i];
-        DPointLight& o = ctx->point[i];
+        DPointLight& o = point[i];
         memset(&o, 0, sizeof o);
         memcpy(o.pos, L.position, sizeof o.pos);
         memcpy(o.color, L.color, sizeof o.color);
@@ -692,7 +702,7 @@ int pack_scene(vrt_ctx* ctx) {
     const int nsl = std::min(s.n_spot_lights, VRT_MAX_SPOT_LIGHTS);
     for (int i = 0; i < nsl; i++) {
         const vrt_spot_light& L = s.spot_lights[i];
-        DSpotLight& o = ctx->spot[i];
+        DSpotLight& o = spot[i];
         memset(&o, 0, sizeof o);
         memcpy(o.pos, L.position, sizeof o.pos);
         memcpy(o.fwd, L.forward, sizeof o.fwd);
@@ -703,6 +713,13 @@ int pack_scene(vrt_ctx* ctx) {
         o.cos_angle = L.cos_angle;
         o.cos_falloff = L.cos_falloff_angle;
     }
+}
+
+int pack_scene(vrt_ctx* ctx) {
+    const vrt_scene& s = ctx->scene;
+    pack_scene_arrays(ctx, s, ctx->inst, ctx->nodes, ctx->n_nodes, ctx->point, ctx->spot);
+    const int npl = std::min(s.n_point_lights, VRT_MAX_POINT_LIGHTS);
+    const int nsl = std::min(s.n_spot_lights, VRT_MAX_SPOT_LIGHTS);
     for (auto& D : ctx->dev) {
         HIP_TRY(hipSetDevice(D.ordinal));
         if (s.n_instances > 0) {
@@ -715,7 +732,20 @@ int pack_scene(vrt_ctx* ctx) {
     return VRT_OK;
 }
 
-int check_params(const vrt_ctx* ctx, const vrt_params* p) {
+/* What vrt_scene_set refuses (and vrt_render_block, per frame of vrt_block::scenes). */
+int validate_scene(const vrt_ctx* ctx, const vrt_scene* scene) {
+    if (!scene) return VRT_ERR_INVALID;
+    if (scene->n_instances < 0 || scene->n_instances > VRT_MAX_INSTANCES) return VRT_ERR_INVALID;
+    if (scene->n_point_lights < 0 || scene->n_spot_lights < 0) return VRT_ERR_INVALID;
+    for (int i = 0; i < scene->n_instances; i++) {
+        const vrt_instance& I = scene->instances[i];
+        if (I.volume_slot < 0 || I.volume_slot >= VRT_MAX_VOLUMES || !ctx->vol[I.volume_slot].used) return VRT_ERR_SLOT;
+        if (I.scale[0] == 0.0f || I.scale[1] == 0.0f || I.scale[2] == 0.0f) return VRT_ERR_INVALID;
+    }
+    return VRT_OK;
+}
+
+int check_params(const vrt_ctx* ctx, const vrt_params* p, bool own_scenes = false) {
     if (!ctx || !p) return VRT_ERR_INVALID;
     if (p->width <= 0 || p->height <= 0 || p->width > 16384 || p->height > 16384) return VRT_ERR_INVALID;
     if (p->max_steps < 0 || p->max_steps > 65535 || p->max_bounces < 0 || p->max_bounces > 2) return VRT_ERR_INVALID;
@@ -729,7 +759,7 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
                       VRT_FLAG_FULL_ONE_KERNEL | VRT_FLAG_FULL_THREE_PASS | VRT_FLAG_NO_HIT_POLISH)) != 0 || (p->flags & 3) == 3 ||
         ((p->flags & VRT_FLAG_FULL_ONE_KERNEL) && (p->flags & VRT_FLAG_FULL_THREE_PASS)))
         return VRT_ERR_INVALID;
-    if (!ctx->have_scene) return VRT_ERR_NOT_READY;
+    if (!ctx->have_scene && !own_scenes) return VRT_ERR_NOT_READY;
     return VRT_OK;
 }
 
@@ -737,10 +767,15 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p) {
  * when every instanced volume is VRT_FORMAT_TEXEL16; a scene that mixes the two marches the dense grids (which hold the
  * same values in either format).  The LDS brick cache is wave-cooperative and covers single-instance fp32 scenes.  Returns
  * a negative status for the one combination without a kernel: a Cube mode over mixed formats. */
-int resolve_path(const vrt_ctx* ctx, int path, bool single, int mode) {
+int resolve_path(const vrt_ctx* ctx, int path, bool single, int mode, const vrt_scene* scenes = nullptr, int n_scenes = 0) {
     int n16 = 0, n32 = 0;
-    for (int i = 0; i < ctx->scene.n_instances; i++)
-        (ctx->vol[ctx->scene.instances[i].volume_slot].format == VRT_FORMAT_TEXEL16 ? n16 : n32)++;
+    if (!scenes) {
+        scenes = &ctx->scene;
+        n_scenes = 1;
+    }
+    for (int f = 0; f < n_scenes; f++)
+        for (int i = 0; i < scenes[f].n_instances; i++)
+            (ctx->vol[scenes[f].instances[i].volume_slot].format == VRT_FORMAT_TEXEL16 ? n16 : n32)++;
     const bool mixed = n16 > 0 && n32 > 0, all16 = n16 > 0 && n32 == 0;
     if (mode >= VRT_MODE_CUBE) { /* exact grid traversal over the bricks, whatever path was asked for */
         if (mixed) return VRT_ERR_UNSUPPORTED;
@@ -761,15 +796,19 @@ struct RowSet {
 /* Screen rectangle of everything a primary ray can reach (DFrame::cull_*): the corners of every instance's active box
    (object space -> world -> camera -> pixel), double precision, two pixels of margin.  Any corner at or behind the camera
    plane: the whole frame. */
-void cull_rect(const vrt_ctx* ctx, const vrt_params* p, DCam& F) {
+void cull_rect(const vrt_ctx* ctx, const vrt_params* p, DCam& F, const vrt_scene* scene = nullptr, const DInstance* inst = nullptr) {
+    if (!scene) {
+        scene = &ctx->scene;
+        inst = ctx->inst;
+    }
     /* (frames are at most 16384 pixels wide and high: 16 bits per coordinate) */
     F.cull_lo = pack_cull(0, 0);
     F.cull_hi = pack_cull(p->width - 1, p->height - 1);
     if (p->flags & VRT_FLAG_NO_CULL_RECT) return;
     double x0 = 1e30, y0 = 1e30, x1 = -1e30, y1 = -1e30;
-    for (int i = 0; i < ctx->scene.n_instances; i++) {
-        const HostVolume& h = ctx->vol[ctx->scene.instances[i].volume_slot];
-        const DInstance& I = ctx->inst[i];
+    for (int i = 0; i < scene->n_instances; i++) {
+        const HostVolume& h = ctx->vol[scene->instances[i].volume_slot];
+        const DInstance& I = inst[i];
         double lo[3], hi[3];
         const double cell = ((double)h.extent * 2.0) / (double)(h.N - 1);
         /* The kernel clips a ray to the active box only when its whole interval ends before t_skip_end = (smax/2 - eps_hit) /
@@ -777,7 +816,7 @@ void cull_rect(const vrt_ctx* ctx, const vrt_params* p, DCam& F) {
            only if that holds for EVERY primary ray: the farthest corner of the volume box is nearer than the smallest t_skip_end */
         bool clip_everywhere = true;
         if (h.step_max > 0.0f) {
-            const vrt_instance& in = ctx->scene.instances[i];
+            const vrt_instance& in = scene->instances[i];
             const double min_scale = std::min(std::min(fabs((double)in.scale[0]), fabs((double)in.scale[1])), fabs((double)in.scale[2]));
             const double smax_min = (double)h.step_max * min_scale;
             double far2 = 0.0;
@@ -841,31 +880,44 @@ void cull_rect(const vrt_ctx* ctx, const vrt_params* p, DCam& F) {
 struct ClosestHitForm {
     bool textured, full, may_bounce;
 };
-ClosestHitForm closest_hit_form(const vrt_ctx* ctx, const vrt_params* p) {
+ClosestHitForm form_of_scene(const vrt_ctx* ctx, const vrt_params* p, const vrt_scene& sc) {
     /* the lean kernel covers directional light + shadow; the full closest hit is only launched when the
        frame can need it: extra lights, or bounces allowed and some instanced material mirrors (roughness < 0.3) */
     bool smooth = false;
-    for (int i = 0; i < ctx->scene.n_instances; i++) {
-        const HostVolume& hv = ctx->vol[ctx->scene.instances[i].volume_slot];
+    for (int i = 0; i < sc.n_instances; i++) {
+        const HostVolume& hv = ctx->vol[sc.instances[i].volume_slot];
         smooth = smooth || std::min(std::max(hv.mat.roughness, 0.0f), 1.0f) < 0.3f;
     }
     /* textured modes read the material textures; a frame needs that code only when a bound texture is in sight */
     const bool tex_mode = p->mode == VRT_MODE_INTERP || p->mode == VRT_MODE_INTERP_UNLIT || p->mode == VRT_MODE_CUBE ||
                           p->mode == VRT_MODE_CUBE_UNLIT;
     bool textured = false;
-    for (int i = 0; tex_mode && i < ctx->scene.n_instances; i++) {
-        const HostVolume& hv = ctx->vol[ctx->scene.instances[i].volume_slot];
+    for (int i = 0; tex_mode && i < sc.n_instances; i++) {
+        const HostVolume& hv = ctx->vol[sc.instances[i].volume_slot];
         for (int k = 0; k < 3; k++) textured = textured || (hv.tex[k] >= 0 && ctx->tex[hv.tex[k]].used);
     }
     ClosestHitForm f;
     f.textured = textured;
-    f.full = ctx->scene.n_point_lights > 0 || ctx->scene.n_spot_lights > 0 || (p->max_bounces > 0 && smooth) || textured;
+    f.full = sc.n_point_lights > 0 || sc.n_spot_lights > 0 || (p->max_bounces > 0 && smooth) || textured;
     f.may_bounce = p->max_bounces > 0 && (smooth || textured); /* (a roughness texture can make any material mirror) */
     return f;
 }
+/* ... of a launch: the scene of vrt_scene_set, or — a block over per-frame scenes (vrt_block::scenes) — the union of what its frames
+   need (the full closest hit renders a frame without extra lights like the lean kernel does: same pixels, same counters). */
+ClosestHitForm closest_hit_form(const vrt_ctx* ctx, const vrt_params* p, const vrt_scene* scenes = nullptr, int n_scenes = 0) {
+    if (!scenes) return form_of_scene(ctx, p, ctx->scene);
+    ClosestHitForm u = {false, false, false};
+    for (int f = 0; f < n_scenes; f++) {
+        const ClosestHitForm x = form_of_scene(ctx, p, scenes[f]);
+        u.textured = u.textured || x.textured;
+        u.full = u.full || x.full;
+        u.may_bounce = u.may_bounce || x.may_bounce;
+    }
+    return u;
+}
 
 void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, const RowSet& rs, float* out,
-                 unsigned* stats, DFrame& F, const SceneArrays* snapshot = nullptr) {
+                 unsigned* stats, DFrame& F, const SceneArrays* snapshot = nullptr, const vrt_scene* scenes = nullptr, int n_scenes = 0) {
     const int row0 = rs.row0, rows = rs.rows;
     memset(&F, 0, sizeof F);
     F.inv_w = 1.0f / (float)p->width;
@@ -901,7 +953,7 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.strip_rows = rs.strip_rows;
     F.strip_first = rs.strip_first;
     F.strip_stride = rs.strip_stride;
-    const ClosestHitForm form = closest_hit_form(ctx, p);
+    const ClosestHitForm form = closest_hit_form(ctx, p, scenes, n_scenes);
     F.textured = form.textured ? 1 : 0;
     F.full = form.full ? 1 : 0;
     F.may_bounce = form.may_bounce ? 1 : 0;
@@ -924,16 +976,24 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
 /* Enqueue n_frames frames of one tile on one device as ONE launch (grid.y = frame): frame f from cams[f] (null: the scene's own
    camera) into out + f * frame_stride bytes.  No allocation after the stream's first launch of that size, no host sync. */
 int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet& rs, float* out, hipStream_t stream,
-                 int ring, const SceneArrays* snapshot = nullptr, int n_frames = 1, const vrt_camera* cams = nullptr, size_t frame_stride = 0) {
+                 int ring, const SceneArrays* snapshot = nullptr, int n_frames = 1, const vrt_camera* cams = nullptr, size_t frame_stride = 0,
+                 const vrt_scene* scenes = nullptr) {
     if (n_frames < 1 || n_frames > kMaxLaunchFrames) return VRT_ERR_INVALID;
-    const bool device_cams = n_frames > kMaxBlockFrames; /* more cameras than the kernarg segment holds */
+    /* more cameras than the kernarg segment holds, or per-frame scene state (its records live in device memory, the cameras with them) */
+    const bool device_cams = n_frames > kMaxBlockFrames || scenes != nullptr;
     DBlock B;
     memset(B.cam, 0, sizeof B.cam); /* (the whole struct travels as the kernarg: no stale stack bytes behind the block's frames) */
     DFrame& F = B.f;
-    build_frame(ctx, D, p, rs, out, nullptr, F, snapshot);
+    build_frame(ctx, D, p, rs, out, nullptr, F, snapshot, scenes, n_frames);
     if ((long long)F.tiles_x * F.tiles_y > kMaxBlocks / 2) return VRT_ERR_INVALID;
-    const bool single = ctx->scene.n_instances == 1;
-    const int path = resolve_path(ctx, p->path, single, p->mode);
+    bool single = ctx->scene.n_instances == 1;
+    if (scenes) { /* one kernel form for the launch: the single-instance one only when every frame has exactly one instance */
+        if (snapshot || (p->flags & VRT_FLAG_DIAG_TIMELINE)) return VRT_ERR_INVALID;
+        single = true;
+        for (int f = 0; f < n_frames; f++) single = single && scenes[f].n_instances == 1;
+        F.vol0 = nullptr;
+    }
+    const int path = resolve_path(ctx, p->path, single, p->mode, scenes, n_frames);
     if (path < 0) return path;
     D.last_blocks = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if ((long long)D.last_blocks * n_frames > 8LL * kMaxBlocks) return VRT_ERR_INVALID;
@@ -989,11 +1049,39 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
         } else {
             HIP_TRY(hipEventSynchronize(D.cams_copied[slot])); /* the previous launch's copy has read the pinned records (long ago, normally) */
         }
+        if (scenes && !D.d_dyn[slot]) {
+            HIP_TRY(hipMalloc(&D.d_dyn[slot], (size_t)kDynStride * kMaxLaunchFrames));
+            HIP_TRY(hipHostMalloc(&D.h_dyn[slot], (size_t)kDynStride * kMaxLaunchFrames));
+        }
         for (int f = 0; f < n_frames; f++) {
-            pack_camera(cams ? cams[f] : own, p->width, p->height, D.h_cams[slot][f]);
-            cull_rect(ctx, p, D.h_cams[slot][f]);
+            if (!scenes) {
+                pack_camera(cams ? cams[f] : own, p->width, p->height, D.h_cams[slot][f]);
+                cull_rect(ctx, p, D.h_cams[slot][f]);
+                continue;
+            }
+            /* frame f's scene as vrt_scene_set would pack it (instances, BVH rebuilt per frame like the reference's TLAS,
+               DXRenderer.cpp:809-825; lights), its camera and its own cull rectangle */
+            const vrt_scene& sc = scenes[f];
+            char* sec = D.h_dyn[slot] + (size_t)f * kDynStride;
+            DDyn* rec = reinterpret_cast<DDyn*>(sec);
+            DInstance* inst = reinterpret_cast<DInstance*>(sec + kDynInstOff);
+            memset(rec, 0, sizeof *rec);
+            pack_scene_arrays(ctx, sc, inst, reinterpret_cast<DBvhNode*>(sec + kDynNodesOff), rec->n_nodes,
+                              reinterpret_cast<DPointLight*>(sec + kDynPointOff), reinterpret_cast<DSpotLight*>(sec + kDynSpotOff));
+            memcpy(rec->light_dir, sc.light_dir, sizeof rec->light_dir);
+            rec->light_strength = sc.light_strength;
+            rec->n_inst = sc.n_instances;
+            rec->n_point = std::min(sc.n_point_lights, VRT_MAX_POINT_LIGHTS);
+            rec->n_spot = std::min(sc.n_spot_lights, VRT_MAX_SPOT_LIGHTS);
+            rec->vol0_slot = sc.n_instances > 0 ? sc.instances[0].volume_slot : 0;
+            pack_camera(scene_camera(sc), p->width, p->height, D.h_cams[slot][f]);
+            cull_rect(ctx, p, D.h_cams[slot][f], &sc, inst);
         }
         HIP_TRY(hipMemcpyAsync(D.d_cams[slot], D.h_cams[slot], sizeof(DCam) * (size_t)n_frames, hipMemcpyHostToDevice, stream));
+        if (scenes) {
+            HIP_TRY(hipMemcpyAsync(D.d_dyn[slot], D.h_dyn[slot], (size_t)kDynStride * (size_t)n_frames, hipMemcpyHostToDevice, stream));
+            F.dyn = D.d_dyn[slot];
+        }
         HIP_TRY(hipEventRecord(D.cams_copied[slot], stream));
         F.cams = D.d_cams[slot];
     }
@@ -1277,13 +1365,8 @@ int vrt_env_upload(vrt_ctx* ctx, int face_size, const uint8_t* rgba8_faces) {
 
 int vrt_scene_set(vrt_ctx* ctx, const vrt_scene* scene) {
     if (!ctx || !scene) return VRT_ERR_INVALID;
-    if (scene->n_instances < 0 || scene->n_instances > VRT_MAX_INSTANCES) return VRT_ERR_INVALID;
-    if (scene->n_point_lights < 0 || scene->n_spot_lights < 0) return VRT_ERR_INVALID;
-    for (int i = 0; i < scene->n_instances; i++) {
-        const vrt_instance& I = scene->instances[i];
-        if (!valid_slot(I.volume_slot) || !ctx->vol[I.volume_slot].used) return VRT_ERR_SLOT;
-        if (I.scale[0] == 0.0f || I.scale[1] == 0.0f || I.scale[2] == 0.0f) return VRT_ERR_INVALID;
-    }
+    const int bad = validate_scene(ctx, scene);
+    if (bad != VRT_OK) return bad;
     /* an adaptor re-sends the scene every frame (VRDXScene::SyncWithScene runs per frame): the same scene over the same volumes
        needs no re-packing and no copies to the device */
     if (ctx->have_scene && !ctx->scene_stale && memcmp(&ctx->scene, scene, sizeof *scene) == 0) return VRT_OK;
@@ -1344,9 +1427,16 @@ int vrt_render_strips(vrt_ctx* ctx, const vrt_params* params, int strip_rows, in
 }
 
 int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* block, void* device_rgba, void* hip_stream) {
-    int rc = check_params(ctx, params);
+    int rc = check_params(ctx, params, block && block->scenes);
     if (rc != VRT_OK) return rc;
     if (!block || block->n_frames < 1 || block->n_frames > kMaxLaunchFrames || !device_rgba) return VRT_ERR_INVALID;
+    if (block->scenes) { /* per-frame scene state: every frame's scene must be one vrt_scene_set would take */
+        if (block->cameras || (params->flags & VRT_FLAG_DIAG_TIMELINE)) return VRT_ERR_INVALID;
+        for (int f = 0; f < block->n_frames; f++) {
+            rc = validate_scene(ctx, block->scenes + f);
+            if (rc != VRT_OK) return rc;
+        }
+    }
     RowSet rs;
     if (block->strip_rows > 0) {
         if (block->strip_stride < 1 || block->first_strip < 0 || block->first_strip >= block->strip_stride || block->n_strips < 0 ||
@@ -1378,8 +1468,17 @@ int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* bl
     int chunk = (params->flags & VRT_FLAG_BLOCK_PER_FRAME) ? 1 : (capture != hipStreamCaptureStatusNone || block->n_frames <= kMaxBlockFrames) ? kMaxBlockFrames : kMaxLaunchFrames;
     {   /* the full closest hit in passes keeps 20 bytes per pixel of the launch's tiles between its passes: at most kPassBytesMax per launch */
         const size_t per_frame = (size_t)((params->width + 15) / 16) * (size_t)((rs.rows + 15) / 16) * 256 * (sizeof(HitRecord) + sizeof(unsigned));
-        if (per_frame > 0 && closest_hit_form(ctx, params).full)
+        if (per_frame > 0 && closest_hit_form(ctx, params, block->scenes, block->n_frames).full)
             chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)chunk, kPassBytesMax / per_frame));
+    }
+    {   /* a launch's grid holds at most 8 * kMaxBlocks workgroups (enqueue_rows), and its per-wave counters — 128 bytes per workgroup and
+           frame, kept per launch stream until vrt_destroy — at most kStatsBytesMax: larger blocks are cut into several launches instead of
+           being refused (3840x2160 x 256 frames fitted by 0.4 %, 4096x2304 x 256 did not) */
+        const long long blocks = grid_blocks((params->width + 15) / 16, (rs.rows + 15) / 16, params->flags & 3);
+        if (blocks > 0) {
+            chunk = (int)std::max<long long>(1, std::min<long long>(chunk, 8LL * kMaxBlocks / blocks));
+            chunk = (int)std::max<long long>(1, std::min<long long>(chunk, (long long)(kStatsBytesMax / (sizeof(unsigned) * kStatRecord * 4)) / blocks));
+        }
     }
     vrt_params q = *params;
     for (int f = 0; f < block->n_frames; f += chunk) {
@@ -1388,7 +1487,8 @@ int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* bl
         q.flags = (f == 0 || chunk > 1) ? params->flags : (params->flags | VRT_FLAG_NO_TIMING);
         const int ring = (int)(ctx->launches % kRing);
         rc = enqueue_rows(ctx, D, &q, rs, reinterpret_cast<float*>(static_cast<char*>(device_rgba) + (size_t)f * block->frame_stride_bytes), stream,
-                          ring, nullptr, n, block->cameras ? block->cameras + f : nullptr, (size_t)block->frame_stride_bytes);
+                          ring, nullptr, n, block->cameras ? block->cameras + f : nullptr, (size_t)block->frame_stride_bytes,
+                          block->scenes ? block->scenes + f : nullptr);
         if (rc != VRT_OK) return rc;
         ctx->launches++;
     }

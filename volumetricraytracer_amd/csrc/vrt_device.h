@@ -200,7 +200,27 @@ struct DFrame {
     const DCam* cams;          /* launches of more than kMaxBlockFrames frames: the frames' camera records in device memory (null: DBlock::cam) */
     uint32_t rec_stride;       /* records between the frames of a launch (= workgroups per frame * 64) */
     int32_t may_bounce;        /* 1: bounces allowed and some material can mirror (smooth, or roughness from a texture) */
+    const void* dyn;           /* per-frame scene state (vrt_block::scenes): n_frames sections of kDynStride bytes in device memory, each a
+                                  DDyn record followed by the frame's instances, BVH nodes, point and spot lights; null: every frame of the
+                                  launch renders the scene in this struct.  Read by the DYN instantiations of the march kernels only */
 };
+
+/* Per-frame scene state of a launch over a scene that changes from frame to frame — what the reference re-sends every frame: the
+ * scene constant buffer's light (RDXScene.cpp:703-724), the light buffers (:726-755) and the TLAS's instance list (:454-545,
+ * rebuilt every frame, DXRenderer.cpp:809-825).  One section per frame at dyn + frame * kDynStride: */
+struct DDyn {                  /* 64 bytes: one s_load_dwordx16 */
+    float light_dir[3];
+    float light_strength;
+    int32_t n_inst, n_nodes, n_point, n_spot;
+    int32_t vol0_slot;         /* single-instance launches: the frame's one instance's volume slot */
+    int32_t pad_[7];
+};
+constexpr uint32_t kDynInstOff = sizeof(DDyn);
+constexpr uint32_t kDynNodesOff = kDynInstOff + 64 /* VRT_MAX_INSTANCES */ * sizeof(DInstance);
+constexpr uint32_t kDynPointOff = kDynNodesOff + 128 * sizeof(DBvhNode);
+constexpr uint32_t kDynSpotOff = kDynPointOff + 5 /* VRT_MAX_POINT_LIGHTS */ * sizeof(DPointLight);
+constexpr uint32_t kDynStride = (kDynSpotOff + 5 /* VRT_MAX_SPOT_LIGHTS */ * sizeof(DSpotLight) + 63u) & ~63u;
+static_assert(sizeof(DDyn) == 64 && kDynStride % 64 == 0, "frame sections stay 64-byte aligned");
 
 /* The kernarg of a march launch: the shared part and one DCam per frame of the block.  The dispatcher walks blockIdx.x
  * first, so frame f + 1's waves back-fill the wave slots frame f's latency-bound tail leaves empty — what the reference gets from

@@ -1097,6 +1097,38 @@ __device__ __forceinline__ DCam load_cam(const DBlock& B, int frame) {
     return C;
 }
 
+/* The scene a frame of the launch renders.  Static launches: the kernarg's own (no copy).  DYN instantiations (vrt_block::scenes —
+ * objects and lights that move from frame to frame, as in the reference's demo, RendererEngineInstance.cpp:111-130): the kernarg's
+ * struct with the frame's light, counts and array pointers from its section of DFrame::dyn — one scalar load of 64 bytes at a
+ * wave-uniform address plus four pointer additions; everything stays in scalar registers. */
+template <bool DYN>
+__device__ __forceinline__ const DFrame& frame_view(const DBlock& B, int frame, DFrame& Fd) {
+    if constexpr (!DYN) {
+        (void)frame;
+        (void)Fd;
+        return B.f;
+    } else {
+        typedef unsigned u16v __attribute__((ext_vector_type(16)));
+        Fd = B.f;
+        const char* sec = static_cast<const char*>(B.f.dyn) + (size_t)(unsigned)frame * kDynStride;
+        const u16v w = *reinterpret_cast<const u16v __attribute__((address_space(4)))*>((const __attribute__((address_space(4))) char*)sec);
+        Fd.light_dir[0] = __uint_as_float(w[0]);
+        Fd.light_dir[1] = __uint_as_float(w[1]);
+        Fd.light_dir[2] = __uint_as_float(w[2]);
+        Fd.light_strength = __uint_as_float(w[3]);
+        Fd.n_inst = (int)w[4];
+        Fd.n_nodes = (int)w[5];
+        Fd.n_point = (int)w[6];
+        Fd.n_spot = (int)w[7];
+        Fd.vol0 = B.f.vols + (int)w[8];
+        Fd.inst = reinterpret_cast<const DInstance*>(sec + kDynInstOff);
+        Fd.nodes = reinterpret_cast<const DBvhNode*>(sec + kDynNodesOff);
+        Fd.point = reinterpret_cast<const DPointLight*>(sec + kDynPointOff);
+        Fd.spot = reinterpret_cast<const DSpotLight*>(sec + kDynSpotOff);
+        return Fd;
+    }
+}
+
 /* Camera ray of pixel (px,py) (Ray.hlsli:36-48, then normalised). */
 __device__ __forceinline__ void camera_ray(const DFrame& F, const DCam& C, int px, int py, F3& o, F3& d) {
     float sx = (((float)px + 0.5f) * F.inv_w) * 2.0f - 1.0f; /* 1/width, 1/height from the host (oracle: the same two products) */
@@ -1250,7 +1282,7 @@ __device__ __forceinline__ int frame_row(const DFrame& F, int pyl) {
  * waves end at once.  Letting three out of four sky waves end at once changes nothing (41.1 against 41.0 us per frame: the sky
  * waves only fill wave slots the marching waves leave empty), and the four-pixel sky wave made the frame 20 % slower:
  * profiles/r03_sky_tile_and_occupancy_experiments.txt.) */
-template <int PATH, bool SINGLE, bool DIAG>
+template <int PATH, bool SINGLE, bool DIAG, bool DYN = false>
 /* The multi-instance (BVH) instantiations on brick / cell-record paths are asked to fit 7 waves per SIMD (72 VGPRs instead of the 78 the
  * register allocator settles for; 3 registers and 10 scalars spilled outside the march loop): config 5 68.6 -> 70.9 Grays/s.  The
  * single-instance ones sit at the hardware's 8 waves per SIMD anyway. */
@@ -1260,8 +1292,9 @@ template <int PATH, bool SINGLE, bool DIAG>
 __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu((!SINGLE && !DIAG && PATH != VRT_PATH_DENSE) ? VRT_BVH_WAVES : 1))) void march_kernel(const DBlock B) {
     unsigned long long t_start = 0;
     if constexpr (DIAG) t_start = __builtin_amdgcn_s_memrealtime(); /* 100 MHz; diagnostic build only */
-    const DFrame& F = B.f;
     const int frame = (int)blockIdx.y;
+    DFrame Fd;
+    const DFrame& F = frame_view<DYN>(B, frame, Fd);
     const DCam C = load_cam(B, frame);
     int b, wave;
     block_and_wave(b, wave);
@@ -1477,10 +1510,11 @@ __device__ __forceinline__ F3 direct_light_from_bits(const DFrame& F, F3 so, F3 
 
 /* SHADE_PASS: third pass of the three-pass form (below): the camera ray's hit comes from the first pass's record, the verdicts of its
  * light shadow rays from the second's bits; everything behind a mirror bounce is traced here as in the one-kernel form. */
-template <int PATH, bool SINGLE, bool SHADE_PASS = false>
+template <int PATH, bool SINGLE, bool SHADE_PASS = false, bool DYN = false>
 __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(VRT_FULL_WAVES))) void march_kernel_full(const DBlock B) {
-    const DFrame& F = B.f;
     const int frame = (int)blockIdx.y;
+    DFrame Fd;
+    const DFrame& F = frame_view<DYN>(B, frame, Fd);
     int b, wave;
     block_and_wave(b, wave);
     const int lane = (int)threadIdx.x & 63;
@@ -1655,11 +1689,12 @@ __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(V
 #ifndef VRT_SHADOW_PASS_WAVES
 #define VRT_SHADOW_PASS_WAVES 7
 #endif
-template <int PATH, bool SINGLE>
+template <int PATH, bool SINGLE, bool DYN = false>
 __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu((!SINGLE && PATH != VRT_PATH_DENSE) ? VRT_PRIMARY_PASS_WAVES : 1)))
 void primary_pass_kernel(const DBlock B) {
-    const DFrame& F = B.f;
     const int frame = (int)blockIdx.y;
+    DFrame Fd;
+    const DFrame& F = frame_view<DYN>(B, frame, Fd);
     const DCam C = load_cam(B, frame);
     int b, wave;
     block_and_wave(b, wave);
@@ -1698,10 +1733,11 @@ void primary_pass_kernel(const DBlock B) {
     write_records<false, true>(F, frame, b, wave, lane, k, dg, 0ull);
 }
 
-template <int PATH, bool SINGLE>
+template <int PATH, bool SINGLE, bool DYN = false>
 __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(VRT_SHADOW_PASS_WAVES))) void light_pass_kernel(const DBlock B) {
-    const DFrame& F = B.f;
     const int frame = (int)blockIdx.y;
+    DFrame Fd;
+    const DFrame& F = frame_view<DYN>(B, frame, Fd);
     int b, wave;
     block_and_wave(b, wave);
     const int lane = (int)threadIdx.x & 63;
@@ -2379,7 +2415,10 @@ static hipError_t launch_nodiag_t(const DBlock& B, hipStream_t stream) {
     const DFrame& F = B.f;
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), ab_lds_bytes(), stream, B);
+    if (F.dyn != nullptr)
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false, true>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), ab_lds_bytes(), stream, B);
+    else
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), ab_lds_bytes(), stream, B);
     return hipGetLastError();
 }
 
@@ -2400,6 +2439,16 @@ static hipError_t launch_full_t(const DBlock& B, hipStream_t stream) {
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
     const dim3 g((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), t(kMarchThreads);
+    if (F.dyn != nullptr) { /* per-frame scene state: the DYN instantiations */
+        if (F.hit_rec != nullptr) {
+            hipLaunchKernelGGL((primary_pass_kernel<PATH, SINGLE, true>), g, t, ab_lds_bytes(), stream, B);
+            hipLaunchKernelGGL((light_pass_kernel<PATH, SINGLE, true>), g, t, ab_lds_bytes(), stream, B);
+            if (F.may_bounce) hipLaunchKernelGGL((march_kernel_full<PATH, false, true, true>), g, t, ab_lds_bytes(), stream, B);
+            return hipGetLastError();
+        }
+        hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE, false, true>), g, t, ab_lds_bytes(), stream, B);
+        return hipGetLastError();
+    }
     if (F.hit_rec != nullptr) { /* three passes, see primary_pass_kernel */
         hipLaunchKernelGGL((primary_pass_kernel<PATH, SINGLE>), g, t, ab_lds_bytes(), stream, B);
         hipLaunchKernelGGL((light_pass_kernel<PATH, SINGLE>), g, t, ab_lds_bytes(), stream, B);
@@ -2430,6 +2479,7 @@ static hipError_t launch_path(const DBlock& B, bool single, bool diag_build, hip
 hipError_t launch_march(const DBlock& B, int path, bool single, hipStream_t stream) {
     const DFrame& F = B.f;
     if (F.n_frames < 1 || F.n_frames > (F.cams != nullptr ? kMaxLaunchFrames : kMaxBlockFrames)) return hipErrorInvalidValue;
+    if (F.dyn != nullptr && F.diag) return hipErrorInvalidValue; /* (the diagnostic build has no per-frame-scene instantiation) */
     switch (path) {
         case kPathCube: return launch_path<kPathCube>(B, single, false, stream);
         case kPathCube16: return launch_path<kPathCube16>(B, single, false, stream);
@@ -2437,7 +2487,7 @@ hipError_t launch_march(const DBlock& B, int path, bool single, hipStream_t stre
         case kPathCells16: return launch_path<kPathCells16>(B, single, F.diag != 0, stream);
         case VRT_PATH_DENSE: return launch_path<VRT_PATH_DENSE>(B, single, F.diag != 0, stream);
         case VRT_PATH_BRICK_LDS:
-            if (single && !F.full) return launch_coop(B, stream);
+            if (single && !F.full && F.dyn == nullptr) return launch_coop(B, stream);
             return launch_path<VRT_PATH_BRICK>(B, single, F.diag != 0, stream);
         default: return launch_path<VRT_PATH_BRICK>(B, single, F.diag != 0, stream);
     }

@@ -222,11 +222,13 @@ class VHipRenderer:
                                                C.c_void_p(device_ptr), C.c_void_p(stream)), "vrt_render_strips")
 
     def render_block(self, params: _abi.vrt_params, n_frames: int, device_ptr: int, frame_stride_bytes: int, stream: int = 0,
-                     strips=None, rows=None, cameras=None) -> None:
+                     strips=None, rows=None, cameras=None, scenes=None) -> None:
         """vrt_render_block: n_frames frames of the current scene in flight with one call, frame f into
         device_ptr + f*frame_stride_bytes; to the caller one asynchronous operation on `stream`.  strips = (strip_rows,
         first_strip, strip_stride, n_strips) or rows = (row0, rows) (default: the whole frame); cameras: n_frames
-        (position[3], rotation[4], fov_deg) triples overriding the scene's camera per frame."""
+        (position[3], rotation[4], fov_deg) triples overriding the scene's camera per frame; scenes: per-frame scene state —
+        (a ctypes vrt_scene array from scene_array(), index of the first scene): frame f renders scenes[start + f] (objects,
+        lights and camera that move from frame to frame) over the volumes of the scene this renderer is synced with."""
         self._require()
         b = _abi.vrt_block()
         b.n_frames = int(n_frames)
@@ -240,9 +242,33 @@ class VHipRenderer:
             if start < 0 or start + b.n_frames > len(arr):
                 raise ValueError("camera range outside the array")
             b.cameras = C.cast(C.byref(arr, start * C.sizeof(_abi.vrt_camera)), C.POINTER(_abi.vrt_camera))
+        if scenes is not None:
+            sarr, sstart = scenes
+            if sstart < 0 or sstart + b.n_frames > len(sarr):
+                raise ValueError("scene range outside the array")
+            b.scenes = C.cast(C.byref(sarr, sstart * C.sizeof(_abi.vrt_scene)), C.POINTER(_abi.vrt_scene))
         b.frame_stride_bytes = int(frame_stride_bytes)
         _abi.check(self._lib.vrt_render_block(self._ctx, C.byref(params), C.byref(b), C.c_void_p(device_ptr), C.c_void_p(stream)),
                    "vrt_render_block")
+
+    def scene_array(self, scenes):
+        """A ctypes vrt_scene array from VScene objects that place (a subset of) the SAME volumes as the scene this renderer
+        is synced with (SetSceneToRender + SyncWithScene): their instances name the synced scene's volume slots.  For
+        render_block(scenes=(array, start)): objects, lights and camera per frame."""
+        if self._scene is None:
+            raise RuntimeError("SetSceneToRender was not called")
+        slots = {id(vol): i for i, vol in enumerate(self._scene.volumes())}
+        arr = (_abi.vrt_scene * len(scenes))()
+        for k, sc in enumerate(scenes):
+            a = sc.to_abi()
+            own = sc.volumes()
+            for i in range(a.n_instances):
+                vol = own[a.instances[i].volume_slot]
+                if id(vol) not in slots:
+                    raise ValueError("a per-frame scene places a volume the synced scene does not hold")
+                a.instances[i].volume_slot = slots[id(vol)]
+            arr[k] = a
+        return arr
 
     @staticmethod
     def camera_array(cameras):

@@ -106,6 +106,65 @@ def orbit_cameras(scene: v.VScene, n: int, step_deg: float = 0.25):
     return out
 
 
+def demo_scene(mesh_resolution: int = 7, env: int = 64, mirror: bool = True) -> v.VScene:
+    """The reference demo's scene (App/Private/RendererEngineInstance.cpp:232-263): the model of Resources/Model/Monkey.vox
+    (absent from the checkout: the build's voxelized torus stands in), camera (300, 0, 100) yawed 180 degrees, the demo's
+    directional light, and two 64^3 SDF spheres — radius 40, red, and radius 20, blue, roughness 0.1 / metallic 0.6 (they
+    mirror: roughness < 0.3) — at their relative positions (200, 0, 100) and (100, 0, 200).  mirror=False gives them
+    roughness 0.8 (no bounce rays: the directional-light kernel)."""
+    rough = 0.1 if mirror else 0.8
+    model = voxelized_torus(mesh_resolution)
+    s1 = v.sphere_volume(6, 100.0, 40.0, v.VMaterial((1.0, 0.0, 0.0, 1.0), rough, 0.6))
+    s2 = v.sphere_volume(6, 100.0, 20.0, v.VMaterial((0.0, 0.0, 1.0, 1.0), rough, 0.6))
+    objs = [v.VVoxelObject(Volume=model), v.VVoxelObject(Position=(200.0, 0.0, 100.0), Volume=s1),
+            v.VVoxelObject(Position=(100.0, 0.0, 200.0), Volume=s2)]
+    return v.VScene(Camera=v.look_minus_x_camera(300.0, 100.0), DirectionalLight=v.demo_light(), Objects=objs,
+                    EnvironmentMap=v.procedural_skybox(env))
+
+
+def demo_frames(scene: v.VScene, n: int, dt: float = 1.0 / 60.0, t0: float = 0.0):
+    """n consecutive frames of the demo's animation (RendererEngineInstance.cpp:111-130): sphere 1 orbits the up axis at
+    +10 degrees per second, sphere 2 at -50, from their relative positions; everything else stands still.  Returns n scenes
+    that share the volumes (and the sky box) of `scene` — what VRDXScene::SyncWithScene sees frame after frame."""
+    import copy
+
+    rel1, rel2 = (200.0, 0.0, 100.0), (100.0, 0.0, 200.0)
+    out = []
+    for f in range(n):
+        t = t0 + (f + 1) * dt
+        a1, a2 = math.radians((10.0 * t) % 360.0), math.radians((-50.0 * t) % 360.0)
+        sc = copy.copy(scene)
+        objs = [copy.copy(o) for o in scene.Objects]
+        objs[1].Position = tuple(float(x) for x in v.quat_rotate(v.quat_from_axis_angle(v.UP, a1), rel1))
+        objs[2].Position = tuple(float(x) for x in v.quat_rotate(v.quat_from_axis_angle(v.UP, a2), rel2))
+        sc.Objects = objs
+        out.append(sc)
+    return out
+
+
+def moving_instances(scene: v.VScene, n: int, step_deg: float = 0.25):
+    """n consecutive frames of `scene` with EVERY placed object moving (each spins about the up axis at its own rate and bobs along
+    it) under the camera of orbit_cameras: the per-frame scene state of bench.py's dynamic_scene leg — BASELINE config 5 as the
+    reference would animate it (objects move every frame, TLAS rebuilt every frame: RendererEngineInstance.cpp:111-130,
+    DXRenderer.cpp:809-825).  The scenes share `scene`'s volumes."""
+    import copy
+
+    cams = orbit_cameras(scene, n, step_deg)
+    out = []
+    for f in range(n):
+        sc = copy.copy(scene)
+        objs = []
+        for k, o in enumerate(scene.Objects):
+            q = copy.copy(o)
+            q.Rotation = tuple(v.quat_mul(v.quat_from_axis_angle(v.UP, math.radians(0.5 * (k % 3 + 1) * (f - n // 2))), o.Rotation))
+            q.Position = (o.Position[0], o.Position[1], o.Position[2] + 6.0 * math.sin(0.1 * (f - n // 2) + k))
+            objs.append(q)
+        sc.Objects = objs
+        sc.Camera = v.VCamera(Position=cams[f][0], Rotation=cams[f][1], FOVAngle=cams[f][2])
+        out.append(sc)
+    return out
+
+
 def full_closest_hit_scene(resolution: int = 6, env: int = 32) -> v.VScene:
     """Exercises the whole closest-hit shader: smooth metallic spheres that mirror each
     other (roughness 0.1 < 0.3 → bounce, as in the reference's demo materials,
