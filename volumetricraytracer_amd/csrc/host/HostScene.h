@@ -37,7 +37,7 @@ public:
     /* A cube map from a .dds file — what VTextureFactory::LoadTextureCubeFromFile reads (Renderer/Private/
        TextureFactory.cpp:28-67; the reference's Resources/Skybox/Skybox.dds): uncompressed 32-bit RGBA / BGRA / BGRX or
        24-bit RGB, or block-compressed BC1 / BC2 / BC3 (DXT1 / DXT3 / DXT5); legacy or DX10 header, six faces, top mip level only.
-       nullptr for anything else (not a cube map, BC4-BC7 / float formats, truncated, faces not square). */
+       nullptr for anything else (not a cube map, BC6H / BC7 / float formats, truncated, faces not square). */
     static std::shared_ptr<VTextureCube> LoadFromDDSFile(const std::string& path);
     /* Whether a sky box argument names a .dds file (suffix, any case) rather than a folder of face images: the one rule every
        caller uses. */

@@ -62,11 +62,10 @@ std::shared_ptr<Voxel::VVoxelVolume> VVolumeConverter::ConvertMeshInfoToVoxelVol
     uint8_t resolution = 5;
     if (!ExtractResolutionFromName(meshInfo.MeshName, resolution)) {
         resolution = 5;
-        std::cout << "[WARNING] Mesh with name " << meshInfo.MeshName
-                  << " has no or invalid resolution specifier. Correct syntax is meshName_resolution (cubeMesh_6). Using default resolution of 5!" << std::endl;
+        std::cout << "[voxelizer] mesh '" << meshInfo.MeshName << "': no '_<resolution>' suffix in its name (e.g. cube_6): resolution 5" << std::endl;
     }
     if (resolution > 8) {
-        std::cout << "[WARNING] Mesh with name " << meshInfo.MeshName << " has invalid resolution. Resolution needs to be between or equal than 0 and 8." << std::endl;
+        std::cout << "[voxelizer] mesh '" << meshInfo.MeshName << "': resolution " << (int)resolution << " is outside 0..8: resolution 5" << std::endl;
         resolution = 5;
     }
 

@@ -130,7 +130,7 @@ int vrh_cubemap_load(const char* dir, int* face_size, uint8_t* out, size_t cap) 
     const bool dds = VTextureCube::IsDDSPath(where);
     VObjectPtr<VTextureCube> t = dds ? VTextureCube::LoadFromDDSFile(where) : VTextureCube::LoadFromFaceDirectory(where);
     if (!t) {
-        g_error = (dds ? std::string("cannot read an uncompressed cube map from ") : std::string("cannot load six equal square faces from ")) + where;
+        g_error = (dds ? std::string("cannot read a cube map (uncompressed or BC1-BC5) from ") : std::string("cannot load six equal square faces from ")) + where;
         return -1;
     }
     if (face_size) *face_size = (int)t->GetWidth();

@@ -198,7 +198,7 @@ struct DFrame {
     unsigned* hit_aux;         /* instance | shadowed-by-light bits << 16 (bit 0 directional, 1.. point, 6.. spot lights) */
     unsigned long long* hit_mask; /* per (frame, wave): the lanes whose camera ray hit */
     const DCam* cams;          /* launches of more than kMaxBlockFrames frames: the frames' camera records in device memory (null: DBlock::cam) */
-    uint32_t rec_stride;       /* records between the frames of a launch (= workgroups per frame * 64) */
+    uint32_t rec_stride;       /* records between the frames of a launch (= workgroups per frame * 256: four waves of 64 lanes) */
     int32_t may_bounce;        /* 1: bounces allowed and some material can mirror (smooth, or roughness from a texture) */
     const void* dyn;           /* per-frame scene state (vrt_block::scenes): n_frames sections of kDynStride bytes in device memory, each a
                                   DDyn record followed by the frame's instances, BVH nodes, point and spot lights; null: every frame of the
