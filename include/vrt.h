@@ -64,6 +64,8 @@ extern "C" {
                                        light shadow rays and their shading / a third pass for the lanes that mirror, in frames that can
                                        bounce; same pixels and counters, twice the waves per SIMD).  A lone frame is one kernel by default */
 #define VRT_FLAG_FULL_THREE_PASS 512 /* ... and the three passes even for a lone frame (tests, measurements).  Not both */
+#define VRT_FLAG_OUTPUT_BGRA8 2048 /* together with VRT_FLAG_OUTPUT_RGBA8: the bytes in the reference's back-buffer order, B8G8R8A8_UNORM
+                                     (DXGI_FORMAT_B8G8R8A8_UNORM, DXConstants.cpp:21, DXRenderer.cpp:1322): B in the low byte; same values */
 #define VRT_FLAG_NO_HIT_POLISH 1024 /* closest hits stay where the cone threshold stopped the ray (rounds 1-3) instead of moving on to the surface's
                                       zero crossing by VRT_HIT_POLISH_SAMPLES secant samples: A/B measurements, tests */
 #define VRT_HIT_POLISH_SAMPLES 2   /* part of the march contract: samples a closest hit spends on its way from the stop point to the crossing */
@@ -191,7 +193,7 @@ typedef struct vrt_params {
                              (speed only, never results); bit 2: VRT_FLAG_DIAG_TIMELINE; bit 3:
                              VRT_FLAG_OUTPUT_RGBA8; bit 4: VRT_FLAG_NO_TIMING; bit 5: accepted and ignored (it was round 1's
                              VRT_FLAG_SKIP_EMPTY: the march never samples empty cells now); bit 6: VRT_FLAG_BLOCK_PER_FRAME; bit 7: VRT_FLAG_NO_CULL_RECT;
-                             bit 8: VRT_FLAG_FULL_ONE_KERNEL; bit 9: VRT_FLAG_FULL_THREE_PASS; bit 10: VRT_FLAG_NO_HIT_POLISH.  Others 0 */
+                             bit 8: VRT_FLAG_FULL_ONE_KERNEL; bit 9: VRT_FLAG_FULL_THREE_PASS; bit 10: VRT_FLAG_NO_HIT_POLISH; bit 11: VRT_FLAG_OUTPUT_BGRA8.  Others 0 */
     float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
     float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
     float step_min;       /* lower bound of one march step (ray-parameter units) */
@@ -354,6 +356,14 @@ typedef struct vrt_block {
  * vrt_launch_history report one duration per LAUNCH (vrt_launch_history also says how many frames it covered);
  * vrt_last_timing holds the counters of the block's last frame and the duration of its last launch. */
 int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* block, void* device_rgba, void* hip_stream);
+
+/* vrt_render_block with the frames handed to the HOST: the block is marched into a context-owned device buffer (one launch, as
+ * above) and copied into context-owned pinned host memory; *host_frames points at frame 0, frame f at + f * (bytes of one frame's
+ * rows), valid until the next call of this function or vrt_destroy.  For the VRenderer-shaped side (csrc/host/HipRenderer.cpp:
+ * RenderBlock): a camera path, or a stretch of a scene's animation (block->scenes), reaches the block launch without the caller
+ * owning device memory.  block->frame_stride_bytes is ignored (frames are packed).  Blocks of more than 4 GB are refused
+ * (VRT_ERR_INVALID: render the path in parts).  Synchronous; single-device contexts. */
+int vrt_render_block_host(vrt_ctx* ctx, const vrt_params* params, const vrt_block* block, const void** host_frames);
 
 /* ---- multi-GPU exchange (one process per GPU) --------------------------------------------------------------------------
  * The reference is single-adapter (every D3D12 object is created with NodeMask 0, DXRenderer.cpp:253); the frame of this

@@ -1681,6 +1681,91 @@ def test_voxelized_shell_volume_parity(renderer, oracle_lib, path):
     assert (t["primary_steps"] + t["shadow_steps"]) / t["hits"] > 5 and t["hits"] > 10000
 
 
+def test_bgra8_output_is_the_rgba8_frame_with_red_and_blue_swapped(renderer, oracle_lib):
+    """VRT_FLAG_OUTPUT_BGRA8: the reference's back buffer is DXGI_FORMAT_B8G8R8A8_UNORM (DXConstants.cpp:21,
+    DXRenderer.cpp:1322).  Same 8-bit values as the R8G8B8A8 target, B in the low byte — lean kernel, full closest hit (one kernel and
+    passes), block launch; the flag alone (without RGBA8) is refused."""
+    import torch
+
+    for sc, bounces in ((scenes.config3_voxelized(6, 16), 0), (scenes.full_closest_hit_scene(5, 16), 2)):
+        p = v.default_params(200, 112, scenes.min_cell(sc), 255, shadow=True)
+        p.max_bounces = bounces
+        p.flags |= _abi.FLAG_OUTPUT_RGBA8
+        rgba, _ = gpu_render(renderer, sc, p)
+        q = _abi.vrt_params.from_buffer_copy(p)
+        q.flags |= _abi.FLAG_OUTPUT_BGRA8
+        bgra, _ = gpu_render(renderer, sc, q)
+        assert np.array_equal(bgra[..., [2, 1, 0, 3]], rgba) and (rgba[..., 3] == 255).all() and not np.array_equal(bgra, rgba)
+        n = 3
+        blk = torch.zeros((n, 112, 200, 4), dtype=torch.uint8, device="cuda:0")
+        renderer.render_block(q, n, blk.data_ptr(), 112 * 200 * 4, 0, cameras=_orbit(sc.Camera, n))
+        torch.cuda.synchronize()
+        ref = torch.zeros_like(blk)
+        renderer.render_block(p, n, ref.data_ptr(), 112 * 200 * 4, 0, cameras=_orbit(sc.Camera, n))
+        torch.cuda.synchronize()
+        assert torch.equal(blk[..., [2, 1, 0, 3]], ref)
+    only = _abi.vrt_params.from_buffer_copy(p)
+    only.flags = _abi.FLAG_OUTPUT_BGRA8
+    one = torch.zeros((112, 200, 4), dtype=torch.float32, device="cuda:0")
+    assert _abi.load().vrt_render_rows(renderer._ctx, C.byref(only), 0, 112, C.c_void_p(one.data_ptr()), None) == _abi.VRT_ERR_INVALID
+
+
+def test_render_block_host_hands_the_frames_to_the_host(renderer, oracle_lib):
+    """vrt_render_block_host: the block launch for callers without device memory (the C++ adaptor's RenderBlock): frames in
+    context-owned pinned memory, bit-equal to vrt_render_block's — a camera path of 70 frames (copied in parts under the march) and
+    a block over per-frame scenes."""
+    import torch
+
+    sc = scenes.config3_voxelized(6, 16)
+    W, H, n = 168, 96, 70
+    p = v.default_params(W, H, scenes.min_cell(sc), 255, shadow=True)
+    p.flags |= _abi.FLAG_OUTPUT_RGBA8 | _abi.FLAG_OUTPUT_BGRA8
+    renderer.SetSceneToRender(sc)
+    renderer.ResizeRenderOutput(W, H)
+    renderer.SyncWithScene()
+    cams = renderer.camera_array(_orbit(sc.Camera, n))
+    dev = torch.zeros((n, H, W, 4), dtype=torch.uint8, device="cuda:0")
+    renderer.render_block(p, n, dev.data_ptr(), H * W * 4, 0, cameras=(cams, 0))
+    torch.cuda.synchronize()
+    b = _abi.vrt_block()
+    b.n_frames, b.rows = n, H
+    b.cameras = C.cast(cams, C.POINTER(_abi.vrt_camera))
+    ptr = C.c_void_p()
+    lib = _abi.load()
+    _abi.check(lib.vrt_render_block_host(renderer._ctx, C.byref(p), C.byref(b), C.byref(ptr)), "vrt_render_block_host")
+    host = np.frombuffer((C.c_uint8 * (n * H * W * 4)).from_address(ptr.value), dtype=np.uint8).reshape(n, H, W, 4)
+    assert np.array_equal(host, dev.cpu().numpy())
+    frames = scenes.moving_instances(sc, 9)
+    arr = renderer.scene_array(frames)
+    dev9 = torch.zeros((9, H, W, 4), dtype=torch.uint8, device="cuda:0")
+    renderer.render_block(p, 9, dev9.data_ptr(), H * W * 4, 0, scenes=(arr, 0))
+    torch.cuda.synchronize()
+    b2 = _abi.vrt_block()
+    b2.n_frames, b2.rows = 9, H
+    b2.scenes = C.cast(arr, C.POINTER(_abi.vrt_scene))
+    _abi.check(lib.vrt_render_block_host(renderer._ctx, C.byref(p), C.byref(b2), C.byref(ptr)), "vrt_render_block_host")
+    host9 = np.frombuffer((C.c_uint8 * (9 * H * W * 4)).from_address(ptr.value), dtype=np.uint8).reshape(9, H, W, 4)
+    assert np.array_equal(host9, dev9.cpu().numpy()) and not np.array_equal(host9[0], host9[8])
+    assert lib.vrt_render_block_host(renderer._ctx, C.byref(p), C.byref(b2), None) == _abi.VRT_ERR_INVALID
+
+
+def test_cpp_host_adaptor_block_of_the_demo_animation_equals_frame_by_frame(tmp_path):
+    """VHipRenderer::RenderBlock (the VRenderer-shaped side of vrt_block::scenes): the demo's animation — its two spheres orbiting —
+    as ONE march launch per 12 frames writes the same last frame as 12 Render() calls with three frames in flight and as 12
+    synchronous ones, in every frame format (the PPM holds R, G, B whatever the byte order in memory)."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(_abi.LIB_PATH), "vrt_demo")
+    outs = {}
+    for name, extra in (("block_bgra8", ["--block", "12"]), ("flight_bgra8", []), ("sync_rgba8", ["--in-flight", "1", "--format", "rgba8"]),
+                        ("sync_float", ["--in-flight", "1", "--format", "float"]), ("block_float", ["--block", "5", "--format", "float"])):
+        out = str(tmp_path / (name + ".ppm"))
+        r = subprocess.run([exe, "--frames", "12", "--size", "320x180", "--out", out] + extra, capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0, r.stderr
+        outs[name] = open(out, "rb").read()
+    assert len(set(outs.values())) == 1, {k: len(x) for k, x in outs.items()}
+
+
 def test_cpp_host_adaptor_renders_the_demo_scene(renderer, tmp_path):
     """The C++ VRenderer adaptor (csrc/host/HipRenderer.cpp, driven by vrt_demo exactly like
     VEngine::EngineLoop drives the reference's renderer) against the Python host path on the same

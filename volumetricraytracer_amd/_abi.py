@@ -45,6 +45,7 @@ FLAG_BLOCK_PER_FRAME = 64
 FLAG_NO_CULL_RECT = 128
 FLAG_FULL_ONE_KERNEL = 256   # full closest hit of a block of frames as ONE kernel (default: three passes)
 FLAG_FULL_THREE_PASS = 512   # ... and three passes even for a lone frame
+FLAG_OUTPUT_BGRA8 = 2048       # with FLAG_OUTPUT_RGBA8: B8G8R8A8 byte order, the reference's back buffer (DXConstants.cpp:21)
 FLAG_NO_HIT_POLISH = 1024     # closest hits stay at the cone threshold's stop point (rounds 1-3) instead of moving on to the crossing
 HIT_POLISH_SAMPLES = 2
 MAX_BLOCK_FRAMES = 48  # frames one march launch covers with their cameras in the kernarg segment (csrc/vrt_device.h kMaxBlockFrames)
@@ -196,6 +197,7 @@ SYMBOLS = {
     "vrt_render_rows": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vrt_render_strips": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vrt_render_block": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.POINTER(vrt_block), C.c_void_p, C.c_void_p]),
+    "vrt_render_block_host": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.POINTER(vrt_block), C.POINTER(C.c_void_p)]),
     "vrt_comm_unique_id": (C.c_int, [C.c_void_p]),
     "vrt_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vrt_comm_destroy": (C.c_int, [C.c_void_p]),

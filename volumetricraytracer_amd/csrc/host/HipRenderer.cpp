@@ -349,7 +349,9 @@ void VHipRenderer::Stop() {
     UploadedEnv = nullptr;
     for (bool& b : SlotBusy) b = false;
     FramePixels = nullptr;
-    FramePixelCount = 0;
+    FrameBytes = 0;
+    BlockFrames = nullptr;
+    BlockFrameCount = 0;
     TextureIds.clear();
     for (auto& kv : Textures) kv.second.Id = -1;
 }
@@ -463,8 +465,16 @@ bool VHipRenderer::SyncWithScene(Scene::VScene& scene) {
     const VTextureCube* env = scene.GetEnvironmentTexture().get();
     if (env != UploadedEnv) UploadToGPU(scene.GetEnvironmentTexture());
 
-    /* scene constants + instance list (UpdateSceneConstantBuffer, BuildTopLevelAccelerationStructures) */
     vrt_scene s;
+    if (!FillSceneStruct(scene, s)) return false;
+    return ok(vrt_scene_set(Ctx, &s), "vrt_scene_set");
+}
+
+/* The scene's constants, lights and instance list as the C-ABI takes them (UpdateSceneConstantBuffer, UpdateLights,
+   BuildTopLevelAccelerationStructures: RDXScene.cpp:703-755, 454-545) — for vrt_scene_set, or as one frame of vrt_block::scenes.
+   Volume slots are the indices of scene.GetAllRegisteredVolumes(), which SyncWithScene uploaded. */
+bool VHipRenderer::FillSceneStruct(Scene::VScene& scene, vrt_scene& s) {
+    const auto volumes = scene.GetAllRegisteredVolumes();
     memset(&s, 0, sizeof s);
     const VObjectPtr<Scene::VCamera> cam = scene.GetActiveCamera();
     if (!cam) {
@@ -518,19 +528,11 @@ bool VHipRenderer::SyncWithScene(Scene::VScene& scene) {
             I.scale[0] = vo->Scale.X; I.scale[1] = vo->Scale.Y; I.scale[2] = vo->Scale.Z;
         }
     }
-    return ok(vrt_scene_set(Ctx, &s), "vrt_scene_set");
+    return true;
 }
 
-void VHipRenderer::Render() {
-    if (!IsActive()) {
-        V_LOG_WARNING("Render() on an inactive renderer"); /* DXRenderer.cpp:62-65 */
-        return;
-    }
-    const VObjectPtr<Scene::VScene> scene = SceneRef.lock();
-    if (!scene) return;
-    if (const VObjectPtr<Scene::VCamera> cam = scene->GetActiveCamera()) cam->AspectRatio = (float)Width / (float)Height; /* :47 */
-    if (!SyncWithScene(*scene)) return;
-
+/* March parameters of a frame of `scene` (DESIGN.md §3 defaults from the scene's smallest cell) in the adaptor's frame format. */
+vrt_params VHipRenderer::MakeParams(Scene::VScene& scene) const {
     vrt_params p;
     memset(&p, 0, sizeof p);
     p.width = (int)Width;
@@ -544,13 +546,29 @@ void VHipRenderer::Render() {
     p.eps_in = 0.01f; /* Raytracing.hlsl:178 */
     p.step_min = 0.004f * MinCell;
     p.k_relax = Relaxation;
-    const VObjectPtr<Scene::VCamera> cam = scene->GetActiveCamera();
-    p.cone_eps = std::tan(cam->FOVAngle * (3.14159265358979323846f / 180.0f) * 0.5f) / (float)Height;
-    Frame.resize((size_t)Width * Height * 4);
+    const VObjectPtr<Scene::VCamera> cam = scene.GetActiveCamera();
+    p.cone_eps = std::tan((cam ? cam->FOVAngle : 60.f) * (3.14159265358979323846f / 180.0f) * 0.5f) / (float)Height;
+    if (FrameFormat != EFrameFormat::Float4) p.flags |= VRT_FLAG_OUTPUT_RGBA8;
+    if (FrameFormat == EFrameFormat::BGRA8) p.flags |= VRT_FLAG_OUTPUT_BGRA8;
+    return p;
+}
+
+void VHipRenderer::Render() {
+    if (!IsActive()) {
+        V_LOG_WARNING("Render() on an inactive renderer"); /* DXRenderer.cpp:62-65 */
+        return;
+    }
+    const VObjectPtr<Scene::VScene> scene = SceneRef.lock();
+    if (!scene) return;
+    if (const VObjectPtr<Scene::VCamera> cam = scene->GetActiveCamera()) cam->AspectRatio = (float)Width / (float)Height; /* :47 */
+    if (!SyncWithScene(*scene)) return;
+    const vrt_params p = MakeParams(*scene);
+    const size_t bytes = (size_t)Width * Height * BytesPerPixel();
     if (FramesInFlight <= 1 || Devices.size() != 1) {
+        Frame.resize((bytes + sizeof(float) - 1) / sizeof(float));
         if (ok(vrt_render(Ctx, &p, Frame.data()), "vrt_render")) {
             FramePixels = Frame.data();
-            FramePixelCount = Frame.size();
+            FrameBytes = bytes;
         }
         return;
     }
@@ -561,17 +579,60 @@ void VHipRenderer::Render() {
     if (SlotBusy[slot]) Collect(slot);
     if (ok(vrt_render_begin(Ctx, &p, slot), "vrt_render_begin")) {
         SlotBusy[slot] = true;
-        SlotPixels[slot] = (size_t)Width * Height * 4;
+        SlotBytes[slot] = bytes;
         FrameIndex++;
     }
+}
+
+/* A stretch of the application's animation as ONE march launch (vrt_render_block_host over vrt_block::scenes): tick(f) is the
+   application's per-frame update (RendererEngineInstance::OnEngineUpdate: objects, lights and camera move; volumes must not
+   change inside a block), the scene is mirrored after every tick like SyncWithScene does per frame, then the block is marched
+   and its frames land in pinned host memory: GetBlockFrame(f).  What VEngine::EngineLoop does frame by frame
+   (tick -> Render), for n frames at once — the reference's TLAS rebuild per frame (DXRenderer.cpp:809-825) becomes one BVH per
+   frame of the block, built on the host. */
+bool VHipRenderer::RenderBlock(int n_frames, const std::function<void(int)>& tick) {
+    if (!IsActive()) {
+        V_LOG_WARNING("RenderBlock() on an inactive renderer");
+        return false;
+    }
+    const VObjectPtr<Scene::VScene> scene = SceneRef.lock();
+    if (!scene || n_frames < 1 || n_frames > 256 || Devices.size() != 1) return false;
+    Flush();
+    if (const VObjectPtr<Scene::VCamera> cam = scene->GetActiveCamera()) cam->AspectRatio = (float)Width / (float)Height;
+    if (!SyncWithScene(*scene)) return false; /* volumes, materials, textures, sky: as they are at the block's start */
+    for (const auto& v : scene->GetAllRegisteredVolumes()) v->PostRender(); /* uploaded: clean (what the engine's post-render tick does, Engine.cpp:214) */
+    BlockScenes.resize((size_t)n_frames);
+    for (int f = 0; f < n_frames; f++) {
+        if (tick) tick(f);
+        for (const auto& v : scene->GetAllRegisteredVolumes())
+            if (v->IsDirty()) {
+                V_LOG_ERROR("RenderBlock: a volume changed inside the block; render such frames with Render()");
+                return false;
+            }
+        if (!FillSceneStruct(*scene, BlockScenes[(size_t)f])) return false;
+    }
+    const vrt_params p = MakeParams(*scene);
+    vrt_block b;
+    memset(&b, 0, sizeof b);
+    b.n_frames = n_frames;
+    b.rows = (int)Height;
+    b.scenes = BlockScenes.data();
+    const void* frames = nullptr;
+    if (!ok(vrt_render_block_host(Ctx, &p, &b, &frames), "vrt_render_block_host")) return false;
+    BlockFrames = static_cast<const unsigned char*>(frames);
+    BlockFrameCount = n_frames;
+    BlockFrameBytes = (size_t)Width * Height * BytesPerPixel();
+    FramePixels = BlockFrames + (size_t)(n_frames - 1) * BlockFrameBytes; /* the newest frame, as after Render() */
+    FrameBytes = BlockFrameBytes;
+    return true;
 }
 
 void VHipRenderer::Collect(int slot) {
     const void* px = nullptr;
     if (ok(vrt_render_end(Ctx, slot, &px), "vrt_render_end") && px) {
         /* no copy: the pinned frame of the slot stays valid until the slot is begun again, FramesInFlight - 1 frames on */
-        FramePixels = static_cast<const float*>(px);
-        FramePixelCount = SlotPixels[slot];
+        FramePixels = px;
+        FrameBytes = SlotBytes[slot];
     }
     SlotBusy[slot] = false;
 }

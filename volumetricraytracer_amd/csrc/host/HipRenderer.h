@@ -9,6 +9,7 @@
  * Error convention of the reference: Start() returns bool, everything else logs and returns.
  */
 #pragma once
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -41,11 +42,17 @@ public:
 
     /* backend-specific */
     void SetDevices(const std::vector<int>& hipOrdinals) { Devices = hipOrdinals; } /* before Start(); default {0} */
-    /* The newest finished frame: Width*Height float RGBA (null before the first one).  With frames in flight it points
-       into the slot's pinned buffer and stays valid for FramesInFlight - 1 further Render() calls. */
-    const float* GetFramePixels() const { return FramePixels; }
-    size_t GetFramePixelCount() const { return FramePixelCount; }
-    const std::vector<float>& GetFrame() const { return Frame; }                     /* FramesInFlight == 1 only */
+    /* Pixel format of the frames handed to the host.  BGRA8 is the reference's own back buffer (DXGI_FORMAT_B8G8R8A8_UNORM,
+       DXConstants.cpp:21, DXRenderer.cpp:1322) and the default; RGBA8 the same bytes with R first; Float4 keeps the float
+       channels (16 B per pixel: four times the bytes over PCIe) — what the parity tests compare. */
+    enum class EFrameFormat { Float4, RGBA8, BGRA8 };
+    EFrameFormat FrameFormat = EFrameFormat::BGRA8;
+    size_t BytesPerPixel() const { return FrameFormat == EFrameFormat::Float4 ? 16 : 4; }
+    /* The newest finished frame: Width*Height pixels of FrameFormat (null before the first one).  With frames in flight it
+       points into the slot's pinned buffer and stays valid for FramesInFlight - 1 further Render() calls. */
+    const void* GetFrameData() const { return FramePixels; }
+    size_t GetFrameByteCount() const { return FrameBytes; }
+    const float* GetFramePixels() const { return FrameFormat == EFrameFormat::Float4 ? static_cast<const float*>(FramePixels) : nullptr; }
     unsigned GetWidth() const { return Width; }
     unsigned GetHeight() const { return Height; }
     bool GetLastTiming(vrt_timing& out) const;
@@ -59,20 +66,32 @@ public:
     bool Shadows = true;      /* the reference always casts the directional shadow ray */
     int MaxBounces = 2;       /* MAX_RAY_RECURSION_DEPTH 3 = primary + 2 mirror bounces (RaytracingHlsl.h:32) */
     int DataPath = VRT_PATH_AUTO;
-    /* 1: Render() returns with the finished frame (vrt_render).  2..3: frames in flight like the reference's swap chain
-       (FrameCount 3, DXConstants.cpp:23): Render() enqueues (vrt_render_begin) and GetFrame() lags by FramesInFlight - 1
-       frames until Flush() collects what is still in flight.  Single-device only. */
-    int FramesInFlight = 1;
+    /* 2..3 (default 3, the reference's swap chain: FrameCount 3, DXConstants.cpp:23, fence pacing DXRenderer.cpp:974-989):
+       Render() enqueues the frame (vrt_render_begin) and returns; GetFrameData() lags by FramesInFlight - 1 frames until
+       Flush() collects what is still in flight.  1: Render() returns with the finished frame (vrt_render).  Contexts over
+       several devices always render synchronously. */
+    int FramesInFlight = 3;
     void Flush();
+    /* n_frames frames of the application's animation with ONE march launch: tick(f) moves objects / lights / camera for frame
+       f (may be empty: a standing scene), every frame's scene state is mirrored, the block is marched and copied to pinned host
+       memory.  GetBlockFrame(f): frame f in FrameFormat, valid until the next RenderBlock / Stop.  n_frames <= 256. */
+    bool RenderBlock(int n_frames, const std::function<void(int)>& tick);
+    const void* GetBlockFrame(int f) const { return (BlockFrames && f >= 0 && f < BlockFrameCount) ? BlockFrames + (size_t)f * BlockFrameBytes : nullptr; }
 
 private:
     bool SyncWithScene(Scene::VScene& scene);
+    bool FillSceneStruct(Scene::VScene& scene, vrt_scene& out);
+    vrt_params MakeParams(Scene::VScene& scene) const;
+    std::vector<vrt_scene> BlockScenes;
+    const unsigned char* BlockFrames = nullptr;
+    int BlockFrameCount = 0;
+    size_t BlockFrameBytes = 0;
     vrt_ctx* Ctx = nullptr;
     std::vector<int> Devices{0};
     unsigned Width = 1024, Height = 576; /* Win32Window.cpp:218-219 */
-    std::vector<float> Frame;
-    const float* FramePixels = nullptr;
-    size_t FramePixelCount = 0;
+    std::vector<float> Frame; /* synchronous frames (FramesInFlight 1, or several devices) */
+    const void* FramePixels = nullptr;
+    size_t FrameBytes = 0;
     std::vector<const Voxel::VVoxelVolume*> Uploaded; /* per slot */
     const VTextureCube* UploadedEnv = nullptr;
     struct TextureEntry {
@@ -88,7 +107,7 @@ private:
     void Collect(int slot);
     unsigned long long FrameIndex = 0;
     bool SlotBusy[VRT_FRAMES_IN_FLIGHT] = {};
-    size_t SlotPixels[VRT_FRAMES_IN_FLIGHT] = {};
+    size_t SlotBytes[VRT_FRAMES_IN_FLIGHT] = {};
 };
 
 }  // namespace Hip

@@ -8,6 +8,8 @@
  * tick → Renderer->Render() → post-render.  Writes the last frame as a PPM.
  *
  *   vrt_demo [--frames N] [--size WxH] [--scene file.vox] [--out frame.ppm] [--mode 0..7 (EVRenderMode)] [--in-flight 1..3] [--skybox dir-with-XP..ZM.png | cube.dds]
+ *            [--format bgra8|rgba8|float]   frame format handed to the host; default bgra8, the reference's back buffer (DXConstants.cpp:21)
+ *            [--block N]                    N frames of the animation per RenderBlock call (ONE march launch per N frames) instead of one Render() per frame
  */
 #include <chrono>
 #include <cmath>
@@ -59,7 +61,8 @@ int main(int argc, char** argv) {
     int frames = 60;
     unsigned W = 1024, H = 576;
     std::string scenePath, skyboxDir, outPath = "vrt_demo.ppm";
-    int mode = 0, inFlight = 1;
+    int mode = 0, inFlight = 3, block = 0; /* three frames in flight: the reference's swap chain (FrameCount, DXConstants.cpp:23) */
+    std::string format = "bgra8";
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--size") && i + 1 < argc) sscanf(argv[++i], "%ux%u", &W, &H);
@@ -68,6 +71,8 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--mode") && i + 1 < argc) mode = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--in-flight") && i + 1 < argc) inFlight = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--skybox") && i + 1 < argc) skyboxDir = argv[++i];
+        else if (!strcmp(argv[i], "--format") && i + 1 < argc) format = argv[++i];
+        else if (!strcmp(argv[i], "--block") && i + 1 < argc) block = atoi(argv[++i]);
     }
 
     std::shared_ptr<Renderer::VRenderer> renderer = Renderer::VRendererFactory::NewRenderer();
@@ -111,32 +116,53 @@ int main(int argc, char** argv) {
     renderer->SetSceneToRender(scene);
 
     auto* hip = dynamic_cast<Renderer::Hip::VHipRenderer*>(renderer.get());
+    using Fmt = Renderer::Hip::VHipRenderer::EFrameFormat;
     if (hip && inFlight >= 1 && inFlight <= 3) hip->FramesInFlight = inFlight;
+    if (hip) hip->FrameFormat = format == "float" ? Fmt::Float4 : (format == "rgba8" ? Fmt::RGBA8 : Fmt::BGRA8);
     double kernel_ms = 0.0;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int f = 0; f < frames; f++) {
-        const float dt = 1.f / 60.f, angle = (float)f * dt * 0.5f;              /* TickEngineInstance */
+    auto tick = [&](int f) {                                                     /* TickEngineInstance */
+        const float dt = 1.f / 60.f, angle = (float)f * dt * 0.5f;
         sphere1->Position = VQuat::FromAxisAngle(VVector::UP, angle) * rel1;
         sphere2->Position = VQuat::FromAxisAngle(VVector::RIGHT, angle) * rel2;
         scene->Touch();
-        renderer->Render();                                                     /* Engine.cpp:212 */
-        scene->PostRender();                                                    /* :214 */
-        vrt_timing tm;
-        if (hip && hip->GetLastTiming(tm)) kernel_ms += tm.kernel_ms;
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    if (hip && block > 0) {
+        /* the same animation, `block` frames per call: per-frame scene state, ONE march launch per block */
+        for (int f0 = 0; f0 < frames; f0 += block) {
+            const int n = frames - f0 < block ? frames - f0 : block;
+            if (!hip->RenderBlock(n, [&](int f) { tick(f0 + f); })) return 1;
+            scene->PostRender();
+            vrt_timing tm;
+            if (hip->GetLastTiming(tm)) kernel_ms += tm.kernel_ms;
+        }
+    } else {
+        for (int f = 0; f < frames; f++) {
+            tick(f);
+            renderer->Render();                                                     /* Engine.cpp:212 */
+            scene->PostRender();                                                    /* :214 */
+            vrt_timing tm;
+            if (hip && inFlight <= 1 && hip->GetLastTiming(tm)) kernel_ms += tm.kernel_ms; /* (asking a frame in flight for its time would wait for it) */
+        }
+        if (hip) hip->Flush(); /* collect the frames still in flight: GetFrameData() is the last frame again */
     }
-    if (hip) hip->Flush(); /* collect the frames still in flight: GetFrame() is the last frame again */
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("%d frames %ux%u: %.2f ms/frame wall (%.1f FPS), march kernel %.3f ms/frame\n", frames, W, H, wall / frames * 1e3, frames / wall,
-           kernel_ms / frames);
+    printf("%d frames %ux%u %s%s: %.3f ms/frame wall (%.0f frames/s)", frames, W, H, format.c_str(),
+           block > 0 ? (", RenderBlock of " + std::to_string(block)).c_str() : (", " + std::to_string(inFlight) + " in flight").c_str(), wall / frames * 1e3, frames / wall);
+    if (kernel_ms > 0.0) printf(", march kernel %.3f ms/%s", kernel_ms / (block > 0 ? (frames + block - 1) / block : frames), block > 0 ? "block" : "frame");
+    printf("\n");
 
-    if (hip && hip->GetFramePixels()) {
+    if (hip && hip->GetFrameData()) {
         FILE* fp = fopen(outPath.c_str(), "wb");
         if (fp) {
             fprintf(fp, "P6 %u %u 255\n", W, H);
             const float* fr = hip->GetFramePixels();
+            const unsigned char* by = static_cast<const unsigned char*>(hip->GetFrameData());
+            const bool bgra = hip->FrameFormat == Fmt::BGRA8;
             for (size_t i = 0; i < (size_t)W * H; i++) {
                 unsigned char rgb[3];
-                for (int c = 0; c < 3; c++) rgb[c] = (unsigned char)(std::fmin(std::fmax(fr[i * 4 + c], 0.f), 1.f) * 255.f + 0.5f);
+                for (int c = 0; c < 3; c++)
+                    rgb[c] = fr ? (unsigned char)(std::fmin(std::fmax(fr[i * 4 + c], 0.f), 1.f) * 255.f + 0.5f) : by[i * 4 + (bgra ? 2 - c : c)];
                 fwrite(rgb, 1, 3, fp);
             }
             fclose(fp);

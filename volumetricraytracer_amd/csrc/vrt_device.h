@@ -162,7 +162,7 @@ struct DFrame {
     int32_t tile_map;          /* kMapSupertile / kMapBand / kMapLinear */
     int32_t diag;              /* 1: diagnostic kernel build that stamps per-wave timeline records */
     int32_t full;              /* 1: full closest hit needed (point/spot lights, or bounces allowed and a smooth material in the scene) */
-    int32_t rgba8;             /* 1: store R8G8B8A8_UNORM (4 B/pixel) instead of float4 */
+    int32_t rgba8;             /* 1: store R8G8B8A8_UNORM (4 B/pixel) instead of float4; 2: B8G8R8A8_UNORM (the reference's back buffer) */
     /* interleaved strips (multi-GPU load balance): local row l of the compact tile is frame row
        ((l / strip_rows) * strip_stride + strip_first) * strip_rows + l % strip_rows; strip_rows == 0:
        contiguous rows row0 + l */

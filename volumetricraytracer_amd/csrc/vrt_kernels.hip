@@ -1254,7 +1254,9 @@ __device__ __forceinline__ void store_pixel(const DFrame& F, int frame, unsigned
     const float r = tonemap(color.x), g = tonemap(color.y), b = tonemap(color.z);
     /* streaming stores: a frame writes as many bytes as an XCD's whole L2 holds; they must not push the bricks out */
     if (F.rgba8) {
-        __builtin_nontemporal_store(unorm8(r) | unorm8(g) << 8 | unorm8(b) << 16 | 0xff000000u,
+        /* R8G8B8A8, or (2) the reference's own back-buffer order B8G8R8A8 (DXConstants.cpp:21): which channel goes low, which third */
+        const bool bgra = F.rgba8 == 2;
+        __builtin_nontemporal_store(unorm8(bgra ? b : r) | unorm8(g) << 8 | unorm8(bgra ? r : b) << 16 | 0xff000000u,
                                     reinterpret_cast<unsigned*>(out) + pix);
     } else {
         typedef float f4 __attribute__((ext_vector_type(4)));
