@@ -126,6 +126,15 @@ int main(int argc, char** argv) {
         sphere2->Position = VQuat::FromAxisAngle(VVector::RIGHT, angle) * rel2;
         scene->Touch();
     };
+    /* one untimed frame / block first: the pinned frame buffers and the device buffers of this size are allocated by the first call */
+    if (hip && block > 0) {
+        if (!hip->RenderBlock(frames < block ? frames : block, tick)) return 1;
+    } else {
+        tick(0);
+        renderer->Render();
+        if (hip) hip->Flush();
+    }
+    scene->PostRender();
     const auto t0 = std::chrono::steady_clock::now();
     if (hip && block > 0) {
         /* the same animation, `block` frames per call: per-frame scene state, ONE march launch per block */

@@ -130,7 +130,8 @@ struct SceneArrays {
 /* One frame in flight (vrt_render_begin / vrt_render_end): stream, completion event, scene snapshot, device frame and
    a pinned host frame. */
 struct FrameSlot {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  /* the device's flight stream (shared by the slots) */
+    hipEvent_t marched = nullptr;  /* the slot's march is done: its read-back may start (copy stream) */
     hipEvent_t done = nullptr;
     SceneArrays* d_scene = nullptr;
     SceneArrays* h_scene = nullptr; /* pinned */
@@ -187,6 +188,7 @@ struct DeviceState {
     void* h_blockfb = nullptr;
     size_t blockfb_bytes = 0;
     hipStream_t copy_stream = nullptr;
+    hipStream_t flight_stream = nullptr; /* vrt_render_begin: the marches of the frames in flight */
     hipEvent_t part_done = nullptr;
     int last_slot = 0;
     unsigned* d_diag = nullptr;  /* allocated on first use of VRT_FLAG_DIAG_TIMELINE (never in a capture) */
@@ -211,6 +213,7 @@ struct vrt_ctx {
     int env_size = 0;
     int upload_format = VRT_FORMAT_F32; /* vrt_set_volume_format: device format of the following uploads */
     bool have_scene = false;
+    bool arrays_uploaded = false; /* the device copies of inst / nodes / point / spot hold the packed scene (pack_scene defers them while frames are in flight) */
     bool scene_stale = true; /* a volume was uploaded / freed / re-measured since the scene arrays were packed (boxes, BVH) */
     vrt_scene scene;
     DInstance inst[VRT_MAX_INSTANCES];
@@ -544,8 +547,9 @@ void destroy_device(DeviceState& D) {
     if (D.d_env) (void)hipFree(D.d_env);
     for (int i = 0; i < VRT_MAX_TEXTURES; i++)
         if (D.tex[i]) (void)hipFree(D.tex[i]);
+    if (D.flight_stream) (void)hipStreamDestroy(D.flight_stream);
     for (auto& S : D.slot) {
-        if (S.stream) (void)hipStreamDestroy(S.stream);
+        if (S.marched) (void)hipEventDestroy(S.marched);
         if (S.done) (void)hipEventDestroy(S.done);
         if (S.d_scene) (void)hipFree(S.d_scene);
         if (S.h_scene) (void)hipHostFree(S.h_scene);
@@ -725,9 +729,9 @@ void pack_scene_arrays(const vrt_ctx* ctx, const vrt_scene& s, DInstance* inst, 
     }
 }
 
-int pack_scene(vrt_ctx* ctx) {
+/* The packed scene's arrays -> every device (synchronous copies on the null stream). */
+int upload_scene_arrays(vrt_ctx* ctx) {
     const vrt_scene& s = ctx->scene;
-    pack_scene_arrays(ctx, s, ctx->inst, ctx->nodes, ctx->n_nodes, ctx->point, ctx->spot);
     const int npl = std::min(s.n_point_lights, VRT_MAX_POINT_LIGHTS);
     const int nsl = std::min(s.n_spot_lights, VRT_MAX_SPOT_LIGHTS);
     for (auto& D : ctx->dev) {
@@ -739,7 +743,21 @@ int pack_scene(vrt_ctx* ctx) {
         if (npl > 0) HIP_TRY(hipMemcpy(D.d_point, ctx->point, sizeof(DPointLight) * (size_t)npl, hipMemcpyHostToDevice));
         if (nsl > 0) HIP_TRY(hipMemcpy(D.d_spot, ctx->spot, sizeof(DSpotLight) * (size_t)nsl, hipMemcpyHostToDevice));
     }
+    ctx->arrays_uploaded = true;
     return VRT_OK;
+}
+
+int pack_scene(vrt_ctx* ctx) {
+    pack_scene_arrays(ctx, ctx->scene, ctx->inst, ctx->nodes, ctx->n_nodes, ctx->point, ctx->spot);
+    ctx->arrays_uploaded = false;
+    /* While frames are in flight (vrt_render_begin: each carries its own snapshot of these arrays, copied on its own stream) the
+       device copies of the context are not what the next frame reads: they are brought up to date by the first launch that needs
+       them.  A synchronous copy here would queue behind a frame's march and stall the application for its whole duration — the
+       reference's per-frame scene update (RendererEngineInstance.cpp:111-130) would cost the overlap of march and read-back. */
+    for (auto& D : ctx->dev)
+        for (const FrameSlot& S : D.slot)
+            if (S.busy) return VRT_OK;
+    return upload_scene_arrays(ctx);
 }
 
 /* What vrt_scene_set refuses (and vrt_render_block, per frame of vrt_block::scenes). */
@@ -1006,6 +1024,12 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
     }
     const int path = resolve_path(ctx, p->path, single, p->mode, scenes, n_frames);
     if (path < 0) return path;
+    if (!snapshot && !scenes && !ctx->arrays_uploaded) { /* deferred by pack_scene (frames were in flight): now */
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream != nullptr && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return VRT_ERR_NOT_READY;
+        const int rc = upload_scene_arrays(ctx);
+        if (rc != VRT_OK) return rc;
+    }
     D.last_blocks = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if ((long long)D.last_blocks * n_frames > 8LL * kMaxBlocks) return VRT_ERR_INVALID;
     D.last_frames = n_frames;
@@ -1537,7 +1561,7 @@ int vrt_render_block_host(vrt_ctx* ctx, const vrt_params* params, const vrt_bloc
     }
     /* In parts: the copy of one part (its own stream) runs under the march of the next.  The march is ~4x faster than the copy over
        PCIe (1080p RGBA8: 0.04 against 0.16 ms per frame), so what the parts buy is that the first frames do not wait for the last. */
-    const int part = block->scenes || block->n_frames <= 32 ? block->n_frames : 32;
+    const int part = block->n_frames <= 32 ? block->n_frames : 32;
     for (int f = 0; f < block->n_frames; f += part) {
         const int n = std::min(part, block->n_frames - f);
         vrt_block b = *block;
@@ -1773,8 +1797,18 @@ int vrt_render_begin(vrt_ctx* ctx, const vrt_params* params, int slot) {
     if (S.busy) return VRT_ERR_NOT_READY; /* vrt_render_end(slot) first */
     HIP_TRY(hipSetDevice(D.ordinal));
     const size_t need = (size_t)params->width * params->height * ((params->flags & VRT_FLAG_OUTPUT_RGBA8) ? 4 : 16);
-    if (!S.stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    if (!D.copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&D.copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&D.part_done, hipEventDisableTiming));
+    }
+    if (!D.flight_stream) HIP_TRY(hipStreamCreateWithFlags(&D.flight_stream, hipStreamNonBlocking));
+    if (!S.done) {
+        /* ONE march stream and ONE copy stream for all the frame slots (a slot owns its buffers and two events): the marches run back
+           to back, frame k's read-back runs under frame k+1's march whatever the number of slots and however HIP maps streams to
+           hardware queues.  (A stream per slot — round 3 — gave 4 300 frames/s with three slots and 5 500 with two on the demo
+           scene: with three, a slot's stream shares a hardware queue with another's.) */
+        S.stream = D.flight_stream;
+        HIP_TRY(hipEventCreateWithFlags(&S.marched, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
         HIP_TRY(hipMalloc(&S.d_scene, sizeof(SceneArrays)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S.h_scene), sizeof(SceneArrays), hipHostMallocDefault));
@@ -1801,8 +1835,10 @@ int vrt_render_begin(vrt_ctx* ctx, const vrt_params* params, int slot) {
     rs.rows = params->height;
     rc = enqueue_rows(ctx, D, params, rs, static_cast<float*>(S.d_fb), S.stream, ring, S.d_scene);
     if (rc != VRT_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(S.h_fb, S.d_fb, need, hipMemcpyDeviceToHost, S.stream));
-    HIP_TRY(hipEventRecord(S.done, S.stream));
+    HIP_TRY(hipEventRecord(S.marched, S.stream));
+    HIP_TRY(hipStreamWaitEvent(D.copy_stream, S.marched, 0));
+    HIP_TRY(hipMemcpyAsync(S.h_fb, S.d_fb, need, hipMemcpyDeviceToHost, D.copy_stream));
+    HIP_TRY(hipEventRecord(S.done, D.copy_stream));
     S.busy = true;
     S.ring = ring;
     ctx->launches++;
