@@ -52,7 +52,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
 # tools/microbench/gather.hip on MI355X (profiles/r01_gather_microbench.txt): trilinear samples/s the chip sustains for
 # 4 x dwordx2 taps per lane at random cells, by where the bricks live
-GATHER_CEILING_GSAMPLES = {"l1": 264.0, "l2": 209.0, "mall_hbm": 126.0}
+GATHER_CEILING_GSAMPLES = {"l1": 264.0, "l2": 209.0, "mall_hbm": 126.0, "l1_int16": 295.0}
 
 
 def parse_args(argv=None):
@@ -78,6 +78,10 @@ def parse_args(argv=None):
                          "overlaps the next block's march)")
     ap.add_argument("--frames-per-step", type=int, default=96,
                     help="frames in the batch ONE step renders: consecutive views of a camera on a short orbit (0.25 degrees apart)")
+    ap.add_argument("--launches-per-step", type=int, default=0,
+                    help="passes over the batch that make ONE step (each pass = --frames-per-step frames); 0 = default: 30 on the main "
+                         "line (a step is then 2 880 frames, about 0.11 s on one MI355X: the driver's --steps 20 --warmup 5 times 2 s after "
+                         "0.5 s of warm-up, long enough for clocks to settle and for SMI samples to see the GPU busy), 1 with --steps <= 2")
     ap.add_argument("--block-frames", type=int, default=0,
                     help="frames per vrt_render_block call = per march launch (up to 48; one event pair per launch); 0 = default")
     ap.add_argument("--per-frame-launches", action="store_true",
@@ -91,10 +95,11 @@ def parse_args(argv=None):
                     help="N>1: where the frames of a block are assembled: rotate = frame g on rank g // (block / N), one all-to-all "
                          "per block (every xGMI link carries tiles); gather = every frame on rank 0 (ncclGather; rank 0's inbound "
                          "links bound the job).  The other one is measured as a leg of the same run")
-    ap.add_argument("--gather", default="torch", choices=["torch", "native"],
-                    help="N>1: the collective's implementation: torch.distributed (RCCL under torch), or the C-ABI's own "
-                         "vrt_gather_tiles / vrt_exchange_tiles (ncclGather / grouped ncclSend+ncclRecv on the march stream; then "
-                         "torch's is cross-checked after the timed region, native_gather_check)")
+    ap.add_argument("--gather", default="native", choices=["torch", "native"],
+                    help="N>1: the collective's implementation: the C-ABI's own vrt_gather_tiles / vrt_exchange_tiles (the PRODUCT's path: "
+                         "ncclGather / grouped ncclSend+ncclRecv on the march stream, RCCL resolved by dlopen; default — falls back to "
+                         "torch.distributed, and says so in `collective`, when librccl cannot be resolved or vrt_comm_init fails), or "
+                         "torch.distributed (RCCL under torch).  Whichever is not the main line is cross-checked after the timed region")
     ap.add_argument("--native-check", action="store_true",
                     help="N>1 with --gather torch: also bring up the C-ABI's own RCCL communicator and run a few frames through "
                          "vrt_gather_tiles after the timed region (native_gather_check)")
@@ -322,6 +327,32 @@ def timed_run(pipe: Pipeline, steps: int, warmup: int, world: int, cdev, frames_
     return elapsed
 
 
+def multi_gpu_summary(value, anchor_v, rotate, exchange_other, world, W, H, bytes_per_pixel, rays_per_frame, other_steps):
+    """The N > 1 line's top-level account of the exchange: both exchanges side by side with their speed-up over
+    the one-GPU anchor, and what the link model says about them.  north_star asks for ">= 6x at 8 GPUs" with "an RCCL gather ... for
+    the final image": a gather onto ONE rank moves (N-1)/N of every frame over that rank's N-1 inbound xGMI links (~77 GB/s per
+    direction each, ~80 % reached by RCCL), which bounds the whole job whatever the march does; rotating roots (one all-to-all per
+    block) spread the same bytes over every link of the node."""
+    main_name, other_name = ("rotate", "gather") if rotate else ("gather", "rotate")
+    ex = {main_name: {"value": round(value, 2), "speedup_vs_anchor": round(value / anchor_v, 3) if anchor_v else None, "main_line": True}}
+    if isinstance(exchange_other, dict) and exchange_other.get("value"):
+        ex[other_name] = {"value": exchange_other["value"], "speedup_vs_anchor": round(exchange_other["value"] / anchor_v, 3) if anchor_v else None,
+                          "main_line": False, "steps": other_steps}
+    frame_bytes = W * H * bytes_per_pixel
+    link_gbs, eff = 77.0, 0.8
+    cap_fps = world * (link_gbs * 1e9 * eff) / frame_bytes  # (N-1)/N of a frame over N-1 links
+    return {
+        "exchanges": ex,
+        "link_model": {
+            "gather_to_rank0_cap_Mrays_per_s": round(cap_fps * rays_per_frame / 1e6, 1),
+            "gather_to_rank0_cap_speedup_vs_anchor": round(cap_fps * rays_per_frame / 1e6 / anchor_v, 2) if anchor_v else None,
+            "assumes": f"{frame_bytes} B per assembled frame, {world - 1} inbound xGMI links x {link_gbs} GB/s x {eff} into the root",
+            "rotating_roots": "the same bytes over all N(N-1) directed links: not link-bound at these rates"},
+        "north_star_6x_at_8_gpus": ({k: (x["speedup_vs_anchor"] is not None and x["speedup_vs_anchor"] >= 6.0) for k, x in ex.items()}
+                                    if world == 8 else None),
+    }
+
+
 def launch_check(args) -> None:
     """The N-rank plumbing without a march (CPU, gloo): rendezvous, strip layout, gather, un-shuffle, max-over-ranks."""
     import numpy as np
@@ -366,8 +397,11 @@ def launch_check(args) -> None:
         dist.barrier()
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
     if rank == 0:
+        # (the N > 1 line's exchange account, assembled from synthetic figures: its keys are what a SCALE record must carry)
+        summary = multi_gpu_summary(400000.0, 62000.0, True, {"value": 140000.0}, max(world, 2), 1920, 1080, 4, 2.4e6, 3)
         print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_joined": world, "gathered_frame_ok": ok,
-                          "elapsed_s": round(float(te.item()), 4)}), flush=True)
+                          "elapsed_s": round(float(te.item()), 4), "multi_gpu_line_keys": sorted(summary),
+                          "multi_gpu_line_sample": summary}), flush=True)
         if not ok:
             raise SystemExit(3)
     if world > 1:
@@ -479,9 +513,10 @@ def main() -> None:
     r.SyncWithScene()
 
     native_ready, native_error = False, None
-    if world > 1 and not rehearsal and (args.gather == "native" or args.native_check):
-        # the C-ABI's own communicator (only on request: a second RCCL communicator next to torch's is not something a default
-        # benchmark run should depend on): rank 0 makes the id, torch.distributed carries it to the others
+    if world > 1 and not rehearsal:
+        # the C-ABI's own communicator — the product's exchange path, and the main line's by default (an N > 1 run
+        # must measure vrt_comm_init / vrt_exchange_tiles / vrt_gather_tiles, not torch.distributed): rank 0 makes the id,
+        # torch.distributed carries it to the others
         try:
             idt = torch.zeros(_abi.VRT_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
             if rank == 0:
@@ -495,12 +530,17 @@ def main() -> None:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         native_ready = bool(flag.item())
     use_native = args.gather == "native" and native_ready
+    native_fallback = None
     if args.gather == "native" and world > 1 and not native_ready and not rehearsal:
-        raise SystemExit(f"[bench] --gather native: vrt_comm_init failed on some rank ({native_error})")
+        # never lose the run: torch.distributed carries the exchange instead, and the line says so
+        native_fallback = f"vrt_comm_init unavailable ({native_error}): torch.distributed carries the exchange"
+        print(f"[bench] {native_fallback}", file=sys.stderr)
 
     # One STEP = one batch of B frames: consecutive views of a camera on a short orbit through the workload's own view
     # (frames of a moving camera, not B copies of one frame, so a frame does not find its predecessor's lines in L2).
     B = max(args.frames_per_step, 1)
+    # the main line's step: L passes over the batch (L launches of B frames on one GPU)
+    L = args.launches_per_step if args.launches_per_step > 0 else (30 if args.steps > 2 else 1)
     # frames per vrt_render_block call = per march launch: one GPU the whole step (96: a launch's latency-bound tail is paid once per
     # launch; beyond 48 frames the cameras are copied to the device ahead of the launch instead of travelling in the kernarg segment);
     # several GPUs: about 48 (a multiple of N), exchanged as ONE block per collective
@@ -542,9 +582,9 @@ def main() -> None:
                         n_cameras=B, rotate=rotate if rot is None else rot)
 
     pipe = pipeline(p, W, H, K, use_native)
-    elapsed = timed_run(pipe, args.steps, args.warmup, world, cdev, B)
+    elapsed = timed_run(pipe, args.steps, args.warmup, world, cdev, B * L)
     # the event-timed march launches of the timed region: (ms, frames the launch covered); only whole blocks count
-    n_timed = len(list(block_plan(args.steps * B, G, K)))  # launches of the timed region (the warm-up's come before them)
+    n_timed = len(list(block_plan(args.steps * B * L, G, K)))  # launches of the timed region (the warm-up's come before them)
     hist = [(ms, fr) for ms, fr in r.launch_history(min(max(n_timed, 1), 200)) if ms > 0.0]
     fpl = max((fr for _, fr in hist), default=1)  # frames per launch
     kms = [ms for ms, fr in hist if fr == fpl]
@@ -579,8 +619,9 @@ def main() -> None:
             raise SystemExit("[bench] the assembled frame differs from the single-GPU frame")
 
     cnt = batch_counts(p, W, H)  # whole job, one batch
-    rays_per_step = cnt["primary_rays"] + cnt["shadow_rays"]
-    rays_per_frame = rays_per_step / B
+    rays_per_batch = cnt["primary_rays"] + cnt["shadow_rays"]
+    rays_per_step = rays_per_batch * L
+    rays_per_frame = rays_per_batch / B
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
     value = rays_per_step * args.steps / elapsed / 1e6 if args.steps > 0 else 0.0
     # mean frame of the batch as this rank's launch sees it (algorithmic bytes of ONE launch)
@@ -630,7 +671,7 @@ def main() -> None:
 
         def run_other(other):
             eo = timed_run(other, osteps, 1, world, cdev, B)
-            return {"ms_per_frame": round(eo / (osteps * B) * 1e3, 4), "value": round(rays_per_step * osteps / eo / 1e6, 2), "unit": "Mrays/s",
+            return {"ms_per_frame": round(eo / (osteps * B) * 1e3, 4), "value": round(rays_per_batch * osteps / eo / 1e6, 2), "unit": "Mrays/s",
                     "last_frame_equals_single_gpu_frame": last_frame_ok(other, p, W, H)}
 
         if native_ready:  # the other implementation of the same collective, a few steps: same pixels, and its frame time
@@ -651,7 +692,7 @@ def main() -> None:
             g1 = world if rotate else 1
             k1 = [x / g1 for x, fr in r.launch_history(200) if x > 0.0 and fr == g1]
             return {"streams": 1, "frames_per_launch": g1, "ms_per_frame": round(e1 / (lsteps * B) * 1e3, 4),
-                    "value": round(rays_per_step * lsteps / e1 / 1e6, 2), "unit": "Mrays/s",
+                    "value": round(rays_per_batch * lsteps / e1 / 1e6, 2), "unit": "Mrays/s",
                     "kernel_ms_per_frame": round(float(np.mean(k1)), 4) if k1 else None}
 
         latency = leg(lambda: pipeline(p, W, H, 1, use_native, world if rotate else 1), run_latency)
@@ -709,7 +750,7 @@ def main() -> None:
             pipen = pipeline(pn, W, H, K, False)
             sn = max(min(args.steps, 4), 1)
             en = timed_run(pipen, sn, 1, world, cdev, B)
-            no_cull = {"ms_per_frame": round(en / (sn * B) * 1e3, 4), "value": round(rays_per_step * sn / en / 1e6, 2), "unit": "Mrays/s",
+            no_cull = {"ms_per_frame": round(en / (sn * B) * 1e3, 4), "value": round(rays_per_batch * sn / en / 1e6, 2), "unit": "Mrays/s",
                        "what": "the same frames with VRT_FLAG_NO_CULL_RECT: every wave loads the scene and slab-tests its rays"}
             del pipen
 
@@ -807,8 +848,60 @@ def main() -> None:
         r.SetSceneToRender(sc)
         r.SyncWithScene()
 
+    coverage_leg = None
+    if not args.no_extra_legs and args.steps > 0 and world == 1 and args.workload == "c3":
+        # Every pixel marches: the same 256^3 volume with the camera INSIDE its box, 0.6 extents from the centre,
+        # looking at it — no sky wave, no wave outside the cull rectangle; the case that stresses the texture path hardest.
+        def run_coverage(_):
+            ext = float(sc.volumes()[0].VolumeExtends)
+            scc = workloads.config3_voxelized(8, 256, distance=0.6 * ext, device_format=fmt)
+            scc.Objects[0].Volume = sc.volumes()[0]  # the resident volume (no second upload)
+            r.SetSceneToRender(scc)
+            r.SyncWithScene()
+            camsc = r.camera_array(workloads.orbit_cameras(scc, B))
+            buf = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev)
+            fb = H * W * 16
+            tot = {k: 0.0 for k in KEYS}
+            busy_waves = waves = 0
+            for f in range(B):
+                r.render_block(p, 1, buf.data_ptr(), fb, 0, cameras=(camsc, f))
+                torch.cuda.synchronize()
+                tt = r.last_timing()
+                for k in KEYS:
+                    tot[k] += tt[k]
+                if f == B // 2:
+                    rec = r.wave_records(0).astype(np.int64)
+                    busy_waves, waves = int(((rec[:, 3] + rec[:, 4]) > 0).sum()), int((rec[:, 0] > 0).sum())
+            sd = max(min(args.steps, 10), 1)
+            for _ in range(2):
+                r.render_block(p, B, buf.data_ptr(), fb, 0, cameras=(camsc, 0))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(sd):
+                r.render_block(p, B, buf.data_ptr(), fb, 0, cameras=(camsc, 0))
+            torch.cuda.synchronize()
+            ec = time.perf_counter() - t0
+            kc = [ms for ms, fr in r.launch_history(sd) if ms > 0.0 and fr == B]
+            samples_c = tot["primary_steps"] + tot["shadow_steps"]
+            rays_c = tot["primary_rays"] + tot["shadow_rays"]
+            outc = {"scene": f"config 3's volume, camera inside its box at 0.6 extents ({0.6 * ext:.1f}) from the centre: every wave marches",
+                    "ms_per_frame": round(ec / (sd * B) * 1e3, 4), "value": round(rays_c * sd / ec / 1e6, 2), "unit": "Mrays/s",
+                    "waves_marching": busy_waves, "waves": waves, "samples_per_ray": round(samples_c / max(rays_c, 1), 2),
+                    "hits_per_frame": int(tot["hits"] / B), "frames_per_launch": B}
+            if kc:
+                gs = samples_c / (float(np.mean(kc)) * 1e-3) / 1e9
+                outc.update({"kernel_ms_per_launch": round(float(np.mean(kc)), 4), "gsamples_per_s": round(gs, 2),
+                             "limiter_frac": round(gs / GATHER_CEILING_GSAMPLES["l1_int16" if fmt == _abi.FORMAT_TEXEL16 else "l1"], 4),
+                             "roofline_frac_algorithmic": round(v.algorithmic_bytes({k: tot[k] for k in KEYS}, 16) / (float(np.mean(kc)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            return outc
+
+        coverage_leg = leg(lambda: None, run_coverage)
+        r.SetSceneToRender(sc)
+        r.SyncWithScene()
+
     if rank == 0:
         alg_bytes = v.algorithmic_bytes(t, 4 if rgba8 else 16) * fpl  # of ONE launch: fpl frames
+        gather_key = "l1_int16" if fmt == _abi.FORMAT_TEXEL16 else "l1"  # the active data path's taps
         k_ms = float(np.mean(kms)) if kms else float("nan")
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if kms else 0.0
         samples = int(t["primary_steps"] + t["shadow_steps"]) * fpl
@@ -833,6 +926,15 @@ def main() -> None:
             "samples_per_launch": samples,
             "gsamples_per_s": round(samples / (k_ms * 1e-3) / 1e9, 2) if kms else None,
             "gather_ceiling_gsamples_per_s": GATHER_CEILING_GSAMPLES,
+            # The roof the kernel is actually under: its trilinear samples per second against the rate the chip
+            # sustains for this very access pattern served from L1 (tools/microbench/gather.hip, profiles/r04_gather_microbench.txt) —
+            # 96 % of the march's taps are L1 hits.  `frac` above counts cache-served taps as HBM bytes (the contract's algorithmic
+            # bytes): it says how many samples the kernel takes, not how many bytes cross the HBM interface, and MAY EXCEED 1.
+            "limiter": "L1-served trilinear gather (texture path: td_busy_frac is its busy fraction from the PMC counters)",
+            "limiter_frac": round(samples / (k_ms * 1e-3) / 1e9 / GATHER_CEILING_GSAMPLES[gather_key], 4) if kms else None,
+            "limiter_ceiling_gsamples_per_s": GATHER_CEILING_GSAMPLES[gather_key],
+            "frac_note": "frac = algorithmic bytes (32 B per sample, cache-served or not) / launch time / 8 TB/s: an accounting of samples; it may exceed 1. "
+                         "limiter_frac is the fraction of the measured roof; hbm_measured_frac the physical HBM share",
         }
         if pmc and kms:
             # physical picture, from the keyed PMC passes (profiles/counters_latest.json: tools/r03_profile.sh on this kernel source
@@ -862,15 +964,16 @@ def main() -> None:
         out = {
             "metric": "Mrays/sec at 1080p, 256^3 SDF volume" if args.workload in ("c3", "c3sdf") else "Mrays/sec",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step / B, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step / (B * L), 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": W, "height": H, "volume": f"{sc.volumes()[0].N - 1}^3 cells",
                        "volume_format": {_abi.FORMAT_F32: "f32 bricks (512 B per 4^3 cells)",
                                          _abi.FORMAT_TEXEL16: "reference texel: sign + 15-bit |d|*100, 16-bit bricks (256 B per 4^3 cells)"}[fmt],
                        "max_steps": max_steps, "shadow": bool(shadow), "k_relax": round(float(p.k_relax), 3), "data_path": args.path,
                        "output": "rgba8 (R8G8B8A8_UNORM tiles; march and shading in f32)" if rgba8 else "f32 (float4)",
-                       "step": f"one batch of {B} frames: consecutive views of a camera orbiting the workload's view, 0.25 degrees apart",
-                       "frames_per_step": B, "streams": K, "frames_per_launch": G,
+                       "step": f"{L} pass(es) over a batch of {B} frames (consecutive views of a camera orbiting the workload's view, 0.25 degrees "
+                               f"apart): {B * L} frames per step, one march launch per {G} frames",
+                       "frames_per_step": B * L, "frames_per_batch": B, "launches_per_step": (B * L + G - 1) // G, "streams": K, "frames_per_launch": G,
                        "parallelism": ("1 GPU" if world == 1 else
                                        (f"{strip_rows}-row interleaved strips" if strip_rows else "contiguous row tiles") +
                                        f" x{world} + " + exchange_label(rotate, world, G, rehearsal)),
@@ -878,10 +981,10 @@ def main() -> None:
                        # (the waves of a frame that lie outside the host's cull rectangle go straight to the sky: their pixels count as
                        # primary rays, like the reference's DispatchRays(W, H) counts them; how many rays sit in waves that march:)
                        "marching": marching,
-                       "samples_per_ray": round((psteps + ssteps) / max(rays_per_step, 1), 2)},
+                       "samples_per_ray": round((psteps + ssteps) / max(rays_per_batch, 1), 2)},
             "roofline": roofline, "cpu_baseline": cpu,
             "latency": latency, "scale_anchor": scale_anchor, "end_to_end": end_to_end, "config4": config4, "reference_texel_format": texel_leg, "full_closest_hit": full_leg,
-            "no_cull_rect": no_cull, "dynamic_scene": dynamic_leg,
+            "no_cull_rect": no_cull, "dynamic_scene": dynamic_leg, "full_coverage": coverage_leg,
         }
         if world > 1:
             out["speedup_vs_anchor"] = round(value / scale_anchor["value"], 3) if scale_anchor and scale_anchor.get("value") else None
@@ -891,6 +994,10 @@ def main() -> None:
             out["other_exchange"] = exchange_other
             if exchange_fallback:
                 out["exchange_fallback"] = exchange_fallback
+            if native_fallback:
+                out["collective_fallback"] = native_fallback
+            out.update(multi_gpu_summary(value, scale_anchor.get("value") if scale_anchor else None, rotate, exchange_other, world, W, H,
+                                         4 if rgba8 else 16, rays_per_frame, max(min(args.steps, 3), 1)))
         if verified is not None:
             out["assembled_frame_equals_single_gpu_frame"] = verified
         print(json.dumps(out), flush=True)

@@ -300,6 +300,14 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert out == {**out, "launch_check": True, "n_gpus": 2, "ranks_joined": 2, "gathered_frame_ok": True}
+    # the N > 1 line states both exchanges, their speed-up over the one-GPU anchor and the link model's cap for the rank-0 gather
+    assert out["multi_gpu_line_keys"] == ["exchanges", "link_model", "north_star_6x_at_8_gpus"]
+    sample = out["multi_gpu_line_sample"]
+    assert set(sample["exchanges"]) == {"rotate", "gather"} and sample["exchanges"]["rotate"]["main_line"] and not sample["exchanges"]["gather"]["main_line"]
+    assert abs(sample["exchanges"]["rotate"]["speedup_vs_anchor"] - 400000.0 / 62000.0) < 1e-3
+    # (N-1)/N of every 8.3-MB frame over the root's N-1 inbound links: N * 77 GB/s * 0.8 / frame bytes frames per second
+    want = 2 * 77e9 * 0.8 / (1920 * 1080 * 4) * 2.4e6 / 1e6 / 62000.0
+    assert abs(sample["link_model"]["gather_to_rank0_cap_speedup_vs_anchor"] - want) < 0.01
     bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--launch-check"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert bad.returncode == 2 and "refusing" in bad.stderr
