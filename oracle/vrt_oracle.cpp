@@ -179,6 +179,7 @@ struct Packed {
     const vrt_scene* scene;
     vrt_params prm;
     bool ref_intersection = false; /* vrto_ref_render: every ray is intersected by the REFERENCE's hit search (ref_march_instance) */
+    uint32_t* lead_img = nullptr; /* optional debug output, rows*width: positions the primary ray skipped before its first sample */
     uint32_t* steps_img; /* optional debug output, rows*width: march positions of the primary ray (low 16 bits) and of the rays after it (high 16) */
 };
 
@@ -581,6 +582,8 @@ thread_local uint64_t g_exhausted = 0;
    rays that follow it [1] — what the length of a GPU lane's dependent chain is made of */
 thread_local uint64_t g_positions[2] = {0, 0};
 thread_local int g_ray_class = 0;
+/* debug only (vrto_debug_set_lead_image): positions the primary ray SKIPPED before its first sample — what a beam pre-pass could take over */
+thread_local uint64_t g_leading_skips = 0;
 /* debug only (vrto_debug_set_position_log): one record {t, s or NaN when skipped, leap, step taken} per position */
 float* g_pos_log = nullptr;
 int g_pos_log_cap = 0, g_pos_log_n = 0;
@@ -769,6 +772,7 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
        been jumped over: the ray goes back and takes the plain step from the previous sample.  relaxed: the step that led to
        the current position was a stretched one. */
     bool relaxed = false;
+    bool leading = true; /* (debug statistics) no position of this march has been sampled yet */
     for (int i = 0; i < P.prm.max_steps; i++) {
         if (t > t_end) return false;
         g_positions[g_ray_class]++;
@@ -790,6 +794,7 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
                (factor 2: rounding margin), and max(min(s*k, smax), footprint, leap) = max(footprint, leap) once
                leap >= smax.  The ray advances without sampling (no tap is read, no sample is counted). */
             if (leap > 0.0f && leap >= smax && t <= t_skip_end) {
+                if (leading && g_ray_class == 0) g_leading_skips++;
                 t_prev = t;
                 s_prev = smax;
                 relaxed = false;
@@ -800,6 +805,7 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
         }
         float s = trilinear(V, cx, cy, cz, fx, fy, fz) * ds;
         steps++;
+        leading = false;
         if (relaxed && fmaxf(fminf(s, smax), 0.0f) + s_prev < t - t_prev) {
             /* the spheres do not overlap: back to the previous sample's plain step (that sample stays the "previous" one) */
             relaxed = false;
@@ -1253,11 +1259,13 @@ void render_rows(const Packed& P, int y0, int y1, int row0, float* out, Stats& s
             st.primary_rays++;
             g_positions[0] = g_positions[1] = 0;
             g_ray_class = 0;
+            g_leading_skips = 0;
             V3 c = radiance_ray(P, o, d, 1, 0.0f, st);
             if (P.steps_img) {
                 const uint64_t a = g_positions[0] < 0xffffu ? g_positions[0] : 0xffffu, b = g_positions[1] < 0xffffu ? g_positions[1] : 0xffffu;
                 P.steps_img[(size_t)(y - row0) * W + x] = (uint32_t)(a | (b << 16));
             }
+            if (P.lead_img) P.lead_img[(size_t)(y - row0) * W + x] = (uint32_t)g_leading_skips;
             float* px = out + ((size_t)(y - row0) * W + x) * 4;
             px[0] = tonemap(c.x);
             px[1] = tonemap(c.y);
@@ -1275,7 +1283,9 @@ bool mode_supported(int mode) { return mode >= VRT_MODE_INTERP && mode <= VRT_MO
 extern "C" {
 
 static uint32_t* g_steps_img = nullptr;
+static uint32_t* g_lead_img = nullptr;
 void vrto_debug_set_steps_image(uint32_t* img) { g_steps_img = img; }
+void vrto_debug_set_lead_image(uint32_t* img) { g_lead_img = img; }
 int vrto_debug_set_position_log(float* records, int capacity) {
     const int n = g_pos_log_n;
     g_pos_log = records;
@@ -1301,6 +1311,7 @@ int vrto_render(const vrt_scene* scene, const vrto_volume* volumes, const uint8_
         return VRT_ERR_INVALID;
     }
     P->steps_img = g_steps_img;
+    P->lead_img = g_lead_img;
     if (threads < 1) threads = 1;
     if (threads > rows && rows > 0) threads = rows;
     std::vector<Stats> st((size_t)threads);

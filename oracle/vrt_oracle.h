@@ -57,6 +57,9 @@ int vrto_render(const vrt_scene* scene, const vrto_volume* volumes,
  * or skipped) its primary ray visited (low 16 bits) and the rays after it visited (high 16 bits) into img (rows*width):
  * the length of the dependent chain a GPU lane runs for that pixel (tests/chain_lengths.py).  Not thread-safe. */
 void vrto_debug_set_steps_image(uint32_t* img);
+/* Debug: likewise, per pixel the number of positions its primary ray SKIPPED (empty-space leaps) before its first sample — the part of
+ * a lane's chain a per-tile beam pre-pass could take over (tests/chain_lengths.py beam).  Not thread-safe. */
+void vrto_debug_set_lead_image(uint32_t* img);
 /* Debug: while set, every march position of vrto_trace (single-threaded) appends {t, sample or NaN when skipped, leap, step
  * taken (negative: the over-relaxed march went back)} to records (4 floats each, at most capacity).  Returns the number of
  * records written since the previous call. */

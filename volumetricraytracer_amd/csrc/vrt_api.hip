@@ -783,7 +783,12 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p, bool own_scenes = fals
     if (p->mode < VRT_MODE_INTERP || p->mode > VRT_MODE_CUBE_NOTEX_UNLIT) return VRT_ERR_INVALID;
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_CELLS) return VRT_ERR_INVALID;
     /* (bit 5 was round 1's VRT_FLAG_SKIP_EMPTY: empty-space skipping is always on now; the bit is accepted and ignored) */
-    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_NO_TIMING | 32 | VRT_FLAG_BLOCK_PER_FRAME | VRT_FLAG_NO_CULL_RECT |
+#ifdef VRT_AB_TSTART
+    const int ab_bits = 3 << 20; /* A/B build: bit 20 record, bit 21 use (tools/beam_upper_bound.py) */
+#else
+    const int ab_bits = 0;
+#endif
+    if ((p->flags & ~ab_bits & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_NO_TIMING | 32 | VRT_FLAG_BLOCK_PER_FRAME | VRT_FLAG_NO_CULL_RECT |
                       VRT_FLAG_FULL_ONE_KERNEL | VRT_FLAG_FULL_THREE_PASS | VRT_FLAG_NO_HIT_POLISH | VRT_FLAG_OUTPUT_BGRA8)) != 0 || (p->flags & 3) == 3 ||
         ((p->flags & VRT_FLAG_OUTPUT_BGRA8) && !(p->flags & VRT_FLAG_OUTPUT_RGBA8)) ||
         ((p->flags & VRT_FLAG_FULL_ONE_KERNEL) && (p->flags & VRT_FLAG_FULL_THREE_PASS)))
@@ -1139,6 +1144,21 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
         F.hit_aux = reinterpret_cast<unsigned*>(base + D.pass_cap[slot] * sizeof(HitRecord) + D.pass_cap[slot] / 64 * sizeof(unsigned long long));
         F.rec_stride = (uint32_t)per_frame;
     }
+#ifdef VRT_AB_TSTART
+    {
+        static float* ab_buf = nullptr;
+        static size_t ab_cap = 0;
+        const size_t need = (size_t)n_frames * (size_t)D.last_blocks * 256;
+        if (ab_cap < need) {
+            if (ab_buf) (void)hipFree(ab_buf);
+            HIP_TRY(hipMalloc(&ab_buf, need * sizeof(float)));
+            HIP_TRY(hipMemset(ab_buf, 0, need * sizeof(float)));
+            ab_cap = need;
+        }
+        F.ab_tstart = ab_buf;
+        F.ab_mode = (p->flags >> 20) & 3;
+    }
+#endif
     D.last_diag = F.diag != 0;
     if (F.diag) {
         if (stat_blocks > (size_t)kMaxBlocks) return VRT_ERR_INVALID; /* the timeline buffer holds kMaxBlocks workgroups */

@@ -200,6 +200,11 @@ struct DFrame {
     const DCam* cams;          /* launches of more than kMaxBlockFrames frames: the frames' camera records in device memory (null: DBlock::cam) */
     uint32_t rec_stride;       /* records between the frames of a launch (= workgroups per frame * 256: four waves of 64 lanes) */
     int32_t may_bounce;        /* 1: bounces allowed and some material can mirror (smooth, or roughness from a texture) */
+#ifdef VRT_AB_TSTART           /* A/B build only (tools/beam_upper_bound.py): the upper bound of what ANY beam pre-pass could gain */
+    float* ab_tstart;          /* per lane of the launch: the ray parameter of the camera ray's first SAMPLED position */
+    int32_t ab_mode;           /* 1: record it; 2: start the camera ray's march there (its leading skips cost nothing) */
+    int32_t ab_pad_;
+#endif
     const void* dyn;           /* per-frame scene state (vrt_block::scenes): n_frames sections of kDynStride bytes in device memory, each a
                                   DDyn record followed by the frame's instances, BVH nodes, point and spot lights; null: every frame of the
                                   launch renders the scene in this struct.  Read by the DYN instantiations of the march kernels only */

@@ -683,6 +683,9 @@ struct MarchState {
     float chk;             /* over-relaxation (k_relax > 1): s_prev when the step that led to the current position was a stretched
                               one (the next sample checks the overlap of the two empty spheres), else +inf */
     Cell c;
+#ifdef VRT_AB_TSTART
+    float ab_first;        /* A/B build: t of the first sampled position, -1 = none yet */
+#endif
 };
 
 /*
@@ -705,6 +708,9 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
     Cell c = st.c;
     const bool tables = V.skip != nullptr;
     unsigned last_brick = 0xffffffffu, nibw = 0u;
+#ifdef VRT_AB_TSTART
+    float ab_first = st.ab_first;
+#endif
     while (i < limit && !(t > t_end)) {
         unsigned long long st0 = 0, st1 = 0;
         if constexpr (DIAG) st0 = stamp();
@@ -745,6 +751,9 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
             }
             const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
             steps++;
+#ifdef VRT_AB_TSTART
+            ab_first = ab_first < 0.0f ? t : ab_first;
+#endif
             /* Over-relaxation (k_relax > 1): when the step that led here was a stretched one (chk = the previous sample's
                empty radius, else +inf), the empty spheres around the two samples must overlap; if they do not, something
                may have been jumped over and the ray goes BACK to the previous sample's plain step (that sample stays the
@@ -774,6 +783,9 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
         }
         if constexpr (DIAG) dg->loop += stamp() - st0;
     }
+#ifdef VRT_AB_TSTART
+    st.ab_first = ab_first;
+#endif
     st.hit = t_end < R.t_end;
     st.t = t;
     st.t_prev = t_prev;
@@ -810,7 +822,15 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     st.hit = false;
     st.chk = __builtin_inff();
     st.c = Cell{0, 0, 0, 0.0f, 0.0f, 0.0f};
+#ifdef VRT_AB_TSTART
+    st.ab_first = -1.0f;
+    const size_t ab_idx = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    if (NORMAL != 0 && F.ab_mode == 2) st.t = st.t_prev = vmax(R.t0, F.ab_tstart[ab_idx]);
+#endif
     march_lane<DP, DIAG>(F, V, R, st, F.max_steps, steps, dg);
+#ifdef VRT_AB_TSTART
+    if (NORMAL != 0 && F.ab_mode == 1) F.ab_tstart[ab_idx] = st.ab_first >= 0.0f ? st.ab_first : st.t;
+#endif
     if (!st.hit) {
         if (F.max_steps > 0 && st.i >= F.max_steps && !(st.t > R.t_end)) ex += kExhaustedOne; /* budget ran out inside the volume: reported, treated as a miss */
         return false;
@@ -1990,6 +2010,9 @@ __device__ __forceinline__ bool march_hybrid(const DFrame& F, const VolRef& V, c
     st.hit = false;
     st.chk = __builtin_inff();
     st.c = Cell{0, 0, 0, 0.0f, 0.0f, 0.0f};
+#ifdef VRT_AB_TSTART
+    st.ab_first = -1.0f;
+#endif
     const int max_steps = F.max_steps;
     const int head = max_steps < kHeadSteps ? max_steps : kHeadSteps;
     if (act) march_lane<VRT_PATH_BRICK, false>(F, V, R, st, head, steps, nullptr);
