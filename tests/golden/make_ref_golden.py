@@ -24,7 +24,11 @@ import volumetricraytracer_amd as v  # noqa: E402
 
 TEXEL16, F32 = v._abi.FORMAT_TEXEL16, v._abi.FORMAT_F32
 
-# name: (scene builder, kwargs, width, height, row0, rows, shadow)
+def _mirror_scene(**kw):
+    return scenes.full_closest_hit_scene(**kw)
+
+
+# name: (scene builder, kwargs, width, height, row0, rows, shadow[, mirror bounces])
 CASES = {
     # the benched 256^3 Voxelizer shell (bench.py's config 3), whole frame at 320x180, on the field the reference's GPU
     # sees (its 16-bit texel) and on the unquantised floats
@@ -36,13 +40,16 @@ CASES = {
     "ref_c2sphere64_320x180": (scenes.config2_sphere, dict(resolution=6, env=16), 320, 180, 0, 180, False),
     # config 5 at reduced size: 8 instances (rotated, scaled) of a 32^3 CSG volume, shadow rays between instances
     "ref_c5inst32_320x180": (scenes.config5_instances, dict(resolution=5, env=16), 320, 180, 0, 180, True),
+    # the whole closest-hit shader: mirroring spheres (bounces to MAX_RAY_RECURSION_DEPTH), a point and a spot light with their shadow rays
+    "ref_fullhit64_320x180": (_mirror_scene, dict(resolution=6, env=32), 320, 180, 0, 180, True, 2),
 }
 
 
 def build_case(case):
-    fn, kw, w, h, row0, rows, shadow = case
+    fn, kw, w, h, row0, rows, shadow = case[:7]
     sc = fn(**kw)
     p = v.default_params(w, h, scenes.min_cell(sc), 255, shadow=shadow)
+    p.max_bounces = case[7] if len(case) > 7 else 0
     return sc, p, row0, rows
 
 

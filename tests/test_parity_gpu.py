@@ -188,6 +188,50 @@ def test_swapping_a_material_texture_reaches_the_device(oracle_lib):
         r.Stop()
 
 
+def test_scene_swap_with_more_textures_than_fit_together(oracle_lib):
+    """two scenes of 33 material textures each (11 volumes x albedo / normal / RM) given to ONE renderer in turn: the
+    old scene's images leave the device before the new ones arrive (66 > VRT_MAX_TEXTURES = 64 would not fit together), no slot
+    ever names a freed id, and every frame equals a fresh renderer's."""
+    def scene(seed):
+        rng = np.random.default_rng(seed)
+        objs = []
+        for k in range(11):
+            m = v.VMaterial(tuple(rng.uniform(0.3, 1.0, 3)) + (1.0,), 0.7, 0.1)
+            tex = []
+            for _ in range(3):
+                t = rng.integers(40, 255, size=(2, 3, 4), dtype=np.uint8)
+                t[..., 2] = 230
+                t[..., 3] = 255
+                tex.append(t)
+            m.AlbedoTexture, m.NormalTexture, m.RMTexture, m.TextureScale = tex[0], tex[1], tex[2], (17.0, 13.0)
+            vol = v.sphere_volume(3, 100.0, 60.0, m)
+            objs.append(v.VVoxelObject(Position=(0.0, (k - 5) * 70.0, (k % 3 - 1) * 80.0), Scale=(0.3, 0.3, 0.3), Volume=vol))
+        return v.VScene(Camera=v.look_minus_x_camera(500.0), DirectionalLight=v.demo_light(), Objects=objs, EnvironmentMap=v.procedural_skybox(8))
+
+    a, b = scene(1), scene(2)
+    p = v.default_params(240, 136, scenes.min_cell(a), 255, shadow=True, mode=_abi.MODE_INTERP)
+
+    def fresh(sc):
+        r2 = v.VHipRenderer()
+        assert r2.Start()
+        try:
+            return gpu_render(r2, sc, p)[0]
+        finally:
+            r2.Stop()
+
+    fa, fb = fresh(a), fresh(b)
+    assert not np.array_equal(fa, fb)
+    r = v.VHipRenderer()
+    assert r.Start()
+    try:
+        for sc, want in ((a, fa), (b, fb), (a, fa), (b, fb)):
+            got, _ = gpu_render(r, sc, p)
+            assert np.array_equal(got, want)
+            assert len(r._tex_ids) == 33 and max(r._tex_ids.values()) < _abi.VRT_MAX_TEXTURES
+    finally:
+        r.Stop()
+
+
 def test_texture_table_through_the_abi(oracle_lib):
     """vrt_texture_upload / vrt_texture_free / vrt_volume_set_textures: argument checks, replacing an image in place,
     freeing a bound texture (reads as unbound afterwards)."""
@@ -422,6 +466,8 @@ REF_PIXEL_BOUNDS = {
     "ref_c3vox256_texel16_1080p_rows492": (0.001, 0.001),
     "ref_c2sphere64_320x180": (0.0, 0.0),
     "ref_c5inst32_320x180": (0.0, 0.0),
+    # mirror bounces: the reflection of another object's silhouette lies INSIDE the mirror's own surface (measured 0.0073 / 0.0044)
+    "ref_fullhit64_320x180": (0.015, 0.01),
 }
 _ref_pixel_report = []
 

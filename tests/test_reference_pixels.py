@@ -36,6 +36,8 @@ BOUNDS = {
     "ref_c3vox256_texel16_1080p_rows492": (0.001, 0.001),
     "ref_c2sphere64_320x180": (0.0, 0.0),
     "ref_c5inst32_320x180": (0.0, 0.0),
+    # mirror bounces: the reflection of another object's silhouette lies INSIDE the mirror's own surface (measured 0.0073 / 0.0044)
+    "ref_fullhit64_320x180": (0.015, 0.01),
 }
 
 

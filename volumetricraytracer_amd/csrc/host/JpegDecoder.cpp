@@ -231,6 +231,9 @@ struct Decoder {
                 const int s = decode_symbol(br, dc[c.td]);
                 if (s < 0 || s > 11) return false;
                 c.pred += s ? extend(br.bits(s), s) : 0;
+                /* a DC value is an 11-bit difference accumulated over the blocks: T.81 keeps it within 12 bits for 8-bit samples; a
+                   damaged stream that walks it out of 16 bits is refused before the shift below could overflow */
+                if (c.pred < -32768 || c.pred > 32767) return false;
                 blk[0] = (int16_t)(c.pred * (1 << Al));
             } else if (br.bits(1)) {
                 blk[0] = (int16_t)(blk[0] | (1 << Al));
@@ -419,7 +422,8 @@ struct Decoder {
             }
             return;
         }
-        for (int y = 0; y < height; y++) /* any other ratio (and planes too narrow for the filters): replication */
+        for (int y = 0; y < height; y++) /* any other ratio (and planes too narrow for the filters): replication — 4:4:0 (chroma 1x2) among them, where
+                                            libjpeg-turbo uses its h1v2 triangle filter: byte parity with libjpeg is UNPINNED for that layout */
             for (int x = 0; x < width; x++) out[(size_t)y * width + x] = src[(size_t)(y / vs) * stride + x / hs];
     }
 
@@ -550,6 +554,9 @@ struct Decoder {
                         if (Ss == 0 && Ah == 0 && !dc[comp[sel[i]].td].present) return false;
                         if (Se > 0 && !ac[comp[sel[i]].ta].present) return false;
                     }
+                    /* every scan runs over the whole image: a crafted file with millions of tiny SOS segments would be a CPU-time bomb
+                       (libjpeg-turbo caps scans for the same reason; real progressive files have about ten) */
+                    if (scans >= 256) return false;
                     if (!decode_scan(data + pos + len, data + size, sel, nsel, Ss, Se, Ah, Al)) return false;
                     scans++;
                     /* on to the next marker behind the entropy-coded data (stuffed 0xFF00 and restart markers are part of it) */

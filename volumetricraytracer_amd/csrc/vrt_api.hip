@@ -190,6 +190,7 @@ struct DeviceState {
     hipStream_t copy_stream = nullptr;
     hipStream_t flight_stream = nullptr; /* vrt_render_begin: the marches of the frames in flight */
     hipEvent_t part_done = nullptr;
+    bool peer_to_first = false;  /* this device maps device 0's memory (hipDeviceEnablePeerAccess succeeded): the strided 2D gather copy may be used */
     int last_slot = 0;
     unsigned* d_diag = nullptr;  /* allocated on first use of VRT_FLAG_DIAG_TIMELINE (never in a capture) */
     int last_blocks = 0;         /* workgroups per frame of the last launch */
@@ -1207,7 +1208,8 @@ int vrt_create(vrt_ctx** out, int device_count, const int* devices) {
         int can = 0;
         if (hipDeviceCanAccessPeer(&can, ctx->dev[(size_t)i].ordinal, ctx->dev[0].ordinal) == hipSuccess && can) {
             (void)hipSetDevice(ctx->dev[(size_t)i].ordinal);
-            (void)hipDeviceEnablePeerAccess(ctx->dev[0].ordinal, 0);
+            const hipError_t e = hipDeviceEnablePeerAccess(ctx->dev[0].ordinal, 0);
+            ctx->dev[(size_t)i].peer_to_first = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
             (void)hipGetLastError();
         }
     }
@@ -1679,8 +1681,13 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
             while (whole < strips_per && ((whole * n + g) + 1) * kStripRows <= H) whole++;
             char* dst = reinterpret_cast<char*>(ctx->gather) + (size_t)g * strip_bytes;
             const char* src = reinterpret_cast<const char*>(D.fb);
-            if (whole > 0 && hipMemcpy2DAsync(dst, (size_t)n * strip_bytes, src, strip_bytes, strip_bytes, (size_t)whole, hipMemcpyDeviceToDevice,
-                                              D.stream) != hipSuccess) {
+            /* the strided 2D copy needs device 0's memory mapped into this device (checked at vrt_create: an asynchronous failure of an
+               unmapped peer copy would only surface at the final synchronise); VRT_GATHER_PER_STRIP=1 forces the per-strip path.
+               (Unverified on more than one physical GPU in any round: no multi-GPU box was available.) */
+            static const bool per_strip = getenv("VRT_GATHER_PER_STRIP") != nullptr;
+            const bool direct = !per_strip && (g == 0 || D.ordinal == ctx->dev[0].ordinal || D.peer_to_first);
+            if (whole > 0 && (!direct || hipMemcpy2DAsync(dst, (size_t)n * strip_bytes, src, strip_bytes, strip_bytes, (size_t)whole, hipMemcpyDeviceToDevice,
+                                                          D.stream) != hipSuccess)) {
                 (void)hipGetLastError(); /* no direct peer mapping between the two devices: strip by strip through hipMemcpyPeerAsync */
                 for (int k = 0; k < whole; k++)
                     HIP_TRY(hipMemcpyPeerAsync(dst + (size_t)k * n * strip_bytes, ctx->dev[0].ordinal, src + (size_t)k * strip_bytes, D.ordinal,

@@ -34,6 +34,7 @@ class VHipRenderer:
         self._env_id = None
         self._tex_ids: Dict[int, int] = {}   # id(image array) -> texture id on the device
         self._tex_keep: Dict[int, np.ndarray] = {}  # keeps the keyed arrays alive so id() stays unique
+        self._bound_tex: Dict[int, tuple] = {}  # slot -> the (albedo, normal, rm) texture ids bound to it
 
     # -- VRenderer surface -------------------------------------------------------------------
     def Start(self) -> bool:
@@ -56,6 +57,7 @@ class VHipRenderer:
             self._env_id = None
             self._tex_ids.clear()
             self._tex_keep.clear()
+            self._bound_tex.clear()
 
     def IsActive(self) -> bool:
         return bool(self._ctx)
@@ -86,6 +88,20 @@ class VHipRenderer:
         if sc is None:
             raise RuntimeError("SetSceneToRender was not called")
         vols = sc.volumes()
+        # Material textures no volume of the NEW scene names leave the device first — after every slot that still points at one of
+        # them has been un-bound (a slot must never name an id the next upload reuses) — so that a scene swap never needs the old
+        # and the new texture sets resident together (VRT_MAX_TEXTURES ids in all).
+        live = {id(t) for vol in vols for t in vol.Material.textures() if t is not None}
+        dead = {self._tex_ids[k] for k in self._tex_ids if k not in live}
+        if dead:
+            for slot, bound in list(self._bound_tex.items()):
+                if any(i in dead for i in bound):
+                    _abi.check(self._lib.vrt_volume_set_textures(self._ctx, slot, -1, -1, -1, 100.0, 100.0), "vrt_volume_set_textures")
+                    self._bound_tex[slot] = (-1, -1, -1)
+            for key in [k for k in self._tex_ids if k not in live]:
+                _abi.check(self._lib.vrt_texture_free(self._ctx, self._tex_ids[key]), "vrt_texture_free")
+                del self._tex_ids[key]
+                del self._tex_keep[key]
         for slot, vol in enumerate(vols):
             if self._uploaded.get(slot) != id(vol) or vol.dirty:
                 self.upload_volume(slot, vol)
@@ -97,14 +113,7 @@ class VHipRenderer:
         for slot in [s for s in self._uploaded if s >= len(vols)]:
             _abi.check(self._lib.vrt_volume_free(self._ctx, slot), "vrt_volume_free")
             del self._uploaded[slot]
-        # only now, with every slot bound to its current images: material textures no volume of the scene names any more leave
-        # the device (their ids are handed out again), so a renderer that is given scene after scene does not run out of the
-        # VRT_MAX_TEXTURES slots.  (Freeing first would leave a slot pointing at an id that the next upload reuses.)
-        live = {id(t) for vol in vols for t in vol.Material.textures() if t is not None}
-        for key in [k for k in self._tex_ids if k not in live]:
-            _abi.check(self._lib.vrt_texture_free(self._ctx, self._tex_ids[key]), "vrt_texture_free")
-            del self._tex_ids[key]
-            del self._tex_keep[key]
+            self._bound_tex.pop(slot, None)
         env = sc.EnvironmentMap
         if env is None:
             if self._env_id is not None:
@@ -151,6 +160,7 @@ class VHipRenderer:
         ids = [self.upload_texture(t) if t is not None else -1 for t in vol.Material.textures()]
         _abi.check(self._lib.vrt_volume_set_textures(self._ctx, slot, ids[0], ids[1], ids[2], float(vol.Material.TextureScale[0]),
                                                      float(vol.Material.TextureScale[1])), "vrt_volume_set_textures")
+        self._bound_tex[slot] = tuple(ids)
 
     def voxelize_mesh(self, slot: int, positions: np.ndarray, indices: np.ndarray, resolution: int, extent: float) -> int:
         """The Voxelizer's hot loop on the device (vrt_voxelize_mesh): fills `slot` with the shell field of a
