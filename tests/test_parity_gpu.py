@@ -962,13 +962,20 @@ def test_bench_one_gpu_line_has_the_contract_fields(oracle_lib):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frames_per_launch"] == 96
-    # one stream, ONE launch per 96-frame step: the launch's duration is the step's
-    assert 0.85 < r["kernel_ms"] / o["ms_per_step"] <= 1.02
+    # one stream, ONE launch per 96 frames, 30 launches per step (a step is ~0.11 s): the launches' durations add up to the step's
+    assert o["config"]["launches_per_step"] == 30 and o["config"]["frames_per_step"] == 2880 and o["ms_per_step"] > 60.0
+    assert 0.85 < r["kernel_ms"] * o["config"]["launches_per_step"] / o["ms_per_step"] <= 1.02
+    # the roof the kernel is under: its samples per second against the measured L1 gather ceiling (frac counts cache-served taps)
+    assert 0.3 < r["limiter_frac"] < 1.3 and abs(r["limiter_frac"] - r["gsamples_per_s"] / r["limiter_ceiling_gsamples_per_s"]) < 1e-3
     # value = rays of the batch x steps / time
     assert abs(o["value"] - o["config"]["rays_per_step"] / (o["ms_per_step"] * 1e-3) / 1e6) / o["value"] < 0.01
     c = o["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["chain_positions_max"] > 50
-    assert o["latency"]["ms_per_frame"] > o["ms_per_step"] / 96 and o["scale_anchor"]["value"] > 0 and o["end_to_end"]["value"] > 0
+    assert o["latency"]["ms_per_frame"] > o["ms_per_frame"] and o["scale_anchor"]["value"] > 0 and o["end_to_end"]["value"] > 0
+    d = o["dynamic_scene"]
+    assert d["per_frame_scenes"]["launches_per_batch"] == 1 and d["per_frame_over_static"] > 0.85  # per-frame scene state: ONE launch, close to the standing scene
+    fc = o["full_coverage"]
+    assert fc["waves_marching"] > 0.85 * fc["waves"] and fc["samples_per_ray"] > o["config"]["samples_per_ray"] and fc["value"] > 0
     assert o["config4"]["value"] > 0 and o["config4"]["scale_anchor"]["value"] > 0
     assert 0 < o["config"]["marching"]["primary_rays_in_marching_waves"] < o["config"]["marching"]["primary_rays"] == 1920 * 1080
 
