@@ -50,9 +50,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
-# tools/microbench/gather.hip on MI355X (profiles/r01_gather_microbench.txt): trilinear samples/s the chip sustains for
+# tools/microbench/gather.hip / gather16.hip on MI355X (re-measured on the round-4 build: profiles/r04_gather_microbench.txt): trilinear samples/s the chip sustains for
 # 4 x dwordx2 taps per lane at random cells, by where the bricks live
-GATHER_CEILING_GSAMPLES = {"l1": 264.0, "l2": 209.0, "mall_hbm": 126.0, "l1_int16": 295.0}
+GATHER_CEILING_GSAMPLES = {"l1": 264.0, "l2": 209.0, "mall_hbm": 126.0, "l1_int16": 298.0}
 
 
 def parse_args(argv=None):
