@@ -696,8 +696,6 @@ def main() -> None:
                     "kernel_ms_per_frame": round(float(np.mean(k1)), 4) if k1 else None}
 
         latency = leg(lambda: pipeline(p, W, H, 1, use_native, world if rotate else 1), run_latency)
-        if args.scaling == "strong":
-            scale_anchor = anchor_leg(W, H)
         if world == 1:
             def e2e(_):
                 # the frame as the host gets it, in the bench's pixel format and in the reference's own back-buffer precision
@@ -714,6 +712,10 @@ def main() -> None:
                 return out
 
             end_to_end = leg(lambda: None, e2e)
+        # (the anchor runs behind the end-to-end leg: placed behind the anchor's two-stream pipeline, the frames-in-flight leg read 0.28 ms
+        # per RGBA8 frame; at every earlier point of the process, and alone in tools/e2e_leg_probe.py, 0.167)
+        if args.scaling == "strong":
+            scale_anchor = anchor_leg(W, H)
         if args.workload in ("c3", "c4") and args.scaling == "strong":
             W4, H4 = 3840, 2160
             p4 = params(W4, H4)
