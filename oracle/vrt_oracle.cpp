@@ -6,7 +6,9 @@
  * fmaf() where the march contract says so.
  *
  * PARITY UNPINNED by reference tests (the reference has none); pinned by
- * analytic ground truth and by vrto_ref_hit_t below.
+ * analytic ground truth, by vrto_ref_hit_t and — frames, not just hit distances — by vrto_ref_render below: a second,
+ * independent restatement of the reference's OWN intersection (cell walk + exact cubic root + normal at the root) whose
+ * frames the sphere-trace's frames must equal in the reference's 8-bit colours (tests/test_reference_pixels.py).
  *
  * Reference lines each function follows (paths relative to
  * /root/reference/VolumetricRaytracer/VolumetricRaytracer/, SH = Renderer/DX/Resources/Shaders):

@@ -10,7 +10,8 @@
  *  and its hot path (HLSL/DXR + D3D12) cannot be built or run here.
  * The oracle is therefore pinned by analytic ground truth (ray∩sphere, plane, box) and by
  * a restatement of the reference's own per-cell cubic iso-surface solve (vrto_ref_hit_t,
- * Voxel.hlsli:552-605,691-781) — see tests/test_oracle_*.py.
+ * Voxel.hlsli:552-605,691-781) and, since round 4, by whole frames rendered with the reference's own
+ * intersection (vrto_ref_render) — see tests/test_oracle_pins.py, tests/test_reference_pixels.py.
  */
 #ifndef VRT_ORACLE_H
 #define VRT_ORACLE_H
