@@ -523,6 +523,22 @@ def main() -> None:
                 idt.copy_(torch.frombuffer(bytearray(v.VHipRenderer.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, 0)
             r.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
+            # the product's exchange on a few bytes before the run stands on it (it has never run on N > 1 GPUs in any round): chunk d
+            # of my buffer goes to rank d (vrt_exchange_tiles), every rank's tile lands rank-major on rank 0 (vrt_gather_tiles)
+            cb = 64
+            snd = (torch.arange(world, dtype=torch.int32, device=dev)[:, None] + 16 * rank).to(torch.uint8).expand(world, cb).contiguous()
+            rcv = torch.zeros_like(snd)
+            st0 = torch.cuda.current_stream().cuda_stream
+            r.exchange_tiles(snd.data_ptr(), rcv.data_ptr(), cb, st0)
+            tile = torch.full((cb,), 100 + rank, dtype=torch.uint8, device=dev)
+            got = torch.zeros((world, cb), dtype=torch.uint8, device=dev)
+            r.gather_tiles(tile.data_ptr(), got.data_ptr() if rank == 0 else 0, cb, 0, st0)
+            torch.cuda.synchronize()
+            want = (16 * torch.arange(world, dtype=torch.int32)[:, None] + rank).to(torch.uint8).expand(world, cb)
+            ok_x = bool((rcv.cpu() == want).all())
+            ok_g = rank != 0 or bool((got.cpu() == (100 + torch.arange(world, dtype=torch.int32))[:, None].to(torch.uint8)).all())
+            if not (ok_x and ok_g):
+                raise RuntimeError(f"native exchange probe delivered wrong bytes (exchange ok {ok_x}, gather ok {ok_g})")
             native_ready = True
         except Exception as e:  # reported, never fatal: torch.distributed remains
             native_error = repr(e)

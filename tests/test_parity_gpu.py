@@ -931,6 +931,10 @@ def test_bench_two_rank_rehearsal(oracle_lib):
     assert "all-to-all" in out["config"]["parallelism"] and out["config"]["frames_per_launch"] == 48 and out["config"]["streams"] == 2
     assert "gather" in out["other_exchange"]["exchange"] and out["other_exchange"]["last_frame_equals_single_gpu_frame"] is True
     assert out["scale_anchor"]["value"] > 0 and out["scale_anchor"]["n_gpus"] == 1 and out["speedup_vs_anchor"] > 0
+    # the N > 1 line's account of the exchange (round 4): both exchanges with their speed-up over the anchor, the link model's cap
+    assert set(out["exchanges"]) == {"rotate", "gather"} and out["exchanges"]["rotate"]["main_line"] and out["exchanges"]["rotate"]["value"] == out["value"]
+    assert out["exchanges"]["gather"]["value"] == out["other_exchange"]["value"] and out["link_model"]["gather_to_rank0_cap_Mrays_per_s"] > 0
+    assert out["north_star_6x_at_8_gpus"] is None  # (a statement about 8 GPUs only)
     # a rank count that does not match --gpus is refused, not silently measured
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env2, capture_output=True,
