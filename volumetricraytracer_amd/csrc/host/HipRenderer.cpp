@@ -542,9 +542,9 @@ vrt_params VHipRenderer::MakeParams(Scene::VScene& scene) const {
     p.mode = (int)RenderMode;
     p.path = DataPath;
     p.max_bounces = MaxBounces;
-    p.eps_hit = 0.004f * MinCell;
+    p.eps_hit = std::min(0.004f * MinCell, 0.02f); /* at most a fifth of the secondary rays' 0.1 offset (Raytracing.hlsl:52): coarse volumes */
     p.eps_in = 0.01f; /* Raytracing.hlsl:178 */
-    p.step_min = 0.004f * MinCell;
+    p.step_min = std::min(0.004f * MinCell, 0.02f);
     p.k_relax = Relaxation;
     const VObjectPtr<Scene::VCamera> cam = scene.GetActiveCamera();
     p.cone_eps = std::tan((cam ? cam->FOVAngle : 60.f) * (3.14159265358979323846f / 180.0f) * 0.5f) / (float)Height;

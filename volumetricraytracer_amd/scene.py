@@ -498,7 +498,10 @@ def default_params(width: int, height: int, cell: float, max_steps: int = 128, s
                    mode: int = _abi.MODE_INTERP_NOTEX, path: int = _abi.PATH_AUTO, fov_deg: float = 60.0,
                    cone: bool = True, k_relax: float = 1.7) -> _abi.vrt_params:
     """March contract defaults: hit threshold and minimum step are 0.4 % of a cell at
-    the ray origin and grow with the pixel footprint (angular pixel radius tan(fov/2)/height)."""
+    the ray origin — at most 0.02, a fifth of the 0.1 the reference backs its secondary rays off the hit
+    (Raytracing.hlsl:52): in a coarse volume (resolution <= 4: cells of 12 units and more) 0.4 % of a cell is that
+    very offset, and every shadow ray would "hit" the surface it starts on — and grow with the pixel footprint
+    (angular pixel radius tan(fov/2)/height)."""
     p = _abi.vrt_params()
     p.width, p.height = int(width), int(height)
     p.max_steps = int(max_steps)
@@ -507,9 +510,9 @@ def default_params(width: int, height: int, cell: float, max_steps: int = 128, s
     p.path = int(path)
     p.max_bounces = 0
     p.flags = 0
-    p.eps_hit = float(np.float32(0.004 * cell))
+    p.eps_hit = float(np.float32(min(0.004 * cell, 0.02)))
     p.eps_in = 0.01  # Raytracing.hlsl:178
-    p.step_min = float(np.float32(0.004 * cell))
+    p.step_min = float(np.float32(min(0.004 * cell, 0.02)))
     p.k_relax = float(k_relax)  # > 1: over-relaxed sphere-trace with the sphere-overlap fallback
     p.cone_eps = float(np.float32(math.tan(math.radians(fov_deg) * 0.5) / height)) if cone else 0.0
     return p
