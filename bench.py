@@ -60,7 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3sdf", "c3light", "c4", "c5"],
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3sdf", "c3light", "c3cover", "c4", "c5"],
                     help="c3 = BASELINE config 3 (the metric); c3light = the same with one point light: the full closest-hit kernel "
                          "(the reference's default render mode once a scene has a point light)")
     ap.add_argument("--path", default="auto", choices=["auto", "dense", "brick", "lds", "cells"])
@@ -144,6 +144,13 @@ def build_workload(name: str):
         sc = copy.copy(workloads.bench_config3())
         sc.PointLights = [v.VPointLight(Position=(120.0, 60.0, 140.0), Color=(1.0, 0.9, 0.8, 1.0), IlluminationStrength=40.0)]
         return sc, 1920, 1080, 255, True, "config3 + one point light: 256^3 voxelized mesh, 1920x1080, directional + point light with their shadow rays (full closest-hit kernel)"
+    if name == "c3cover":
+        # config 3's volume with the camera INSIDE its box, 0.6 extents from the centre: every wave marches (the `full_coverage` leg as a workload
+        # of its own, for the profiler)
+        base = workloads.bench_config3()
+        sc = workloads.config3_voxelized(8, 256, distance=0.6 * float(base.volumes()[0].VolumeExtends))
+        sc.Objects[0].Volume = base.volumes()[0]
+        return sc, 1920, 1080, 255, True, "config3's 256^3 voxelized mesh, camera inside the volume's box (every wave marches), 1920x1080, shadow ray on"
     if name == "c3sdf":
         sc = workloads.config3_torus(8, 256, distance=190.0)
         return sc, 1920, 1080, 255, True, "config3 (analytic SDF variant): 256^3 torus SDF, 1920x1080, shadow ray on"
