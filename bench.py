@@ -983,6 +983,9 @@ def main() -> None:
                 "occupancy_mean_waves_per_cu": pmc.get("occupancy_mean_waves_per_cu"),
                 # busy cycles of the texture path's two units summed over the CUs / 256 / the launch's GPU cycles (in the counters' own run)
                 "td_busy_frac": pmc.get("td_busy_frac"), "ta_busy_frac": pmc.get("ta_busy_frac"),
+                # cache-line accesses the L1 (TCP) serves per CU and cycle (TCP_TOTAL_CACHE_ACCESSES_sum / 256 CUs / GPU cycles): the
+                # vector L1 looks up about one line per cycle — 0.82 on config 3, 0.89 with every wave marching — and its share that goes on to L2
+                "l1_cache_line_accesses_per_cu_cycle": pmc.get("l1_cache_line_accesses_per_cu_cycle"),
                 "valu_lane_utilisation": pmc.get("valu_lane_utilisation"),
                 "counters_from": pmc.get("tag"),
             })
