@@ -36,10 +36,14 @@ CASES = {
     "ref_c3vox256_f32_320x180": (scenes.config3_voxelized, dict(resolution=8, env=64, device_format=F32), 320, 180, 0, 180, True),
     # the same volume at the BENCHED frame size, 1920x1080: a band of 96 rows through the torus
     "ref_c3vox256_texel16_1080p_rows492": (scenes.config3_voxelized, dict(resolution=8, env=64, device_format=TEXEL16), 1920, 1080, 492, 96, True),
+    # BASELINE config 4's frame size, 3840x2160: a band of 48 rows through the torus
+    "ref_c3vox256_texel16_2160p_rows1040": (scenes.config3_voxelized, dict(resolution=8, env=64, device_format=TEXEL16), 3840, 2160, 1040, 48, True),
     # config 2: the demo's 64^3 sphere
     "ref_c2sphere64_320x180": (scenes.config2_sphere, dict(resolution=6, env=16), 320, 180, 0, 180, False),
     # config 5 at reduced size: 8 instances (rotated, scaled) of a 32^3 CSG volume, shadow rays between instances
     "ref_c5inst32_320x180": (scenes.config5_instances, dict(resolution=5, env=16), 320, 180, 0, 180, True),
+    # BASELINE config 5 at its real size (8 instances of a 128^3 CSG volume, BVH), 1920x1080: a band of 64 rows through four of them
+    "ref_c5inst128_1080p_rows300": (scenes.config5_instances, dict(resolution=7, env=16), 1920, 1080, 300, 64, True),
     # the whole closest-hit shader: mirroring spheres (bounces to MAX_RAY_RECURSION_DEPTH), a point and a spot light with their shadow rays
     "ref_fullhit64_320x180": (_mirror_scene, dict(resolution=6, env=32), 320, 180, 0, 180, True, 2),
 }

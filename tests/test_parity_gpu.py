@@ -464,6 +464,8 @@ REF_PIXEL_BOUNDS = {
     "ref_c3vox256_texel16_320x180": (0.002, 0.002),
     "ref_c3vox256_f32_320x180": (0.002, 0.002),
     "ref_c3vox256_texel16_1080p_rows492": (0.001, 0.001),
+    "ref_c3vox256_texel16_2160p_rows1040": (0.001, 0.001),   # config 4's frame size (measured 0.00014; rounds 1-3: 0.094)
+    "ref_c5inst128_1080p_rows300": (0.0005, 0.0005),          # config 5 at its real size (measured 0.00005 = one pixel; rounds 1-3: 0.024)
     "ref_c2sphere64_320x180": (0.0, 0.0),
     "ref_c5inst32_320x180": (0.0, 0.0),
     # mirror bounces: the reflection of another object's silhouette lies INSIDE the mirror's own surface (measured 0.0073 / 0.0044)
