@@ -498,7 +498,9 @@ def test_hip_frame_is_the_reference_frame(renderer, name):
         m = ref_pixels.compare(img[row0:row0 + rows], name)
         _ref_pixel_report.append((name, k_relax, m))
         print("ref-pixels", name, "k_relax", k_relax, m)
-        assert m["interior_pixels"] > 1000 and t["exhausted_rays"] == 0
+        # (no march runs out of its 255 positions with the default over-relaxation; plain sphere tracing at 3840x2160 — footprints of a
+        # twentieth of a cell — leaves a few dozen grazing rays of 8.3 M short, counted as misses: §3.5)
+        assert m["interior_pixels"] > 1000 and t["exhausted_rays"] <= (0 if k_relax > 1.0 else 100)
         assert m["gt1"] <= gt1 and m["gt2"] <= gt2, (k_relax, m)
         assert m["frame_gt1"] <= 0.01, (k_relax, m)
     # the 8-bit target the reference presents (VRT_FLAG_OUTPUT_RGBA8) holds exactly the quantised float frame
