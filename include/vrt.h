@@ -298,7 +298,9 @@ int vrt_render(vrt_ctx* ctx, const vrt_params* params, float* host_rgba_or_null)
  * the stream you are going to capture on makes the launch safe to capture into a hipGraph.  Counter buffers are
  * never freed before vrt_destroy, so a captured launch stays replayable after later, larger launches; it must be
  * re-captured after vrt_volume_upload* / vrt_volume_free / vrt_texture_* / a vrt_env_upload of another size /
- * vrt_scene_set (they replace device buffers or arrays the launch dereferences).  Up to 16 streams may have
+ * vrt_scene_set (they replace device buffers or arrays the launch dereferences).  A vrt_scene_set made WHILE frames are in flight
+ * (vrt_render_begin) defers its small device copies to the next launch that needs them: that launch must not be a captured one
+ * (VRT_ERR_NOT_READY) — the un-captured launch ahead of a capture covers it.  Up to 16 streams may have
  * launches in flight at once (the reference keeps 3 frames in flight, DXConstants.cpp:23): each stream has its
  * own counter buffer, each launch its own event pair. */
 int vrt_render_rows(vrt_ctx* ctx, const vrt_params* params, int row0, int rows,
