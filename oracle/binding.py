@@ -17,7 +17,8 @@ from volumetricraytracer_amd import _abi
 from volumetricraytracer_amd.scene import VScene
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libvrt_oracle.so")
+# VRT_ORACLE_LIB: another build of the same oracle (the sanitizer build of `make -C oracle asan`)
+LIB_PATH = os.environ.get("VRT_ORACLE_LIB") or os.path.join(_HERE, "_build", "libvrt_oracle.so")
 
 
 class vrto_texture(C.Structure):
