@@ -1560,8 +1560,8 @@ int vrt_render_block(vrt_ctx* ctx, const vrt_params* params, const vrt_block* bl
 int vrt_render_block_host(vrt_ctx* ctx, const vrt_params* params, const vrt_block* block, const void** host_frames) {
     if (!ctx || !params || !block || !host_frames || ctx->dev.size() != 1) return VRT_ERR_INVALID;
     if (params->width <= 0 || params->height <= 0 || block->n_frames < 1 || block->n_frames > kMaxLaunchFrames) return VRT_ERR_INVALID;
-    const int rows = block->strip_rows > 0 ? block->n_strips * block->strip_rows : block->rows;
-    if (rows < 0 || rows > 16384) return VRT_ERR_INVALID;
+    const long long rows = block->strip_rows > 0 ? (long long)block->n_strips * block->strip_rows : (long long)block->rows;
+    if (block->n_strips < 0 || rows < 0 || rows > 16384) return VRT_ERR_INVALID;
     const size_t frame_bytes = (size_t)rows * (size_t)params->width * ((params->flags & VRT_FLAG_OUTPUT_RGBA8) ? 4 : 16);
     const size_t need = std::max<size_t>(frame_bytes * (size_t)block->n_frames, 16);
     if (need > ((size_t)4 << 30)) return VRT_ERR_INVALID;
