@@ -1853,6 +1853,8 @@ def test_cpp_host_adaptor_renders_the_demo_scene(renderer, tmp_path):
                   Objects=[v.VVoxelObject(Position=(200.0, 0.0, 100.0), Volume=v.sphere_volume(6, 100.0, 40.0, mat((1, 0, 0, 1)))),
                            v.VVoxelObject(Position=(100.0, 0.0, 200.0), Volume=v.sphere_volume(6, 100.0, 20.0, mat((0, 0, 1, 1))))],
                   EnvironmentMap=env)
+    for vol in sc.volumes():
+        vol.set_device_format(_abi.FORMAT_TEXEL16)  # the C++ adaptor's default: the reference's own volume texel
     renderer.SetSceneToRender(sc)
     renderer.ResizeRenderOutput(320, 180)
     renderer.params_override = None
@@ -1915,6 +1917,8 @@ def test_cpp_host_adaptor_binds_material_textures_from_a_vox_scene(renderer, tmp
                            v.VVoxelObject(Position=(200.0, 0.0, 100.0), Volume=v.sphere_volume(6, 100.0, 40.0, mat((1, 0, 0, 1)))),
                            v.VVoxelObject(Position=(100.0, 0.0, 200.0), Volume=v.sphere_volume(6, 100.0, 20.0, mat((0, 0, 1, 1))))],
                   EnvironmentMap=env)
+    for vol in sc.volumes():
+        vol.set_device_format(_abi.FORMAT_TEXEL16)  # the C++ adaptor's default
     r2 = v.VHipRenderer()
     assert r2.Start()
     try:
