@@ -51,8 +51,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
 # tools/microbench/gather.hip / gather16.hip on MI355X (re-measured on the round-4 build: profiles/r04_gather_microbench.txt): trilinear samples/s the chip sustains for
-# 4 x dwordx2 taps per lane at random cells, by where the bricks live
-GATHER_CEILING_GSAMPLES = {"l1": 264.0, "l2": 209.0, "mall_hbm": 126.0, "l1_int16": 298.0}
+# 4 x dwordx2 taps per lane at random cells, by where the bricks live; l1_coherent_lanes: the same with the 64 lanes of a wave on the 3x3 cells
+# an 8x8-pixel tile covers (lanes that share a cell share its lines; 552 / 561 / 540 from L1 / L2 / the 256^3 pool)
+GATHER_CEILING_GSAMPLES = {"l1": 264.0, "l2": 209.0, "mall_hbm": 126.0, "l1_int16": 298.0, "l1_coherent_lanes": 552.0}
 
 
 def parse_args(argv=None):
@@ -933,8 +934,10 @@ def main() -> None:
                     "hits_per_frame": int(tot["hits"] / B), "frames_per_launch": B}
             if kc:
                 gs = samples_c / (float(np.mean(kc)) * 1e-3) / 1e9
-                outc.update({"kernel_ms_per_launch": round(float(np.mean(kc)), 4), "gsamples_per_s": round(gs, 2),
-                             "limiter_frac": round(gs / GATHER_CEILING_GSAMPLES["l1_int16" if fmt == _abi.FORMAT_TEXEL16 else "l1"], 4),
+                ge = (samples_c + 6.0 * tot["hits"]) / (float(np.mean(kc)) * 1e-3) / 1e9  # + the 6 trilinear evaluations of every hit's normal
+                outc.update({"kernel_ms_per_launch": round(float(np.mean(kc)), 4), "gsamples_per_s": round(gs, 2), "gevaluations_per_s": round(ge, 2),
+                             "limiter_frac": round(ge / GATHER_CEILING_GSAMPLES["l1_int16" if fmt == _abi.FORMAT_TEXEL16 else "l1"], 4),
+                             "limiter_frac_coherent_lanes": round(ge / GATHER_CEILING_GSAMPLES["l1_coherent_lanes"], 4),
                              "roofline_frac_algorithmic": round(v.algorithmic_bytes({k: tot[k] for k in KEYS}, 16) / (float(np.mean(kc)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
             return outc
 
@@ -948,6 +951,7 @@ def main() -> None:
         k_ms = float(np.mean(kms)) if kms else float("nan")
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if kms else 0.0
         samples = int(t["primary_steps"] + t["shadow_steps"]) * fpl
+        evals = samples + int(6 * t["hits"]) * fpl
         psteps, ssteps = cnt["primary_steps"], cnt["shadow_steps"]
         key = traffic_key(args, world, K, G, rgba8)
         pmc = measured_counters(key)
@@ -974,10 +978,16 @@ def main() -> None:
             # 96 % of the march's taps are L1 hits.  `frac` above counts cache-served taps as HBM bytes (the contract's algorithmic
             # bytes): it says how many samples the kernel takes, not how many bytes cross the HBM interface, and MAY EXCEED 1.
             "limiter": "L1-served trilinear gather (texture path: td_busy_frac is its busy fraction from the PMC counters)",
-            "limiter_frac": round(samples / (k_ms * 1e-3) / 1e9 / GATHER_CEILING_GSAMPLES[gather_key], 4) if kms else None,
+            # every trilinear evaluation the launch makes — march and polish samples AND the 6 of every hit's normal (SURVEY §8d counts them:
+            # 192 B per hit) — per second, against the ceiling
+            "trilinear_evaluations_per_launch": evals,
+            "gevaluations_per_s": round(evals / (k_ms * 1e-3) / 1e9, 2) if kms else None,
+            "limiter_frac": round(evals / (k_ms * 1e-3) / 1e9 / GATHER_CEILING_GSAMPLES[gather_key], 4) if kms else None,
+            # ... and against the ceiling of a gather whose 64 lanes sit on the 3x3 cells of an 8x8-pixel tile (the march's lanes lie between the two)
+            "limiter_frac_coherent_lanes": round(evals / (k_ms * 1e-3) / 1e9 / GATHER_CEILING_GSAMPLES["l1_coherent_lanes"], 4) if kms else None,
             "limiter_ceiling_gsamples_per_s": GATHER_CEILING_GSAMPLES[gather_key],
             "frac_note": "frac = algorithmic bytes (32 B per sample, cache-served or not) / launch time / 8 TB/s: an accounting of samples; it may exceed 1. "
-                         "limiter_frac is the fraction of the measured roof; hbm_measured_frac the physical HBM share",
+                         "limiter_frac = trilinear evaluations (samples + 6 per hit normal) per second / the measured L1 gather ceiling; hbm_measured_frac the physical HBM share",
         }
         if pmc and kms:
             # physical picture, from the keyed PMC passes (profiles/counters_latest.json: tools/r03_profile.sh on this kernel source

@@ -36,6 +36,32 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ b
     out[gid] = acc;
 }
 
+// The same sample with the lanes of a wave COHERENT, like the 64 rays of an 8x8-pixel tile near a surface: one wave-uniform pseudo-random
+// base cell per iteration, lane (i, j) of the 8x8 tile samples the cell 3i/8, 3j/8 cells further along x and z (the tile spans 3x3 cells;
+// cells beyond the brick's edge fall into the next brick).  Lanes that share a cell share its lines: the L1 looks up fewer lines per
+// instruction than for independent cells — the ceiling a march with coherent lanes runs against.
+__global__ __launch_bounds__(256) void gather_tile_kernel(const float* __restrict__ bricks, unsigned nbricks_mask, int iters, float* __restrict__ out) {
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned state = (gid >> 6) * 2654435761u + 12345u;  // wave-uniform sequence
+    unsigned brick = (gid >> 6) * 97u;
+    const unsigned ox = ((lane & 7u) * 3u) >> 3, oz = ((lane >> 3) * 3u) >> 3;
+    float acc = 0.0f;
+    const float fx = 0.3f, fy = 0.6f, fz = 0.2f;
+    for (int i = 0; i < iters; i++) {
+        state = state * 1664525u + 1013904223u;
+        const unsigned bx = (state >> 8) & 3u, ly = (state >> 12) & 3u, bz = (state >> 16) & 3u;
+        if (((state >> 20) & 7u) == 0u) brick += 1u + ((state >> 24) & 3u);
+        const unsigned cx = bx + ox, cz = bz + oz;
+        const unsigned b = (brick + (cx >> 2) * 17u + (cz >> 2) * 5u) & nbricks_mask;  // a neighbouring brick past the edge
+        const float* p = bricks + ((size_t)b << 7) + ((cx & 3u) * 25u + (cz & 3u) * 5u + ly);
+        const float y00a = p[0], y00b = p[1], y01a = p[5], y01b = p[6], y10a = p[25], y10b = p[26], y11a = p[30], y11b = p[31];
+        const float a00 = lerp1(y00a, y00b, fy), a01 = lerp1(y01a, y01b, fy), a10 = lerp1(y10a, y10b, fy), a11 = lerp1(y11a, y11b, fy);
+        acc += lerp1(lerp1(a00, a01, fz), lerp1(a10, a11, fz), fx);
+    }
+    out[gid] = acc;
+}
+
 // The same sample from a "cell record" layout: every cell stores its own 8 corner values contiguously (32 B, 8x the
 // memory of the shared-corner bricks) and is read with 2 x dwordx4.  Half the vector-memory instructions per sample.
 template <bool WITH_ALU>
@@ -118,6 +144,21 @@ int main(int argc, char** argv) {
             const double samples = (double)blocks * threads * iters;
             printf("%-58s %-9s %8.3f ms  %7.1f Gsamples/s  %6.2f TB/s (32 B/sample)\n", c.name, alu ? "taps+lerp" : "taps only", best,
                    samples / best / 1e6, samples * 32 / best / 1e9);
+        }
+        {   // coherent lanes (an 8x8 tile over 3x3 cells)
+            float best = 1e30f;
+            for (int rep = 0; rep < 5; rep++) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(gather_tile_kernel, dim3(blocks), dim3(threads), 0, 0, bricks, c.nbricks - 1, iters, out);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < best) best = ms;
+            }
+            const double samples = (double)blocks * threads * iters;
+            printf("  the same with COHERENT lanes (8x8 tile over 3x3 cells)    %-9s %8.3f ms  %7.1f Gsamples/s  %6.2f TB/s (32 B/sample)\n", "taps+lerp",
+                   best, samples / best / 1e6, samples * 32 / best / 1e9);
         }
         hipFree(bricks);
         // cell records: same number of bricks, 2 KB each
