@@ -584,6 +584,10 @@ thread_local uint64_t g_exhausted = 0;
    rays that follow it [1] — what the length of a GPU lane's dependent chain is made of */
 thread_local uint64_t g_positions[2] = {0, 0};
 thread_local int g_ray_class = 0;
+/* study only (vrto_debug_unnormalised_offsets): the reference does not normalise its camera direction (Ray.hlsli:44-45), so its 0.1 back-off of
+   the camera ray's secondary rays is 0.1 * |direction| (1 ... 1.5 towards the frame's corners); 1 everywhere else */
+thread_local float g_dir_scale = 1.0f;
+bool g_unnormalised_offsets = false;
 /* debug only (vrto_debug_set_lead_image): positions the primary ray SKIPPED before its first sample — what a beam pre-pass could take over */
 thread_local uint64_t g_leading_skips = 0;
 /* debug only (vrto_debug_set_position_log): one record {t, s or NaN when skipped, leap, step taken} per position */
@@ -1143,7 +1147,7 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
         return albedo;
 
     /* secondary rays start 0.1 back along the ray (Raytracing.hlsl:52), 0.2 in the Cube modes (Raytracing_Cube.hlsl:52) */
-    const float back = mode >= VRT_MODE_CUBE ? 0.2f : 0.1f;
+    const float back = (mode >= VRT_MODE_CUBE ? 0.2f : 0.1f) * g_dir_scale; /* g_dir_scale: 1, or (study only) |un-normalised camera direction| */
     V3 so = v3(hit_pos.x - d.x * back, hit_pos.y - d.y * back, hit_pos.z - d.z * back);
     V3 wo = v3(-d.x, -d.y, -d.z);
     bool shadows = level < MAX_DEPTH; /* TraceShadowRay's recursion guard, Ray.hlsli:83-86 */
@@ -1234,7 +1238,10 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
         float dn = dot(d, n);
         V3 rd = normalize(v3(d.x - (2.0f * dn) * n.x, d.y - (2.0f * dn) * n.y, d.z - (2.0f * dn) * n.z));
         st.bounce_rays++;
+        const float keep_scale = g_dir_scale;
+        g_dir_scale = 1.0f; /* the mirror ray's direction is normalised (Raytracing.hlsl:84) */
         V3 rc = radiance_ray(P, so, rd, level + 1, t_base + h.t, st);
+        g_dir_scale = keep_scale;
         float fade = rough * 2.2f;
         rc = v3(maxf(0.0f, rc.x + (0.0f - rc.x) * fade), maxf(0.0f, rc.y + (0.0f - rc.y) * fade),
                 maxf(0.0f, rc.z + (0.0f - rc.z) * fade));
@@ -1258,6 +1265,10 @@ void render_rows(const Packed& P, int y0, int y1, int row0, float* out, Stats& s
         for (int x = 0; x < W; x++) {
             V3 o, d;
             camera_ray(P.cam, W, H, x, y, o, d);
+            if (g_unnormalised_offsets) {
+                const float sx = (((float)x + 0.5f) / (float)W) * 2.0f - 1.0f, sy = (((float)y + 0.5f) / (float)H) * 2.0f - 1.0f;
+                g_dir_scale = sqrtf(1.0f + (sx * P.cam.cx) * (sx * P.cam.cx) + (sy * P.cam.cy) * (sy * P.cam.cy));
+            }
             st.primary_rays++;
             g_positions[0] = g_positions[1] = 0;
             g_ray_class = 0;
@@ -1288,6 +1299,7 @@ static uint32_t* g_steps_img = nullptr;
 static uint32_t* g_lead_img = nullptr;
 void vrto_debug_set_steps_image(uint32_t* img) { g_steps_img = img; }
 void vrto_debug_set_lead_image(uint32_t* img) { g_lead_img = img; }
+void vrto_debug_unnormalised_offsets(int on) { g_unnormalised_offsets = on != 0; if (!on) g_dir_scale = 1.0f; }
 int vrto_debug_set_position_log(float* records, int capacity) {
     const int n = g_pos_log_n;
     g_pos_log = records;

@@ -61,6 +61,9 @@ void vrto_debug_set_steps_image(uint32_t* img);
 /* Debug: likewise, per pixel the number of positions its primary ray SKIPPED (empty-space leaps) before its first sample — the part of
  * a lane's chain a per-tile beam pre-pass could take over (tests/chain_lengths.py beam).  Not thread-safe. */
 void vrto_debug_set_lead_image(uint32_t* img);
+/* Study only: while on, the camera ray's secondary rays back off 0.1 * |un-normalised camera direction| like the reference's (Ray.hlsli:44-45,
+ * Raytracing.hlsl:52) instead of 0.1: how much the documented normalisation deviation moves pixels (tests/soak_reference_pixels.py offsets). */
+void vrto_debug_unnormalised_offsets(int on);
 /* Debug: while set, every march position of vrto_trace (single-threaded) appends {t, sample or NaN when skipped, leap, step
  * taken (negative: the over-relaxed march went back)} to records (4 floats each, at most capacity).  Returns the number of
  * records written since the previous call. */
