@@ -1828,6 +1828,9 @@ def test_cpp_host_adaptor_block_of_the_demo_animation_equals_frame_by_frame(tmp_
     assert len(set(outs.values())) == 1, {k: len(x) for k, x in outs.items()}
 
 
+REFERENCE_DEFAULT_NORMAL_TEXEL = np.array([[[127, 127, 255, 255]]], np.uint8)  # VColor(0.5, 0.5, 1, 1) * 255, truncated (DXTexture2D.cpp:63-71)
+
+
 def test_cpp_host_adaptor_renders_the_demo_scene(renderer, tmp_path):
     """The C++ VRenderer adaptor (csrc/host/HipRenderer.cpp, driven by vrt_demo exactly like
     VEngine::EngineLoop drives the reference's renderer) against the Python host path on the same
@@ -1856,6 +1859,9 @@ def test_cpp_host_adaptor_renders_the_demo_scene(renderer, tmp_path):
                   EnvironmentMap=env)
     for vol in sc.volumes():
         vol.set_device_format(_abi.FORMAT_TEXEL16)  # the C++ adaptor's default: the reference's own volume texel
+        # ... and the reference's 1x1 default normal texel (127, 127, 255) on materials without a normal map (RDXScene.cpp:241-260),
+        # which the adaptor binds by default: in Interp, the reference's default mode, it tilts every normal by 0.3 degrees
+        vol.Material.NormalTexture = REFERENCE_DEFAULT_NORMAL_TEXEL
     renderer.SetSceneToRender(sc)
     renderer.ResizeRenderOutput(320, 180)
     renderer.params_override = None
@@ -1867,6 +1873,18 @@ def test_cpp_host_adaptor_renders_the_demo_scene(renderer, tmp_path):
     # identical pipeline up to the light quaternion's last bit (float sin/cos vs double) and 8-bit rounding
     assert (diff > 1).mean() < 2e-3, f"{(diff > 1).sum()} pixels differ by more than one 8-bit step"
     assert (ppm[..., 0].astype(int) - ppm[..., 2] > 60).sum() > 2000  # the red sphere is in the frame
+    # --identity-defaults: unbound slots are exact identities — the NoTex frame — and the default texel's 0.3-degree tilt is visible against it
+    out2 = str(tmp_path / "demo_identity.ppm")
+    r = subprocess.run([exe, "--frames", "1", "--size", "320x180", "--out", out2, "--identity-defaults"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    raw2 = open(out2, "rb").read()
+    ppm2 = np.frombuffer(raw2[raw2.index(b"255\n") + 4:], dtype=np.uint8).reshape(180, 320, 3)
+    for vol in sc.volumes():
+        vol.Material.NormalTexture = None
+    renderer.SetRendererMode(_abi.MODE_INTERP_NOTEX)
+    plain8 = (np.clip(renderer.Render()[..., :3], 0, 1) * 255.0 + 0.5).astype(np.uint8)
+    assert (np.abs(plain8.astype(int) - ppm2.astype(int)) > 1).mean() < 2e-3
+    assert 0.005 < (np.abs(ppm2.astype(int) - ppm.astype(int)) > 1).mean() < 0.2
 
 
 def test_cpp_host_adaptor_binds_material_textures_from_a_vox_scene(renderer, tmp_path):
@@ -1920,6 +1938,8 @@ def test_cpp_host_adaptor_binds_material_textures_from_a_vox_scene(renderer, tmp
                   EnvironmentMap=env)
     for vol in sc.volumes():
         vol.set_device_format(_abi.FORMAT_TEXEL16)  # the C++ adaptor's default
+        if vol.Material.NormalTexture is None:
+            vol.Material.NormalTexture = REFERENCE_DEFAULT_NORMAL_TEXEL  # what the adaptor binds to a material without a normal map
     r2 = v.VHipRenderer()
     assert r2.Start()
     try:

@@ -450,7 +450,14 @@ bool VHipRenderer::SyncWithScene(Scene::VScene& scene) {
         vrt_material mat = {{m.AlbedoColor.R, m.AlbedoColor.G, m.AlbedoColor.B, m.AlbedoColor.A}, m.Roughness, m.Metallic};
         if (!ok(vrt_volume_set_material(Ctx, (int)slot, &mat), "vrt_volume_set_material")) return false;
         if (!ok(vrt_volume_set_metric(Ctx, (int)slot, v.DensityScale, v.StepMax), "vrt_volume_set_metric")) return false;
-        const int ta = ResolveTexture(m.AlbedoTexturePath), tn = ResolveTexture(m.NormalTexturePath), tr = ResolveTexture(m.RMTexturePath);
+        const int ta = ResolveTexture(m.AlbedoTexturePath), tr = ResolveTexture(m.RMTexturePath);
+        int tn = ResolveTexture(m.NormalTexturePath);
+        if (tn < 0 && ReferenceDefaultTextures) { /* DefaultNormalTexture->SetPixel(VColor(0.5, 0.5, 1, 1)): 255 * 0.5 truncates to 127 (DXTexture2D.cpp:63-71) */
+            if (!DefaultNormalTexture) DefaultNormalTexture = std::make_shared<VTexture2D>(1, 1, std::vector<uint8_t>{127, 127, 255, 255});
+            UploadToGPU(DefaultNormalTexture);
+            const auto id = TextureIds.find(DefaultNormalTexture.get());
+            tn = id == TextureIds.end() ? -1 : id->second;
+        }
         const float su = m.TextureScale.X != 0.f ? m.TextureScale.X : 100.f, sv = m.TextureScale.Y != 0.f ? m.TextureScale.Y : 100.f;
         if (!ok(vrt_volume_set_textures(Ctx, (int)slot, ta, tn, tr, su, sv), "vrt_volume_set_textures")) return false;
         MinCell = (MinCell == 0.f || v.GetCellSize() < MinCell) ? v.GetCellSize() : MinCell;

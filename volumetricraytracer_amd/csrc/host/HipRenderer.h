@@ -65,6 +65,13 @@ public:
        surface's pixels by more than one 8-bit step: the texel's 0.01 quantum).  VRT_FORMAT_F32 keeps the caller's
        floats (3 % faster, bench.py's format). */
     int VolumeFormat = VRT_FORMAT_TEXEL16;
+    /* The reference binds 1x1 DEFAULT textures to every material slot that names no image (VRDXScene::AllocateDefaultTextures,
+       RDXScene.cpp:241-260): albedo white and RM (1, 1, 0) are exact identities, but the default normal texel, VColor(0.5, 0.5, 1)
+       stored as 8 bits, is (127, 127, 255) and decodes to (-0.0039, -0.0039, 1): in the textured render modes (Interp — the
+       reference's DEFAULT mode —, Interp_Unlit, Cube, Cube_Unlit) it tilts every normal by 0.3 degrees, which moves 2-10 % of a surface's
+       pixels by more than one 8-bit step.  true (default): materials without a normal map get that texel, so that
+       the frames are the reference's; false: unbound slots are exact identities (and a scene without textures keeps the lean kernel). */
+    bool ReferenceDefaultTextures = true;
     float Relaxation = 1.7f;  /* vrt_params::k_relax: over-relaxed sphere-trace with the sphere-overlap fallback; 1 = plain */
     bool Shadows = true;      /* the reference always casts the directional shadow ray */
     int MaxBounces = 2;       /* MAX_RAY_RECURSION_DEPTH 3 = primary + 2 mirror bounces (RaytracingHlsl.h:32) */
@@ -104,6 +111,7 @@ private:
     std::map<std::string, TextureEntry> Textures;
     std::map<const VTexture2D*, int> TextureIds;
     int ResolveTexture(const std::string& path);
+    VObjectPtr<VTexture2D> DefaultNormalTexture; /* the reference's 1x1 default normal texel (127, 127, 255, 255) */
     float MinCell = 1.f;
     int MaxResolution = 0;
     int UploadedFormat = -1;
