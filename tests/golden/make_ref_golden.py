@@ -46,6 +46,8 @@ CASES = {
     "ref_c5inst128_1080p_rows300": (scenes.config5_instances, dict(resolution=7, env=16), 1920, 1080, 300, 64, True),
     # the whole closest-hit shader: mirroring spheres (bounces to MAX_RAY_RECURSION_DEPTH), a point and a spot light with their shadow rays
     "ref_fullhit64_320x180": (_mirror_scene, dict(resolution=6, env=32), 320, 180, 0, 180, True, 2),
+    # ... and the textured mode (Interp, the reference's default): tri-planar albedo / normal / RM textures on the same scene
+    "ref_textured64_320x180": (scenes.textured_scene, dict(resolution=6, env=32), 320, 180, 0, 180, True, 2, v._abi.MODE_INTERP),
 }
 
 
@@ -54,6 +56,8 @@ def build_case(case):
     sc = fn(**kw)
     p = v.default_params(w, h, scenes.min_cell(sc), 255, shadow=shadow)
     p.max_bounces = case[7] if len(case) > 7 else 0
+    if len(case) > 8:
+        p.mode = case[8]
     return sc, p, row0, rows
 
 

@@ -40,6 +40,9 @@ BOUNDS = {
     "ref_c5inst32_320x180": (0.0, 0.0),
     # mirror bounces: the reflection of another object's silhouette lies INSIDE the mirror's own surface (measured 0.0073 / 0.0044)
     "ref_fullhit64_320x180": (0.015, 0.01),
+    # textured mode (tri-planar albedo / normal / RM maps, point-sampled): a texel boundary next to the hit flips a texel (measured
+    # 0.0085 / 0.0076; rounds 1-3: 0.48 — a normal map amplifies the normal's error)
+    "ref_textured64_320x180": (0.02, 0.02),
 }
 
 
