@@ -53,6 +53,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
 # tools/microbench/gather.hip / gather16.hip on MI355X (re-measured on the round-4 build: profiles/r04_gather_microbench.txt): trilinear samples/s the chip sustains for
 # 4 x dwordx2 taps per lane at random cells, by where the bricks live; l1_coherent_lanes: the same with the 64 lanes of a wave on the 3x3 cells
 # an 8x8-pixel tile covers (lanes that share a cell share its lines; 552 / 561 / 540 from L1 / L2 / the 256^3 pool)
+NATIVE_PROBE_DEADLINE_S = float(os.environ.get("VRT_BENCH_NATIVE_PROBE_DEADLINE_S", "120"))  # vrt_comm_init + a 64-byte exchange and gather; RCCL's bootstrap takes a few seconds
 GATHER_CEILING_GSAMPLES = {"l1": 264.0, "l2": 209.0, "mall_hbm": 126.0, "l1_int16": 298.0, "l1_coherent_lanes": 552.0}
 
 
@@ -521,41 +522,65 @@ def main() -> None:
     r.SyncWithScene()
 
     native_ready, native_error = False, None
-    if world > 1 and not rehearsal:
+    # VRT_BENCH_NATIVE_PROBE=1 runs this block in a rehearsal too: two ranks on ONE GPU is something RCCL refuses or waits on for
+    # ever, which is exactly the failure the deadline below exists for (tests/test_parity_gpu.py walks it)
+    if world > 1 and (not rehearsal or os.environ.get("VRT_BENCH_NATIVE_PROBE") == "1"):
         # the C-ABI's own communicator — the product's exchange path, and the main line's by default (an N > 1 run
         # must measure vrt_comm_init / vrt_exchange_tiles / vrt_gather_tiles, not torch.distributed): rank 0 makes the id,
         # torch.distributed carries it to the others
+        # ... inside a thread with a deadline: a bootstrap that never returns (it has never run on N > 1 GPUs) must cost the run its
+        # native path, not the run — ctypes drops the GIL in the call, every rank times out alike, and the flag below agrees on it
+        idt = torch.zeros(_abi.VRT_COMM_ID_BYTES, dtype=torch.uint8, device=cdev)
         try:
-            idt = torch.zeros(_abi.VRT_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(v.VHipRenderer.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, 0)
-            r.comm_init(world, rank, bytes(idt.cpu().numpy().tobytes()))
-            # the product's exchange on a few bytes before the run stands on it (it has never run on N > 1 GPUs in any round): chunk d
-            # of my buffer goes to rank d (vrt_exchange_tiles), every rank's tile lands rank-major on rank 0 (vrt_gather_tiles)
-            cb = 64
-            snd = (torch.arange(world, dtype=torch.int32, device=dev)[:, None] + 16 * rank).to(torch.uint8).expand(world, cb).contiguous()
-            rcv = torch.zeros_like(snd)
-            st0 = torch.cuda.current_stream().cuda_stream
-            r.exchange_tiles(snd.data_ptr(), rcv.data_ptr(), cb, st0)
-            tile = torch.full((cb,), 100 + rank, dtype=torch.uint8, device=dev)
-            got = torch.zeros((world, cb), dtype=torch.uint8, device=dev)
-            r.gather_tiles(tile.data_ptr(), got.data_ptr() if rank == 0 else 0, cb, 0, st0)
-            torch.cuda.synchronize()
-            want = (16 * torch.arange(world, dtype=torch.int32)[:, None] + rank).to(torch.uint8).expand(world, cb)
-            ok_x = bool((rcv.cpu() == want).all())
-            ok_g = rank != 0 or bool((got.cpu() == (100 + torch.arange(world, dtype=torch.int32))[:, None].to(torch.uint8)).all())
-            if not (ok_x and ok_g):
-                raise RuntimeError(f"native exchange probe delivered wrong bytes (exchange ok {ok_x}, gather ok {ok_g})")
-            native_ready = True
-        except Exception as e:  # reported, never fatal: torch.distributed remains
+        except Exception as e:  # noqa: BLE001
             native_error = repr(e)
-        flag = torch.tensor([1 if native_ready else 0], dtype=torch.int32, device=dev)
+        dist.broadcast(idt, 0)
+        id_bytes = bytes(idt.cpu().numpy().tobytes())
+        probe_stream = torch.cuda.Stream(device=dev)
+        probe_result = {}
+
+        def native_probe():
+            try:
+                torch.cuda.set_device(dev)
+                r.comm_init(world, rank, id_bytes)
+                # the product's exchange on a few bytes before the run stands on it: chunk d of my buffer goes to rank d
+                # (vrt_exchange_tiles), every rank's tile lands rank-major on rank 0 (vrt_gather_tiles)
+                cb = 64
+                with torch.cuda.stream(probe_stream):
+                    snd = (torch.arange(world, dtype=torch.int32, device=dev)[:, None] + 16 * rank).to(torch.uint8).expand(world, cb).contiguous()
+                    rcv = torch.zeros_like(snd)
+                    tile = torch.full((cb,), 100 + rank, dtype=torch.uint8, device=dev)
+                    got = torch.zeros((world, cb), dtype=torch.uint8, device=dev)
+                    st0 = probe_stream.cuda_stream
+                    r.exchange_tiles(snd.data_ptr(), rcv.data_ptr(), cb, st0)
+                    r.gather_tiles(tile.data_ptr(), got.data_ptr() if rank == 0 else 0, cb, 0, st0)
+                    probe_stream.synchronize()
+                    want = (16 * torch.arange(world, dtype=torch.int32)[:, None] + rank).to(torch.uint8).expand(world, cb)
+                    ok_x = bool((rcv.cpu() == want).all())
+                    ok_g = rank != 0 or bool((got.cpu() == (100 + torch.arange(world, dtype=torch.int32))[:, None].to(torch.uint8)).all())
+                if not (ok_x and ok_g):
+                    raise RuntimeError(f"native exchange probe delivered wrong bytes (exchange ok {ok_x}, gather ok {ok_g})")
+                probe_result["ok"] = True
+            except Exception as e:  # reported, never fatal: torch.distributed remains
+                probe_result["error"] = repr(e)
+
+        if native_error is None:
+            import threading
+            th = threading.Thread(target=native_probe, daemon=True)
+            th.start()
+            th.join(NATIVE_PROBE_DEADLINE_S)
+            if th.is_alive():
+                native_error = f"vrt_comm_init / the probe exchange did not return within {NATIVE_PROBE_DEADLINE_S} s"
+            else:
+                native_ready, native_error = bool(probe_result.get("ok")), probe_result.get("error")
+        flag = torch.tensor([1 if native_ready else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        native_ready = bool(flag.item())
+        native_ready = bool(flag.item()) and not rehearsal
     use_native = args.gather == "native" and native_ready
     native_fallback = None
-    if args.gather == "native" and world > 1 and not native_ready and not rehearsal:
+    if args.gather == "native" and world > 1 and not native_ready and (not rehearsal or native_error):
         # never lose the run: torch.distributed carries the exchange instead, and the line says so
         native_fallback = f"vrt_comm_init unavailable ({native_error}): torch.distributed carries the exchange"
         print(f"[bench] {native_fallback}", file=sys.stderr)

@@ -921,7 +921,11 @@ def test_bench_two_rank_rehearsal(oracle_lib):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: val for k, val in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(VRT_BENCH_BACKEND="gloo", VRT_BENCH_VERIFY="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # VRT_BENCH_NATIVE_PROBE: the rehearsal also walks the N > 1 line's start-up of the C-ABI's own communicator (vrt_comm_init + a
+    # 64-byte exchange, in a thread with a deadline).  Two ranks on one GPU is a communicator RCCL cannot build: the run must go on
+    # over the other collective and say so — the behaviour a real N-GPU run relies on if RCCL's bootstrap fails or never returns.
+    env.update(VRT_BENCH_BACKEND="gloo", VRT_BENCH_VERIFY="1", HSA_ENABLE_IPC_MODE_LEGACY="0", VRT_BENCH_NATIVE_PROBE="1",
+               VRT_BENCH_NATIVE_PROBE_DEADLINE_S="45")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "c2",
            "--no-cpu-baseline"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
@@ -942,6 +946,7 @@ def test_bench_two_rank_rehearsal(oracle_lib):
     assert set(out["exchanges"]) == {"rotate", "gather"} and out["exchanges"]["rotate"]["main_line"] and out["exchanges"]["rotate"]["value"] == out["value"]
     assert out["exchanges"]["gather"]["value"] == out["other_exchange"]["value"] and out["link_model"]["gather_to_rank0_cap_Mrays_per_s"] > 0
     assert out["north_star_6x_at_8_gpus"] is None  # (a statement about 8 GPUs only)
+    assert "vrt_comm_init unavailable" in out["collective_fallback"] and "torch.distributed" in out["collective"]
     # a rank count that does not match --gpus is refused, not silently measured
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env2, capture_output=True,
