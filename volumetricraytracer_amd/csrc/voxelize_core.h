@@ -64,6 +64,13 @@ VRT_HD bool make_frame(V3 v1, V3 v2, V3 v3_, TriangleFrame& t) {
     return true;
 }
 
+/* roundf(v) as an int held to [lo, hi] (a float beyond int's range — a damaged file's vertex — must not reach the conversion:
+ * that is undefined on the host and saturates on the device); NaN gives if_nan. */
+VRT_HD int clamped_round(float v, int lo, int hi, int if_nan) {
+    const float r = roundf(v);
+    return r != r ? if_nan : r <= (float)lo ? lo : r >= (float)hi ? hi : (int)r;
+}
+
 /* Index box of the voxels a triangle can influence: triangle bounds, grown by the threshold, rounded to
  * voxels, grown by one voxel, clipped (GetTriangleBoundingBox + GetVoxelizedBoundingBox,
  * VolumeConverter.cpp:681-701; VVoxelVolume::RelativePositionToVoxelIndex rounds, VoxelVolume.cpp:148-161). */
@@ -80,8 +87,9 @@ VRT_HD void index_box(TriangleFrame& t, float threshold, float extent, float cel
     const float org = -1.0f * extent; /* volume origin on every axis: -ONE * VolumeExtends */
     const float mn[3] = {bmin.x, bmin.y, bmin.z}, mx[3] = {bmax.x, bmax.y, bmax.z};
     for (int a = 0; a < 3; a++) {
-        int i0 = (int)roundf((mn[a] - org) / cell) - 1;
-        int i1 = (int)roundf((mx[a] - org) / cell) + 1;
+        /* held to one voxel beyond the clip below: the clipped box — empty when the triangle lies outside the volume — is unchanged */
+        int i0 = clamped_round((mn[a] - org) / cell, -1, n_axis + 1, n_axis + 1) - 1;
+        int i1 = clamped_round((mx[a] - org) / cell, -2, n_axis, -2) + 1;
         t.lo[a] = i0 < 0 ? 0 : i0;
         t.hi[a] = i1 > n_axis - 1 ? n_axis - 1 : i1;
     }

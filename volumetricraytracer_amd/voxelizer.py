@@ -23,10 +23,11 @@ _host = None
 def load_host() -> C.CDLL:
     global _host
     if _host is None:
-        if not os.path.exists(HOST_LIB_PATH):
-            raise RuntimeError(f"{HOST_LIB_PATH} is missing: run __graft_entry__.build()")
+        path = os.environ.get("VRT_HOST_LIB") or HOST_LIB_PATH  # VRT_HOST_LIB: the sanitizer build (make -C csrc/host asan)
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run __graft_entry__.build()")
         _abi.load()  # libvrt_host.so links libvrt_hip.so: settle the HIP runtime first
-        lib = C.CDLL(HOST_LIB_PATH)
+        lib = C.CDLL(path)
         lib.vrh_last_error.restype = C.c_char_p
         lib.vrh_convert_mesh.restype = C.c_void_p
         lib.vrh_convert_mesh.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.c_char_p]
