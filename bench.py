@@ -1013,6 +1013,11 @@ def main() -> None:
             "limiter_ceiling_gsamples_per_s": GATHER_CEILING_GSAMPLES[gather_key],
             "frac_note": "frac = algorithmic bytes (32 B per sample, cache-served or not) / launch time / 8 TB/s: an accounting of samples; it may exceed 1. "
                          "limiter_frac = trilinear evaluations (samples + 6 per hit normal) per second / the measured L1 gather ceiling; hbm_measured_frac the physical HBM share",
+            # measured in round 4 (profiles/r04_ab_cell_activity_mask.txt): the evaluation RATE is how the texture path's load is counted, not
+            # what its time is made of — a build that takes a third fewer samples for bit-identical frames is 3.4 % faster
+            "limiter_note": "the texture path is busy with cache-line look-ups per wave instruction (l1_cache_line_accesses_per_cu_cycle of 1 per CU and cycle, "
+                            "td_busy_frac), which lanes of one 8x8-pixel tile share: an A/B that removed 33 % of the samples with bit-identical frames "
+                            "gained 3.4 % (profiles/r04_ab_cell_activity_mask.txt) -- limiter_frac counts lane-level evaluations and overstates what fewer samples would buy",
         }
         if pmc and kms:
             # physical picture, from the keyed PMC passes (profiles/counters_latest.json: tools/r03_profile.sh on this kernel source

@@ -983,6 +983,7 @@ def test_bench_one_gpu_line_has_the_contract_fields(oracle_lib):
     assert 0.85 < r["kernel_ms"] * o["config"]["launches_per_step"] / o["ms_per_step"] <= 1.02
     # the roof the kernel is under: its samples per second against the measured L1 gather ceiling (frac counts cache-served taps)
     assert 0.3 < r["limiter_frac"] < 1.3 and abs(r["limiter_frac"] - r["gevaluations_per_s"] / r["limiter_ceiling_gsamples_per_s"]) < 1e-3
+    assert "cache-line" in r["limiter_note"]  # (what the evaluation rate does and does not say: the round-4 sample-count A/B)
     assert r["trilinear_evaluations_per_launch"] > r["samples_per_launch"]  # + 6 per hit (the normal)
     # value = rays of the batch x steps / time
     assert abs(o["value"] - o["config"]["rays_per_step"] / (o["ms_per_step"] * 1e-3) / 1e6) / o["value"] < 0.01
