@@ -46,6 +46,17 @@ class vrto_stats(C.Structure):
                 ("primary_rays", "shadow_rays", "bounce_rays", "primary_steps", "shadow_steps", "hits", "exhausted_rays")]
 
 
+class vrto_literal_stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("rays", "iterations", "solid_start_hits", "entry_hits", "root_hits", "tail_hits", "red_hits", "rejected_reports")]
+
+
+class vrto_octree_info(C.Structure):
+    _fields_ = [("nodes", C.c_uint64), ("leaves_at_depth", C.c_uint64 * 9), ("texture_edge", C.c_int32), ("pointer_overflow", C.c_int32)]
+
+
+LIT_NORMALISED_CAMERA = 1
+
 _lib = None
 
 
@@ -83,6 +94,12 @@ def load() -> C.CDLL:
         lib.vrto_ref_render.restype = C.c_int
         lib.vrto_ref_render.argtypes = [C.POINTER(_abi.vrt_scene), C.POINTER(vrto_volume), C.c_void_p, C.c_int,
                                         C.POINTER(_abi.vrt_params), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        lib.vrto_ref_literal_render.restype = C.c_int
+        lib.vrto_ref_literal_render.argtypes = [C.POINTER(_abi.vrt_scene), C.POINTER(vrto_volume), C.c_void_p, C.c_int,
+                                                C.POINTER(_abi.vrt_params), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint,
+                                                C.POINTER(vrto_literal_stats), C.c_int]
+        lib.vrto_literal_octree_info.restype = C.c_int
+        lib.vrto_literal_octree_info.argtypes = [C.POINTER(vrto_volume), C.POINTER(vrto_octree_info)]
         lib.vrto_debug_tables.restype = C.c_int
         lib.vrto_debug_tables.argtypes = [C.POINTER(vrto_volume), C.c_void_p, C.c_void_p, C.c_void_p]
         lib.vrto_env_lookup.restype = None
@@ -151,6 +168,29 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError(f"vrto_ref_render failed: {rc}")
         return out, t
+
+    def ref_literal_render(self, params: _abi.vrt_params, row0: int = 0, rows: Optional[int] = None, threads: int = 8, options: int = 0):
+        """vrto_ref_literal_render: the frame the reference's shaders compute LITERALLY (fp32, un-normalised camera direction, nudges,
+        octree leaves, three secant steps, abs()-weighted normal, budget).  Returns (image, t in world units with -1 for misses, stats)."""
+        rows = params.height - row0 if rows is None else rows
+        out = np.empty((rows, params.width, 4), dtype=np.float32)
+        t = np.empty((rows, params.width), dtype=np.float32)
+        st = vrto_literal_stats()
+        rc = load().vrto_ref_literal_render(C.byref(self.abi), self.vols, self.env.ctypes.data if self.env is not None else None,
+                                            self.env_size, C.byref(params), row0, rows, out.ctypes.data, t.ctypes.data, options,
+                                            C.byref(st), threads)
+        if rc != 0:
+            raise RuntimeError(f"vrto_ref_literal_render failed: {rc}")
+        return out, t, {n: getattr(st, n) for n, _ in st._fields_}
+
+    def octree_info(self, slot: int) -> dict:
+        """The collapsed octree the reference would build for the volume in `slot` (VCellOctree)."""
+        info = vrto_octree_info()
+        rc = load().vrto_literal_octree_info(C.byref(self.vols[slot]), C.byref(info))
+        if rc != 0:
+            raise RuntimeError(f"vrto_literal_octree_info failed: {rc}")
+        return {"nodes": info.nodes, "leaves_at_depth": list(info.leaves_at_depth), "texture_edge": info.texture_edge,
+                "pointer_overflow": bool(info.pointer_overflow)}
 
     def trace(self, params: _abi.vrt_params, origin, direction, t_max: float = 10000.0):
         lib = load()

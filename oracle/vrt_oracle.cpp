@@ -121,6 +121,21 @@ inline void camera_ray(const Camera& c, int width, int height, int px, int py, V
     d = normalize(dir);
 }
 
+/* GenerateCameraRay as the shader leaves it (Ray.hlsli:36-48): target = projInv * (x, -y, 1, 1), direction = viewInv * (target.xyz, 0),
+   NOT normalised: |direction| = 1 in the frame's centre, 1.55 in the corner of a 16:9 frame at 60 degrees.  Every t of the reference —
+   its 0.01 / 0.1 nudges, the 0.1 back-off of the secondary rays, TMax — is in units of that length, and the closest-hit shader's
+   wo = -WorldRayDirection() is not a unit vector either.  (vrto_ref_literal_render only.) */
+inline void camera_ray_raw(const Camera& c, int width, int height, int px, int py, V3& o, V3& d) {
+    const float sx = (((float)px + 0.5f) / (float)width) * 2.0f - 1.0f;
+    const float sy = (((float)py + 0.5f) / (float)height) * 2.0f - 1.0f;
+    const float tx = sx * c.cx;
+    const float ty = (-sy) * c.cy;
+    d = v3((tx * c.r0.x + ty * c.r1.x) - c.r2.x, (tx * c.r0.y + ty * c.r1.y) - c.r2.y, (tx * c.r0.z + ty * c.r1.z) - c.r2.z);
+    o = c.origin;
+}
+
+struct LitVolume; /* vrt_ref_literal.inl: what the reference's shaders read of a volume (decoded texels, collapsed octree) */
+
 struct Volume {
     const float* den;
     int N;
@@ -146,6 +161,7 @@ struct Volume {
     /* Active box (with skip): object-space bounding box of the near bricks; the sphere-trace is clipped to it. */
     float alo[3] = {0, 0, 0}, ahi[3] = {0, 0, 0};
     std::shared_ptr<const struct Derived> derived; /* owner of the three tables and of the quantised field */
+    const LitVolume* lit = nullptr;                /* vrto_ref_literal_render only */
 };
 
 /* Everything derived from a volume's samples and metric, cached across vrto_* calls (keyed by a hash of the
@@ -160,7 +176,9 @@ struct Derived {
     std::vector<uint8_t> cube_skip;
     int abox[6] = {0, 0, 0, -1, -1, -1}; /* bounding box of the near bricks {min x, z, y, max x, z, y} */
     bool has_cube = false;
+    std::shared_ptr<LitVolume> lit; /* vrto_ref_literal_render only, built on demand */
 };
+void ensure_literal(Derived& d, const float* den, int N, int resolution);
 
 struct Instance {
     int slot;
@@ -181,6 +199,8 @@ struct Packed {
     const vrt_scene* scene;
     vrt_params prm;
     bool ref_intersection = false; /* vrto_ref_render: every ray is intersected by the REFERENCE's hit search (ref_march_instance) */
+    bool literal = false;          /* vrto_ref_literal_render: ... by the literal restatement of its shaders (vrt_ref_literal.inl) */
+    unsigned lit_options = 0;
     uint32_t* lead_img = nullptr; /* optional debug output, rows*width: positions the primary ray skipped before its first sample */
     uint32_t* steps_img; /* optional debug output, rows*width: march positions of the primary ray (low 16 bits) and of the rays after it (high 16) */
 };
@@ -444,7 +464,7 @@ std::mutex g_cache_mutex;
 std::vector<std::shared_ptr<Derived>> g_cache; /* most recently used last */
 
 /* The derived data of one volume for one metric; `want_cube` adds the Cube modes' table. */
-std::shared_ptr<const Derived> derive(const vrto_volume& s, int N, int nb, bool want_cube) {
+std::shared_ptr<const Derived> derive(const vrto_volume& s, int N, int nb, bool want_cube, bool want_literal = false) {
     const size_t count = (size_t)N * N * N;
     const uint64_t hsh = hash_floats(s.density, count);
     std::lock_guard<std::mutex> lock(g_cache_mutex);
@@ -481,13 +501,14 @@ std::shared_ptr<const Derived> derive(const vrto_volume& s, int N, int nb, bool 
         build_cube_table(s.format == VRT_FORMAT_TEXEL16 ? d->field.data() : s.density, N, nb, d->cube_skip);
         d->has_cube = true;
     }
+    if (want_literal && !d->lit) ensure_literal(*d, s.density, N, s.resolution);
     g_cache.push_back(d);
     while (g_cache.size() > 6) g_cache.erase(g_cache.begin());
     return d;
 }
 
 bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env, int env_size,
-          const vrt_params* prm, Packed& P) {
+          const vrt_params* prm, Packed& P, bool literal = false) {
     if (!scene || !volumes || !prm) return false;
     if (prm->width <= 0 || prm->height <= 0) return false;
     if (scene->n_instances < 0 || scene->n_instances > VRT_MAX_INSTANCES) return false;
@@ -524,7 +545,9 @@ bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env
         v.k = (r1 * r1) / 8.0f; /* RDXVoxelVolume.cpp:383, from the unclamped roughness */
         v.nb = (v.N - 1 + 3) / 4;
         if (s.format != VRT_FORMAT_F32 && s.format != VRT_FORMAT_TEXEL16) return false;
-        v.derived = derive(s, v.N, v.nb, prm->mode >= VRT_MODE_CUBE);
+        if (literal && s.resolution > 8) return false; /* the reference's octree walk ends at depth 8 (Voxel.hlsli:316) */
+        v.derived = derive(s, v.N, v.nb, prm->mode >= VRT_MODE_CUBE, literal);
+        v.lit = literal ? v.derived->lit.get() : nullptr;
         if (s.format == VRT_FORMAT_TEXEL16) v.den = v.derived->field.data();
         v.skip = s.step_max > 0.0f ? v.derived->skip.data() : nullptr;
         v.nib = s.step_max > 0.0f ? v.derived->nib.data() : nullptr;
@@ -551,6 +574,7 @@ bool pack(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env
     P.scene = scene;
     P.prm = *prm;
     P.steps_img = nullptr;
+    P.literal = literal;
     return true;
 }
 
@@ -604,6 +628,7 @@ struct HitRec {
     float t;
     int inst;
     V3 n_world;
+    bool unlit = false; /* literal reference intersection only: n_world is the pixel's colour (attr.unlit, Raytracing.hlsl:44-48) */
 };
 
 /* Ray-box slab test, box = [-e,+e]^3, inf-safe reciprocals. */
@@ -928,8 +953,11 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
     return false;
 }
 
+#include "vrt_ref_literal.inl"
+
 /* Closest hit over all instances (ascending index; strict '<' keeps the lower index on ties). */
 bool trace_closest(const Packed& P, V3 o, V3 d, float t_max, float t_base, HitRec& h, uint64_t& steps) {
+    if (P.literal) return lit_trace_closest(P, o, d, t_max, h);
     bool any = false;
     float best = t_max;
     /* A sphere-trace runs over the instance's whole interval whatever has been hit before: where its stretched steps fall
@@ -953,6 +981,7 @@ bool trace_closest(const Packed& P, V3 o, V3 d, float t_max, float t_base, HitRe
 }
 
 bool trace_any(const Packed& P, V3 o, V3 d, float t_max, float t_base, uint64_t& steps) {
+    if (P.literal) return lit_trace_any(P, o, d, t_max);
     for (int i = 0; i < P.n_inst; i++) {
         float t;
         V3 n;
@@ -1126,6 +1155,7 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
         return v3(rgb[0], rgb[1], rgb[2]);
     }
     st.hits++;
+    if (h.unlit) return h.n_world;
     const Volume& V = P.vol[P.inst[h.inst].slot];
     V3 albedo = v3(V.tint[0], V.tint[1], V.tint[2]);
     int mode = P.prm.mode;
@@ -1265,6 +1295,7 @@ void render_rows(const Packed& P, int y0, int y1, int row0, float* out, Stats& s
         for (int x = 0; x < W; x++) {
             V3 o, d;
             camera_ray(P.cam, W, H, x, y, o, d);
+            if (P.literal && !(P.lit_options & VRTO_LIT_NORMALISED_CAMERA)) camera_ray_raw(P.cam, W, H, x, y, o, d);
             if (g_unnormalised_offsets) {
                 const float sx = (((float)x + 0.5f) / (float)W) * 2.0f - 1.0f, sy = (((float)y + 0.5f) / (float)H) * 2.0f - 1.0f;
                 g_dir_scale = sqrtf(1.0f + (sx * P.cam.cx) * (sx * P.cam.cx) + (sy * P.cam.cy) * (sy * P.cam.cy));
@@ -1760,6 +1791,81 @@ int vrto_ref_render(const vrt_scene* scene, const vrto_volume* volumes, const ui
         for (int k = 0; k < threads; k++) th.emplace_back(work, k);
         for (auto& t : th) t.join();
     }
+    return VRT_OK;
+}
+
+
+/* The frame the reference's shaders compute, LITERALLY (vrt_ref_literal.inl): fp32, the un-normalised camera direction with every
+   offset and the shading's wo in its units, +0.01 / +0.1 nudges, the collapsed octree's leaves, the cubic on [cellEnter, cellExit]
+   with 2 regula-falsi steps + 1 secant, abs()-weighted GetNormal with out-of-bounds texels = 0, 255 leaves then the red hit.
+   Volumes are read through the reference's 16-bit texel whatever vrto_volume::format says (that is all its GPU ever sees).
+   t_out_or_null: the camera ray's hit distance in WORLD units (t * |direction|), -1 = miss.  Interp modes only. */
+int vrto_ref_literal_render(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env_rgba8, int env_face_size,
+                            const vrt_params* params, int row0, int rows, float* out_rgba, float* t_out_or_null, unsigned options,
+                            vrto_literal_stats* stats_or_null, int threads) {
+    std::unique_ptr<Packed> P(new Packed);
+    if (!params || !(params->mode >= VRT_MODE_INTERP && params->mode < VRT_MODE_CUBE)) return VRT_ERR_UNSUPPORTED;
+    if (!pack(scene, volumes, env_rgba8, env_face_size, params, *P, true) || !out_rgba) return VRT_ERR_INVALID;
+    if (row0 < 0 || rows < 0 || row0 + rows > params->height) return VRT_ERR_INVALID;
+    P->lit_options = options;
+    if (threads < 1) threads = 1;
+    const int W = params->width;
+    std::vector<LitCounters> counters((size_t)threads);
+    auto work = [&](int k) {
+        Stats st;
+        g_lit = LitCounters();
+        for (int y = row0 + k; y < row0 + rows; y += threads) {
+            render_rows(*P, y, y + 1, row0, out_rgba, st);
+            if (t_out_or_null) {
+                const LitCounters keep = g_lit; /* the distance probe below repeats the camera rays: not counted twice */
+                for (int x = 0; x < W; x++) {
+                    V3 o, d;
+                    camera_ray(P->cam, W, params->height, x, y, o, d);
+                    if (!(options & VRTO_LIT_NORMALISED_CAMERA)) camera_ray_raw(P->cam, W, params->height, x, y, o, d);
+                    HitRec h;
+                    t_out_or_null[(size_t)(y - row0) * W + x] = lit_trace_closest(*P, o, d, 10000.0f, h) ? h.t * sqrtf(dot(d, d)) : -1.0f;
+                }
+                g_lit = keep;
+            }
+        }
+        counters[(size_t)k] = g_lit;
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int k = 0; k < threads; k++) th.emplace_back(work, k);
+        for (auto& t : th) t.join();
+    }
+    if (stats_or_null) {
+        vrto_literal_stats s;
+        memset(&s, 0, sizeof s);
+        for (const LitCounters& c : counters) {
+            s.rays += c.rays;
+            s.iterations += c.iterations;
+            s.solid_start_hits += c.solid_start;
+            s.entry_hits += c.entry_hits;
+            s.root_hits += c.root_hits;
+            s.tail_hits += c.tail_hits;
+            s.red_hits += c.red_hits;
+            s.rejected_reports += c.rejected;
+        }
+        *stats_or_null = s;
+    }
+    return VRT_OK;
+}
+
+/* The collapsed octree the reference builds for `vol` (VCellOctree, Voxel/Private/Octree.cpp): node count, texture edge S
+   (the traversal texture is (2S)^3 RGBA8 texels whose pointer texels hold block coordinates 2c < 2S in 8 bits), leaves per depth. */
+int vrto_literal_octree_info(const vrto_volume* vol, vrto_octree_info* out) {
+    if (!vol || !vol->density || !out || vol->resolution < 1 || vol->resolution > 8) return VRT_ERR_INVALID;
+    const int N = (1 << vol->resolution) + 1, nb = (N - 1 + 3) / 4;
+    std::shared_ptr<const Derived> d = derive(*vol, N, nb, false, true);
+    memset(out, 0, sizeof *out);
+    out->nodes = d->lit->nodes;
+    out->texture_edge = 2 * d->lit->S;
+    out->pointer_overflow = 2 * (d->lit->S - 1) > 255 ? 1 : 0;
+    for (int k = 0; k < 9; k++) out->leaves_at_depth[k] = d->lit->leaves_at[k];
     return VRT_OK;
 }
 

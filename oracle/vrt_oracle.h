@@ -106,6 +106,42 @@ int vrto_ref_hit_batch(const vrto_volume* vol, int n, const float* origins, cons
 int vrto_ref_render(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env_rgba8, int env_face_size,
                     const vrt_params* params, int row0, int rows, float* out_rgba, float* t_out_or_null, int threads);
 
+/* The frame the reference's shaders compute, LITERALLY (oracle/vrt_ref_literal.inl) — vrto_ref_render is the IDEALISED restatement
+ * (double precision, exact root, no nudges, no octree, no budget, normalised camera direction); this one follows
+ * VRIntersection / VRIntersectionShadowRay statement by statement in fp32: the un-normalised camera direction (Ray.hlsli:36-48) with
+ * every offset, TMax and the closest-hit shader's wo in its units; tEnter += 0.01 (Raytracing.hlsl:178,195); the collapsed octree's
+ * leaf origin and size per step (Voxel.hlsli:293-495, Voxel/Private/Octree.cpp:70-107,181-262); GoToNextVoxel's +0.1 (Voxel.hlsli:80-128);
+ * the cubic on [cellEnter, cellExit] with t0 = max(0, -tIn/(tOut-tIn)), the derivative-root split, 2 regula-falsi steps + 1 secant,
+ * tHit > 0 (Voxel.hlsli:691-781); GetNormal with the abs() weights at a cell-space position that may exceed 1, texels outside the
+ * 3D texture = 0 (Voxel.hlsli:607-684,783-804); 255 leaves, then the red unlit hit at t = 10 (Raytracing.hlsl:229,325-334); ReportHit's
+ * [0, RayTCurrent] acceptance.  Volumes are read through the reference's 16-bit texel whatever `format` says.  It exists to MEASURE
+ * how far the reference's frames are from the idealisation and from the HIP frames (tests/ref_pixels.py).
+ * options: VRTO_LIT_*.  t_out_or_null: camera-ray hit distance in world units, -1 = miss.  Interp modes, resolution <= 8. */
+#define VRTO_LIT_NORMALISED_CAMERA 1u /* study: the same shaders fed the NORMALISED camera direction (the product's documented deviation): \
+                                         isolates the intersection's numerics from what the un-normalised direction does to offsets and shading */
+typedef struct vrto_literal_stats {
+    uint64_t rays;             /* (ray, instance) intersection-shader invocations */
+    uint64_t iterations;       /* leaves visited */
+    uint64_t solid_start_hits; /* accepted hits of a solid start cell (AABB-face normal) */
+    uint64_t entry_hits;       /* accepted hits reported at the START of a leaf's search interval (the cubic is <= 0 there: a root in the
+                                  first 0.1 of the cell that the previous cell's extrapolated cubic did not find) */
+    uint64_t root_hits;        /* accepted hits at a root of the cubic */
+    uint64_t tail_hits;        /* ... of which beyond the leaf's true exit: found on the extrapolated cubic, in the next cell */
+    uint64_t red_hits;         /* accepted budget-exhaustion hits (unlit red, t = 10) */
+    uint64_t rejected_reports; /* ReportHit outside [0, RayTCurrent]: the shader returns without a hit */
+} vrto_literal_stats;
+int vrto_ref_literal_render(const vrt_scene* scene, const vrto_volume* volumes, const uint8_t* env_rgba8, int env_face_size,
+                            const vrt_params* params, int row0, int rows, float* out_rgba, float* t_out_or_null, unsigned options,
+                            vrto_literal_stats* stats_or_null, int threads);
+
+typedef struct vrto_octree_info {
+    uint64_t nodes;              /* nodes of the collapsed tree */
+    uint64_t leaves_at_depth[9]; /* depth 0 = the whole volume ... depth `resolution` = one cell */
+    int32_t texture_edge;        /* 2 * ceil(cbrt(nodes)): the traversal texture's edge in texels */
+    int32_t pointer_overflow;    /* 1: a child-block coordinate exceeds 255 and wraps in its 8-bit pointer texel (RDXVoxelVolume.cpp:282-284) */
+} vrto_octree_info;
+int vrto_literal_octree_info(const vrto_volume* vol, vrto_octree_info* out);
+
 /* Debug: the two-level empty-space table the march uses for `vol` under its metric (step_max > 0) — skip_out: nb^3
  * Chebyshev brick distances D, nib_out: nb^3 words of sub-block nibbles — and (field_out, N^3 floats) the field the march
  * samples (the integer field +-q for VRT_FORMAT_TEXEL16).  Any pointer may be NULL. */

@@ -66,13 +66,37 @@ def quantise(img):
     return np.floor(np.minimum(img[..., :3], 1.0) * 255.0 + 0.5).astype(np.uint8)
 
 
-if __name__ == "__main__":
-    from oracle.binding import OracleScene
+def literal_name(name):
+    """ref_c3vox256_f32_320x180 -> ref_literal_c3vox256_f32_320x180"""
+    return "ref_literal_" + name[len("ref_"):]
 
+
+LITERAL_STATS = ("rays", "iterations", "solid_start_hits", "entry_hits", "root_hits", "tail_hits", "red_hits", "rejected_reports")
+
+if __name__ == "__main__":
+    from oracle.binding import OracleScene, LIT_NORMALISED_CAMERA
+
+    only = set(sys.argv[1:])
     for name, case in CASES.items():
+        if only and name not in only and literal_name(name) not in only and "literal" not in only:
+            continue
         sc, p, row0, rows = build_case(case)
-        img, t = OracleScene(sc).ref_render(p, row0, rows, threads=8)
-        # 8-bit colours (what the reference's target holds) + the camera rays' hit distances as float16-safe float32
-        np.savez_compressed(os.path.join(HERE, name + ".npz"), rgb8=quantise(img), t=t.astype(np.float32),
+        o = OracleScene(sc)
+        if not only or name in only:
+            img, t = o.ref_render(p, row0, rows, threads=8)
+            # 8-bit colours (what the reference's target holds) + the camera rays' hit distances as float16-safe float32
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), rgb8=quantise(img), t=t.astype(np.float32),
+                                window=np.array([p.width, p.height, row0, rows], np.int32))
+            print(name, img.shape, "hits", int((t > 0).sum()))
+        # The LITERAL restatement of the reference's shaders (vrto_ref_literal_render, oracle/vrt_ref_literal.inl): fp32, its own
+        # nudges, octree leaves, three secant steps, abs()-weighted normal, budget, un-normalised camera direction (rgb8 / t) — and the
+        # same shaders fed the normalised direction (rgb8_norm / t_norm), which separates what the intersection's numerics do from
+        # what the un-normalised direction does to the shading.  The volumes are read through the reference's 16-bit texel whatever
+        # the case's device format says.
+        img, t, st = o.ref_literal_render(p, row0, rows, threads=8)
+        imgn, tn, _ = o.ref_literal_render(p, row0, rows, threads=8, options=LIT_NORMALISED_CAMERA)
+        np.savez_compressed(os.path.join(HERE, literal_name(name) + ".npz"), rgb8=quantise(img), t=t.astype(np.float32),
+                            rgb8_norm=quantise(imgn), t_norm=tn.astype(np.float32),
+                            stats=np.array([st[k] for k in LITERAL_STATS], np.int64),
                             window=np.array([p.width, p.height, row0, rows], np.int32))
-        print(name, img.shape, "hits", int((t > 0).sum()))
+        print(literal_name(name), img.shape, "hits", int((t > 0).sum()), st)
