@@ -68,6 +68,20 @@ extern "C" {
                                      (DXGI_FORMAT_B8G8R8A8_UNORM, DXConstants.cpp:21, DXRenderer.cpp:1322): B in the low byte; same values */
 #define VRT_FLAG_NO_HIT_POLISH 1024 /* closest hits stay where the cone threshold stopped the ray (rounds 1-3) instead of moving on to the surface's
                                       zero crossing by VRT_HIT_POLISH_SAMPLES secant samples: A/B measurements, tests */
+/* Two of the reference's artefacts, selectable so that a frame can be "what the DXR backend renders" (the C++ adaptor sets both by default,
+ * like its default normal texel; measured against the literal restatement of the reference's shaders): */
+#define VRT_FLAG_REFERENCE_VIEW_VECTOR 4096 /* the reference never normalises its camera direction (GenerateCameraRay, Shaders/Include/Ray.hlsli:36-48):
+                                      its closest-hit shader evaluates the BRDF with wo = -WorldRayDirection(), a vector of length
+                                      L = |(x aspect tan(fov/2), y tan(fov/2), -1)| = 1 (frame centre) ... 1.55 (corner of a 16:9 frame at 60 degrees),
+                                      and backs the camera ray's secondary rays off by 0.1 L (Raytracing.hlsl:52,85-95).  With this flag the camera
+                                      ray's hit is shaded with wo = -L d and its shadow / mirror rays start 0.1 L (Cube modes 0.2 L) back; rays
+                                      behind a mirror bounce are unit vectors in the reference too.  Smooth materials' highlights move by up
+                                      to 13 of 255 (9.5 % of a mirror scene's surface pixels by more than one step); rough ones do not move */
+#define VRT_FLAG_REFERENCE_BOUNDARY_TEXELS 8192 /* the normal's central difference (GetNormal, Voxel.hlsli:783-804) reads the cells one step either side of
+                                      the hit's; where such a cell lies outside the grid the reference's Load returns texel 0 for the samples beyond
+                                      the volume texture (GetDensity, :607-617), i.e. the neighbour's interpolant is (1 - f) x the boundary plane's.
+                                      Default (SURVEY App. A rule 7): the neighbour cell is clamped to the grid (a one-sided difference).  Only
+                                      surfaces within one cell of the volume's box differ */
 #define VRT_HIT_POLISH_SAMPLES 2   /* part of the march contract: samples a closest hit spends on its way from the stop point to the crossing */
 #define VRT_FLAG_NO_TIMING 16    /* the launch records no event pair: vrt_last_timing / vrt_timing_history report 0 ms for it.
                                    An event pair costs 5-7 us of queue time per launch (profiles/r02_launch_overhead.txt);
@@ -193,7 +207,8 @@ typedef struct vrt_params {
                              (speed only, never results); bit 2: VRT_FLAG_DIAG_TIMELINE; bit 3:
                              VRT_FLAG_OUTPUT_RGBA8; bit 4: VRT_FLAG_NO_TIMING; bit 5: accepted and ignored (it was round 1's
                              VRT_FLAG_SKIP_EMPTY: the march never samples empty cells now); bit 6: VRT_FLAG_BLOCK_PER_FRAME; bit 7: VRT_FLAG_NO_CULL_RECT;
-                             bit 8: VRT_FLAG_FULL_ONE_KERNEL; bit 9: VRT_FLAG_FULL_THREE_PASS; bit 10: VRT_FLAG_NO_HIT_POLISH; bit 11: VRT_FLAG_OUTPUT_BGRA8.  Others 0 */
+                             bit 8: VRT_FLAG_FULL_ONE_KERNEL; bit 9: VRT_FLAG_FULL_THREE_PASS; bit 10: VRT_FLAG_NO_HIT_POLISH; bit 11: VRT_FLAG_OUTPUT_BGRA8;
+                             bit 12: VRT_FLAG_REFERENCE_VIEW_VECTOR; bit 13: VRT_FLAG_REFERENCE_BOUNDARY_TEXELS.  Others 0 */
     float eps_hit;        /* hit when the scaled distance falls below this (ray-parameter units) */
     float eps_in;         /* entry offset after the AABB slab test (reference: 0.01, Raytracing.hlsl:178) */
     float step_min;       /* lower bound of one march step (ray-parameter units) */
@@ -419,6 +434,17 @@ int vrt_launch_history(vrt_ctx* ctx, int n, float* kernel_ms_out, int* frames_ou
  * per-lane sample chain, tap-fetch cycles, march-loop cycles, march-loop iterations} of the lane with the longest
  * chain.  Returns the number of words available and copies min(max_words, that). */
 long long vrt_debug_wave_records(vrt_ctx* ctx, int which, uint32_t* out, long long max_words);
+
+/* Diagnostics: which closest-hit kernel form the last march launch on the first device ran (a bit set of VRT_FORM_*; negative: error).
+ * The lean kernel (camera ray + directional shadow ray, 8 waves per SIMD) is what a frame gets unless it needs more; tests and bench.py
+ * use this to assert that, e.g., the reference's default material state (a 1x1 normal texel on every material) stays on it. */
+#define VRT_FORM_FULL 1        /* full closest hit: point / spot lights, mirror bounces or material IMAGES */
+#define VRT_FORM_PASSES 2      /* ... as three passes (a block of frames) rather than one kernel */
+#define VRT_FORM_TEXTURED 4    /* a textured render mode with a bound texture in sight */
+#define VRT_FORM_MAY_BOUNCE 8  /* bounces allowed and some material can mirror */
+#define VRT_FORM_LEAN_REF 16   /* the lean kernel's instantiation that folds constant (1x1) textures in and honours
+                                  VRT_FLAG_REFERENCE_VIEW_VECTOR / _BOUNDARY_TEXELS */
+int vrt_debug_last_kernel_form(vrt_ctx* ctx);
 
 const char* vrt_strerror(int status);
 /* "x.y.z gfx950" */

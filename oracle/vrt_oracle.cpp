@@ -106,7 +106,7 @@ Camera camera_basis(const vrt_scene* s, int width, int height) {
     return c;
 }
 
-inline void camera_ray(const Camera& c, int width, int height, int px, int py, V3& o, V3& d) {
+inline void camera_ray(const Camera& c, int width, int height, int px, int py, V3& o, V3& d, float* len_or_null = nullptr) {
     /* pixel centre -> NDC with the reciprocal of the frame size (one rounding more than a division; the kernel takes the
        reciprocals from the host: two exact divisions per pixel were 8 % of a sky pixel's instructions) */
     const float inv_w = 1.0f / (float)width, inv_h = 1.0f / (float)height;
@@ -119,6 +119,8 @@ inline void camera_ray(const Camera& c, int width, int height, int px, int py, V
                 (tx * c.r0.z + ty * c.r1.z) - c.r2.z);
     o = c.origin;
     d = normalize(dir);
+    /* |direction| before the normalisation — what the reference's un-normalised WorldRayDirection() is long (VRT_FLAG_REFERENCE_VIEW_VECTOR) */
+    if (len_or_null) *len_or_null = sqrtf(dot(dir, dir));
 }
 
 /* GenerateCameraRay as the shader leaves it (Ray.hlsli:36-48): target = projInv * (x, -y, 1, 1), direction = viewInv * (target.xyz, 0),
@@ -920,9 +922,21 @@ bool march_instance(const Packed& P, int ii, V3 o, V3 d, float t_cur, float t_ba
                     int xp = cx + 1 > N2 ? N2 : cx + 1, xm = cx - 1 < 0 ? 0 : cx - 1;
                     int yp = cy + 1 > N2 ? N2 : cy + 1, ym = cy - 1 < 0 ? 0 : cy - 1;
                     int zp = cz + 1 > N2 ? N2 : cz + 1, zm = cz - 1 < 0 ? 0 : cz - 1;
+                    if (P.prm.flags & VRT_FLAG_REFERENCE_BOUNDARY_TEXELS) {
+                        /* A neighbour cell beyond the grid: the reference's Load returns 0 for its samples outside the volume texture
+                           (Voxel.hlsli:607-617), so its interpolant is the boundary plane's, weighted with the in-texture side's weight:
+                           cell N-1: (1 - f) x the plane of samples N-1 = (1 - f) x cell N-2 at fraction 1; cell -1: f x cell 0 at fraction 0. */
+                        n.x = (cx + 1 > N2 ? (1.0f - fx) * trilinear(V, N2, cy, cz, 1.0f, fy, fz) : trilinear(V, xp, cy, cz, fx, fy, fz)) -
+                              (cx - 1 < 0 ? fx * trilinear(V, 0, cy, cz, 0.0f, fy, fz) : trilinear(V, xm, cy, cz, fx, fy, fz));
+                        n.y = (cy + 1 > N2 ? (1.0f - fy) * trilinear(V, cx, N2, cz, fx, 1.0f, fz) : trilinear(V, cx, yp, cz, fx, fy, fz)) -
+                              (cy - 1 < 0 ? fy * trilinear(V, cx, 0, cz, fx, 0.0f, fz) : trilinear(V, cx, ym, cz, fx, fy, fz));
+                        n.z = (cz + 1 > N2 ? (1.0f - fz) * trilinear(V, cx, cy, N2, fx, fy, 1.0f) : trilinear(V, cx, cy, zp, fx, fy, fz)) -
+                              (cz - 1 < 0 ? fz * trilinear(V, cx, cy, 0, fx, fy, 0.0f) : trilinear(V, cx, cy, zm, fx, fy, fz));
+                    } else {
                     n.x = trilinear(V, xp, cy, cz, fx, fy, fz) - trilinear(V, xm, cy, cz, fx, fy, fz);
                     n.y = trilinear(V, cx, yp, cz, fx, fy, fz) - trilinear(V, cx, ym, cz, fx, fy, fz);
                     n.z = trilinear(V, cx, cy, zp, fx, fy, fz) - trilinear(V, cx, cy, zm, fx, fy, fz);
+                    }
                 }
                 float l2 = dot(n, n);
                 if (!(l2 > 0.0f)) { /* zero or NaN gradient → (0,0,0) (Voxel.hlsli:794-798) */
@@ -1143,7 +1157,9 @@ inline Surface textured_surface(const Volume& V, const Instance& I, V3 hit_world
 const int MAX_DEPTH = 3; /* MAX_RAY_RECURSION_DEPTH, RaytracingHlsl.h:32 */
 
 /* TraceRadianceRay + VRClosestHit / VRMiss, level = 1 for the primary ray. */
-V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st) {
+/* view_scale: |WorldRayDirection()| of the reference for this ray — 1, or with VRT_FLAG_REFERENCE_VIEW_VECTOR the camera ray's un-normalised
+   length: wo = -view_scale * d, secondary rays start 0.1 * view_scale back (Raytracing.hlsl:51-52,85-95). */
+V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st, float view_scale = 1.0f) {
     HitRec h;
     uint64_t steps = 0;
     bool hit = trace_closest(P, o, d, 10000.0f, t_base, h, steps);
@@ -1177,9 +1193,9 @@ V3 radiance_ray(const Packed& P, V3 o, V3 d, int level, float t_base, Stats& st)
         return albedo;
 
     /* secondary rays start 0.1 back along the ray (Raytracing.hlsl:52), 0.2 in the Cube modes (Raytracing_Cube.hlsl:52) */
-    const float back = (mode >= VRT_MODE_CUBE ? 0.2f : 0.1f) * g_dir_scale; /* g_dir_scale: 1, or (study only) |un-normalised camera direction| */
+    const float back = (mode >= VRT_MODE_CUBE ? 0.2f : 0.1f) * (g_dir_scale * view_scale); /* g_dir_scale: 1, or (study only) |un-normalised camera direction| */
     V3 so = v3(hit_pos.x - d.x * back, hit_pos.y - d.y * back, hit_pos.z - d.z * back);
-    V3 wo = v3(-d.x, -d.y, -d.z);
+    V3 wo = v3(-d.x * view_scale, -d.y * view_scale, -d.z * view_scale);
     bool shadows = level < MAX_DEPTH; /* TraceShadowRay's recursion guard, Ray.hlsli:83-86 */
     V3 diffuse = v3(0.0f, 0.0f, 0.0f); /* SHADOW_BRIGHTNESS */
 
@@ -1294,8 +1310,13 @@ void render_rows(const Packed& P, int y0, int y1, int row0, float* out, Stats& s
     for (int y = y0; y < y1; y++) {
         for (int x = 0; x < W; x++) {
             V3 o, d;
-            camera_ray(P.cam, W, H, x, y, o, d);
-            if (P.literal && !(P.lit_options & VRTO_LIT_NORMALISED_CAMERA)) camera_ray_raw(P.cam, W, H, x, y, o, d);
+            float view_scale = 1.0f;
+            camera_ray(P.cam, W, H, x, y, o, d, &view_scale);
+            if (!(P.prm.flags & VRT_FLAG_REFERENCE_VIEW_VECTOR)) view_scale = 1.0f;
+            if (P.literal) { /* the literal restatement takes its own direction; its length travels with it */
+                view_scale = 1.0f;
+                if (!(P.lit_options & VRTO_LIT_NORMALISED_CAMERA)) camera_ray_raw(P.cam, W, H, x, y, o, d);
+            }
             if (g_unnormalised_offsets) {
                 const float sx = (((float)x + 0.5f) / (float)W) * 2.0f - 1.0f, sy = (((float)y + 0.5f) / (float)H) * 2.0f - 1.0f;
                 g_dir_scale = sqrtf(1.0f + (sx * P.cam.cx) * (sx * P.cam.cx) + (sy * P.cam.cy) * (sy * P.cam.cy));
@@ -1304,7 +1325,7 @@ void render_rows(const Packed& P, int y0, int y1, int row0, float* out, Stats& s
             g_positions[0] = g_positions[1] = 0;
             g_ray_class = 0;
             g_leading_skips = 0;
-            V3 c = radiance_ray(P, o, d, 1, 0.0f, st);
+            V3 c = radiance_ray(P, o, d, 1, 0.0f, st, view_scale);
             if (P.steps_img) {
                 const uint64_t a = g_positions[0] < 0xffffu ? g_positions[0] : 0xffffu, b = g_positions[1] < 0xffffu ? g_positions[1] : 0xffffu;
                 P.steps_img[(size_t)(y - row0) * W + x] = (uint32_t)(a | (b << 16));

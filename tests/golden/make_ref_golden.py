@@ -46,6 +46,9 @@ CASES = {
     "ref_c5inst128_1080p_rows300": (scenes.config5_instances, dict(resolution=7, env=16), 1920, 1080, 300, 64, True),
     # the whole closest-hit shader: mirroring spheres (bounces to MAX_RAY_RECURSION_DEPTH), a point and a spot light with their shadow rays
     "ref_fullhit64_320x180": (_mirror_scene, dict(resolution=6, env=32), 320, 180, 0, 180, True, 2),
+    # a surface within one cell of its volume's boundary (a box 0.6 cells inside a 16^3 volume): the normal's central difference reaches
+    # beyond the grid, where the reference's Load returns texel 0 — VRT_FLAG_REFERENCE_BOUNDARY_TEXELS' fixture
+    "ref_boundarybox16_320x180": (scenes.boundary_box_scene, dict(resolution=4, env=16), 320, 180, 0, 180, True),
     # ... and the textured mode (Interp, the reference's default): tri-planar albedo / normal / RM textures on the same scene
     "ref_textured64_320x180": (scenes.textured_scene, dict(resolution=6, env=32), 320, 180, 0, 180, True, 2, v._abi.MODE_INTERP),
 }

@@ -461,6 +461,8 @@ def test_hit_mask_is_the_reference_surface_on_the_benched_volume(renderer, oracl
 # depend on the sphere-trace's contract.  Bounds: fraction of the interior of the reference's surfaces whose 8-bit colour differs
 # by more than 1 / 2 steps (tests/ref_pixels.py); measured values in DESIGN.md §5.
 REF_PIXEL_BOUNDS = {
+    # (ref_boundarybox16_320x180, a surface within a cell of its volume's box, is test_hip_frame_against_the_literal_reference_frame's: the
+    # default boundary rule differs from the reference's there by design)
     "ref_c3vox256_texel16_320x180": (0.002, 0.002),
     "ref_c3vox256_f32_320x180": (0.002, 0.002),
     "ref_c3vox256_texel16_1080p_rows492": (0.001, 0.001),
@@ -512,6 +514,145 @@ def test_hip_frame_is_the_reference_frame(renderer, name):
     img8, _ = gpu_render(renderer, sc, q)
     img, _ = gpu_render(renderer, sc, p)
     assert np.array_equal(np.asarray(img8)[..., :3], ref_pixels.quantise(img))
+
+
+# ---- "what the DXR backend renders" (round 5): the literal restatement's frames, the two reference flags, constant textures -------------------
+REF_FLAGS = _abi.FLAG_REFERENCE_VIEW_VECTOR | _abi.FLAG_REFERENCE_BOUNDARY_TEXELS
+# HIP frame with both flags against tests/golden/ref_literal_*.npz (vrto_ref_literal_render: the reference's shaders statement by statement,
+# fp32, nudges, octree leaves, three secant steps, un-normalised direction): interior "more than one step" fraction.  Same bounds as the
+# oracle's sphere-trace in tests/test_reference_pixels.py (GPU = oracle to 7e-7).
+LITERAL_PIXEL_BOUNDS = {
+    "ref_c3vox256_texel16_320x180": 0.004,
+    "ref_c3vox256_texel16_1080p_rows492": 0.007,
+    "ref_c3vox256_texel16_2160p_rows1040": 0.007,
+    "ref_c5inst128_1080p_rows300": 0.004,
+    "ref_c2sphere64_320x180": 0.002,
+    "ref_c5inst32_320x180": 0.001,
+    "ref_boundarybox16_320x180": 0.003,
+    "ref_fullhit64_320x180": 0.015,
+    "ref_textured64_320x180": 0.02,
+}
+
+
+@pytest.mark.parametrize("name", sorted(LITERAL_PIXEL_BOUNDS))
+def test_hip_frame_against_the_literal_reference_frame(renderer, oracle_lib, name):
+    """HIP <-> literal (bounded), HIP <-> idealised (the fixture of test_hip_frame_is_the_reference_frame) and, on the
+    same inputs, HIP = oracle <= 1e-4 with the two reference flags set — the three columns of DESIGN.md §5.0."""
+    from tests import ref_pixels
+
+    sc, p, row0, rows = _ref_case(name)
+    q = _abi.vrt_params.from_buffer_copy(p)
+    q.flags |= REF_FLAGS
+    img, t = gpu_render(renderer, sc, q)
+    m = ref_pixels.compare(img[row0:row0 + rows], name, against="literal")
+    mi = ref_pixels.compare(img[row0:row0 + rows], name, against="idealised")
+    print("ref-pixels literal", name, m, "| idealised", mi)
+    assert m["interior_pixels"] > 1000 and m["gt1"] <= LITERAL_PIXEL_BOUNDS[name], m
+    ref, st = OracleScene(sc).render(q, row0, rows, threads=8)
+    assert np.abs(img[row0:row0 + rows] - ref).max() <= TOL
+
+
+@pytest.mark.parametrize("case", ["lean", "lean_texel16", "bvh", "full_one_kernel", "full_passes", "textured", "boundary", "cube"])
+def test_reference_flags_parity(renderer, oracle_lib, case):
+    """VRT_FLAG_REFERENCE_VIEW_VECTOR (wo = -L d, secondary rays 0.1 L back) and VRT_FLAG_REFERENCE_BOUNDARY_TEXELS in every kernel form:
+    GPU = oracle <= 1e-4 with exact counters, and the frames DIFFER from the un-flagged ones (the flags reach the kernels)."""
+    bounces, mode, flags = 0, _abi.MODE_INTERP_NOTEX, REF_FLAGS
+    if case == "lean":
+        sc = scenes.config3_torus(6, 16)
+    elif case == "lean_texel16":
+        sc = scenes.config3_voxelized(6, 16, device_format=_abi.FORMAT_TEXEL16)
+    elif case == "bvh":
+        sc = scenes.config5_instances(5, 16)
+    elif case in ("full_one_kernel", "full_passes"):
+        sc, bounces = scenes.full_closest_hit_scene(5, 16), 2
+        flags |= _abi.FLAG_FULL_THREE_PASS if case == "full_passes" else 0
+    elif case == "textured":
+        sc, bounces, mode = scenes.textured_scene(5, 16), 2, _abi.MODE_INTERP
+    elif case == "boundary":
+        sc = scenes.boundary_box_scene(4, 16)
+    else:
+        sc, mode = scenes.config3_torus(5, 16), _abi.MODE_CUBE_NOTEX
+    p = v.default_params(192, 108, scenes.min_cell(sc), 255, shadow=True, mode=mode)
+    p.max_bounces = bounces
+    plain, _ = gpu_render(renderer, sc, p)
+    plain = plain.copy()
+    q = _abi.vrt_params.from_buffer_copy(p)
+    q.flags |= flags
+    img, t = assert_parity(renderer, sc, q, check_stats=len(sc.Objects) == 1)
+    form = renderer.last_kernel_form()
+    if case in ("lean", "lean_texel16", "bvh", "boundary", "cube"):
+        assert form & _abi.FORM_LEAN_REF and not form & _abi.FORM_FULL
+    else:
+        assert form & _abi.FORM_FULL and bool(form & _abi.FORM_PASSES) == (case == "full_passes")
+    assert np.abs(img - plain).max() > 1e-5  # (even the Cube modes' shading sees the longer view vector)
+
+
+@pytest.mark.parametrize("case", ["single_f32", "single_texel16", "bvh", "unlit", "mirror_const_rm", "block"])
+def test_constant_textures_stay_on_the_lean_kernel(renderer, oracle_lib, case):
+    """the reference binds a 1x1 default texture to every unbound material slot (RDXScene.cpp:241-260); its normal texel
+    (127, 127, 255) tilts every normal by 0.3 degrees in Interp, its default mode.  A 1x1 texture is a constant: folded into the lean
+    kernel (no fetch, 8 waves per SIMD, no full closest hit) with the very arithmetic of the texture path — GPU = oracle (which samples
+    the 1x1 image like any other) <= 1e-4, exact counters, and bit-equal to the full closest hit forced onto the same frame."""
+    mode, bounces = _abi.MODE_INTERP, 0
+    if case == "single_f32":
+        sc = scenes.config3_voxelized(6, 16)
+    elif case in ("single_texel16", "block"):
+        sc = scenes.config3_voxelized(6, 16, device_format=_abi.FORMAT_TEXEL16)
+    elif case == "bvh":
+        sc = scenes.config5_instances(5, 16)
+    elif case == "unlit":
+        sc, mode = scenes.config3_torus(5, 16), _abi.MODE_INTERP_UNLIT
+    else:
+        # a constant RM texel that turns a rough material (0.8) into a mirror (0.8 * 51/255 = 0.16): the host must see it and launch the full form
+        sc, bounces = scenes.config3_torus(5, 16), 2
+        sc.volumes()[0].Material.RMTexture = np.array([[[51, 255, 0, 255]]], np.uint8)
+    scenes.with_reference_default_textures(sc)
+    if case in ("bvh", "unlit"):  # every slot a constant: albedo and RM factors too
+        for vol in sc.volumes():
+            vol.Material.AlbedoTexture = np.array([[[200, 180, 90, 255]]], np.uint8)
+            vol.Material.RMTexture = np.array([[[230, 40, 0, 255]]], np.uint8)
+    p = v.default_params(192, 108, scenes.min_cell(sc), 255, shadow=True, mode=mode)
+    p.max_bounces = bounces
+    p.flags |= REF_FLAGS
+    if case == "block":
+        import torch
+
+        cams = scenes.orbit_cameras(sc, 4)
+        renderer.SetSceneToRender(sc)
+        renderer.SyncWithScene()
+        out = torch.zeros((4, p.height, p.width, 4), dtype=torch.float32, device="cuda")
+        renderer.render_block(p, 4, out.data_ptr(), p.height * p.width * 16, 0, cameras=cams, rows=(0, p.height))
+        torch.cuda.synchronize()
+        form = renderer.last_kernel_form()
+        assert form & _abi.FORM_LEAN_REF and form & _abi.FORM_TEXTURED and not form & (_abi.FORM_FULL | _abi.FORM_PASSES)
+        import copy
+
+        for f in (0, 3):
+            s2 = copy.copy(sc)
+            s2.Camera = v.VCamera(Position=cams[f][0], Rotation=cams[f][1], FOVAngle=cams[f][2])
+            ref, _ = OracleScene(s2).render(p, threads=8)
+            assert np.abs(out[f].cpu().numpy() - ref).max() <= TOL
+        return
+    img, t = assert_parity(renderer, sc, p, check_stats=len(sc.Objects) == 1)
+    form = renderer.last_kernel_form()
+    if case == "mirror_const_rm":
+        assert form & _abi.FORM_FULL and form & _abi.FORM_MAY_BOUNCE and t["bounce_rays"] > 0
+        return
+    assert form & _abi.FORM_LEAN_REF and form & _abi.FORM_TEXTURED and not form & _abi.FORM_FULL, form
+    # the texel does something (0.3 degrees of tilt: a third of the surface's pixels move by one 8-bit step) ...
+    bare = scenes.config3_voxelized(6, 16) if case == "single_f32" else None
+    if bare is not None:
+        img0, _ = gpu_render(renderer, bare, p)
+        assert 1e-4 < np.abs(img0 - img).max() < 0.1
+    # ... and the same frame through the full closest hit (a 2x2 copy of the texel is an image to the host): bit-equal
+    for vol in sc.volumes():
+        for name in ("AlbedoTexture", "NormalTexture", "RMTexture"):
+            t1 = getattr(vol.Material, name)
+            if t1 is not None:
+                setattr(vol.Material, name, np.ascontiguousarray(np.tile(t1, (2, 2, 1))))
+    img2, t2 = gpu_render(renderer, sc, p)
+    assert renderer.last_kernel_form() & _abi.FORM_FULL
+    assert np.array_equal(img2, img) and {k: t2[k] for k in STAT_KEYS} == {k: t[k] for k in STAT_KEYS}
 
 
 def test_hip_frame_without_the_hit_polish_is_what_rounds_1_to_3_rendered(renderer):

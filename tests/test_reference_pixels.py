@@ -122,3 +122,204 @@ def test_reference_intersection_on_an_analytic_sphere(cases):
             assert abs(t[y, x] - (-b[i] - np.sqrt(disc[i]))) <= 2 * cell * cell / (8 * 40.0) / max(np.sqrt(disc[i]) / 40.0, 0.05) + 1e-3
         elif disc[i] < -(2 * cell) ** 2 * 4:
             assert t[y, x] < 0
+
+
+# ---- the LITERAL restatement of the reference's shaders (round 5) -----------------------------------------------------
+# tests/golden/ref_literal_*.npz: vrto_ref_literal_render (oracle/vrt_ref_literal.inl) — fp32, the un-normalised camera direction with every
+# offset and the shading's wo in its units, +0.01 / +0.1 nudges, collapsed-octree leaves, the cubic on [cellEnter, cellExit] with 2 regula-falsi
+# steps + 1 secant, abs()-weighted GetNormal with out-of-bounds texels 0, 255 leaves then the red hit — and the same shaders fed the normalised
+# direction.  A measuring instrument: how far are the reference's frames from the idealisation, and the product's frames from either?
+# Measured (fraction of interior pixels off by more than one 8-bit step): literal vs idealised 0.0015 (benched shell), 0.0044 (1080p band),
+# 0.0010 (sphere), 0 (instances), 0.097 (mirror scene) / 0.081 (textured) — of which 0.0032 / 0.0076 with the normalised direction: what the
+# un-normalised wo does to smooth materials' highlights is the large term, the intersection's own numerics are 0.1-0.8 %.
+from oracle.binding import LIT_NORMALISED_CAMERA  # noqa: E402
+
+REF_FLAGS = v._abi.FLAG_REFERENCE_VIEW_VECTOR | v._abi.FLAG_REFERENCE_BOUNDARY_TEXELS
+
+# (literal vs idealised, literal fed the normalised direction vs idealised): bounds on the "more than one step" interior fraction
+PAIR_BOUNDS = {
+    "ref_c3vox256_texel16_320x180": (0.003, 0.003),
+    "ref_c3vox256_texel16_1080p_rows492": (0.006, 0.006),
+    "ref_c3vox256_texel16_2160p_rows1040": (0.006, 0.006),
+    "ref_c5inst128_1080p_rows300": (0.004, 0.004),
+    "ref_c2sphere64_320x180": (0.002, 0.002),
+    "ref_c5inst32_320x180": (0.001, 0.001),
+    "ref_boundarybox16_320x180": (0.001, 0.001),
+    "ref_fullhit64_320x180": (0.11, 0.005),    # smooth mirrors: the un-normalised wo moves the highlights (max 13 of 255)
+    "ref_textured64_320x180": (0.09, 0.010),
+}
+# sphere-trace (oracle = HIP to 7e-7) with the two reference flags vs the literal frame: interior "more than one step" fraction
+# (measured: 0.0019, 0.0046, 0.0041, 0.0026, 0.0010, 0, 0.0015, 0.0087, 0.0134)
+LITERAL_BOUNDS = {
+    "ref_c3vox256_texel16_320x180": 0.004,
+    "ref_c3vox256_texel16_1080p_rows492": 0.007,
+    "ref_c3vox256_texel16_2160p_rows1040": 0.007,
+    "ref_c5inst128_1080p_rows300": 0.004,
+    "ref_c2sphere64_320x180": 0.002,
+    "ref_c5inst32_320x180": 0.001,
+    "ref_boundarybox16_320x180": 0.003,
+    "ref_fullhit64_320x180": 0.015,
+    "ref_textured64_320x180": 0.02,
+}
+
+
+@pytest.mark.parametrize("name", sorted(PAIR_BOUNDS))
+def test_the_two_restatements_of_the_reference_agree(name):
+    """Literal vs idealised, from the committed files alone: same hit mask up to a few silhouette pixels, interiors within the bounds; no
+    budget-exhaustion (red) hit and no rejected report in any fixture's frame."""
+    fp = ref_pixels.fixture_pairs(name)
+    a, b = PAIR_BOUNDS[name]
+    assert fp["literal_vs_idealised"]["gt1"] <= a, fp
+    assert fp["literal_norm_vs_idealised"]["gt1"] <= b, fp
+    assert fp["hit_mask_differs"] <= 30 and fp["t_abs_diff_median"] < 0.01, fp
+    assert fp["stats"]["red_hits"] == 0 and fp["stats"]["root_hits"] > 1000
+
+
+@pytest.mark.parametrize("name", sorted(LITERAL_BOUNDS))
+def test_sphere_trace_frame_against_the_literal_reference_frame(cases, name):
+    """The product's march (CPU restatement; the HIP frames are checked against the same files in tests/test_parity_gpu.py) with
+    VRT_FLAG_REFERENCE_VIEW_VECTOR | _BOUNDARY_TEXELS — what the C++ adaptor sets by default — against the literal restatement's frame."""
+    o, p, row0, rows = cases(name)
+    q = v._abi.vrt_params.from_buffer_copy(p)
+    q.flags |= REF_FLAGS
+    img, _ = o.render(q, row0, rows, threads=8)
+    m = ref_pixels.compare(img, name, against="literal")
+    assert m["gt1"] <= LITERAL_BOUNDS[name], m
+    assert m["frame_gt1"] <= 0.01 or name in ("ref_fullhit64_320x180", "ref_textured64_320x180"), m
+
+
+def test_what_the_two_reference_flags_are_worth(cases):
+    """Without VRT_FLAG_REFERENCE_VIEW_VECTOR a tenth of a mirror scene's surface pixels differ from the reference's by more than a step,
+    without _BOUNDARY_TEXELS an eighth of a surface that hugs its volume's boundary: the numbers DESIGN.md §5.0 quotes."""
+    o, p, row0, rows = cases("ref_fullhit64_320x180")
+    img, _ = o.render(p, row0, rows, threads=8)
+    assert ref_pixels.compare(img, "ref_fullhit64_320x180", against="literal")["gt1"] >= 0.08
+    o, p, row0, rows = cases("ref_boundarybox16_320x180")
+    q = v._abi.vrt_params.from_buffer_copy(p)
+    q.flags |= v._abi.FLAG_REFERENCE_VIEW_VECTOR
+    img, _ = o.render(q, row0, rows, threads=8)
+    assert ref_pixels.compare(img, "ref_boundarybox16_320x180", against="literal")["gt1"] >= 0.10
+
+
+def test_boundary_texel_rule_on_a_surface_that_hugs_its_volume(cases):
+    """a box 0.6 cells inside a 16^3 volume.  The idealised fixture (like the reference: texels beyond the texture read 0)
+    against the march in both rules: the default (neighbour cell clamped, SURVEY App. A rule 7) differs on an eighth of the surface, the
+    reference's rule sits at the interior cases' bound."""
+    name = "ref_boundarybox16_320x180"
+    o, p, row0, rows = cases(name)
+    img, _ = o.render(p, row0, rows, threads=8)
+    assert ref_pixels.compare(img, name)["gt1"] >= 0.10
+    q = v._abi.vrt_params.from_buffer_copy(p)
+    q.flags |= v._abi.FLAG_REFERENCE_BOUNDARY_TEXELS
+    img, _ = o.render(q, row0, rows, threads=8)
+    m = ref_pixels.compare(img, name)
+    assert m["interior_pixels"] > 3000 and m["gt1"] <= 0.002 and m["gt2"] <= 0.002 and m["frame_gt1"] <= 0.01, m
+
+
+def test_literal_fixtures_are_what_the_literal_restatement_renders(cases):
+    for name, r0, n in (("ref_c2sphere64_320x180", 0, 180), ("ref_boundarybox16_320x180", 0, 180), ("ref_c3vox256_texel16_320x180", 80, 24)):
+        o, p, row0, rows = cases(name)
+        for normalised in (False, True):
+            img, t, _ = o.ref_literal_render(p, row0 + r0, n, options=LIT_NORMALISED_CAMERA if normalised else 0)
+            rgb8, tf, _, _ = ref_pixels.load_literal(name, normalised)
+            assert (ref_pixels.quantise(img) == rgb8[r0:r0 + n]).all()
+            assert np.array_equal(t, tf[r0:r0 + n])
+
+
+def test_literal_restatement_reads_nothing_of_the_march_contract_nor_the_device_format(cases):
+    o, p, row0, rows = cases("ref_c5inst32_320x180")
+    q = v._abi.vrt_params.from_buffer_copy(p)
+    q.k_relax, q.eps_hit, q.cone_eps, q.step_min, q.max_steps, q.flags = 0.7, p.eps_hit * 9, 0.0, p.step_min * 5, 7, v._abi.FLAG_NO_HIT_POLISH
+    a, ta, _ = o.ref_literal_render(p, 60, 40)
+    b, tb, _ = o.ref_literal_render(q, 60, 40)
+    assert np.array_equal(a, b) and np.array_equal(ta, tb)
+    # the reference's GPU only ever sees its 16-bit texel: the f32 and the texel16 case of the benched shell give one literal frame
+    f32, _, _, _ = ref_pixels.load_literal("ref_c3vox256_f32_320x180")
+    t16, _, _, _ = ref_pixels.load_literal("ref_c3vox256_texel16_320x180")
+    assert np.array_equal(f32, t16)
+
+
+def test_literal_intersection_on_an_analytic_sphere(cases):
+    """Its own pin: every camera ray's reported hit lies within the trilinear bound of the analytic ray-sphere distance (world units:
+    t x |direction|), although the shader finds it with three secant steps on an interval that overhangs the cell by 0.1."""
+    o, p, row0, rows = cases("ref_c2sphere64_320x180")
+    _, t, st = o.ref_literal_render(p)
+    assert st["red_hits"] == 0 and st["rejected_reports"] == 0
+    cell = 200.0 / 64
+    ys, xs = np.mgrid[0:p.height:7, 0:p.width:7]
+    org, dr = o.camera_rays(p.width, p.height, list(zip(xs.ravel(), ys.ravel())))
+    b = (org * dr).sum(1)
+    c = (org * org).sum(1) - 40.0 ** 2
+    disc = b * b - c
+    n = 0
+    for i, (x, y) in enumerate(zip(xs.ravel(), ys.ravel())):
+        if disc[i] > (2 * cell) ** 2 * 4:
+            n += 1
+            assert abs(t[y, x] - (-b[i] - np.sqrt(disc[i]))) <= 2 * cell * cell / (8 * 40.0) / max(np.sqrt(disc[i]) / 40.0, 0.05) + 2e-3
+        elif disc[i] < -(2 * cell) ** 2 * 4:
+            assert t[y, x] < 0
+    assert n > 20
+
+
+def test_collapsed_octree_of_the_literal_restatement(cases):
+    """VCellOctree as the reference builds and collapses it (Voxel/Private/Octree.cpp:70-107,181-262): leaves tile the volume, every node
+    but the root is one of a branch's 8 children, a volume without any surface is ONE leaf, and the pointer texture stays within 8 bits at
+    the benched size."""
+    from volumetricraytracer_amd import workloads as scenes
+
+    o, p, _, _ = cases("ref_c2sphere64_320x180")
+    info = o.octree_info(0)
+    r = 6
+    assert sum(n * 8 ** (r - d) for d, n in enumerate(info["leaves_at_depth"])) == (2 ** r) ** 3
+    leaves = sum(info["leaves_at_depth"])
+    assert (info["nodes"] - 1) % 8 == 0 and leaves == info["nodes"] - (info["nodes"] - 1) // 8  # nodes = branches + leaves, nodes = 1 + 8 branches
+    assert info["leaves_at_depth"][r] > 1000 and info["leaves_at_depth"][0] == 0 and not info["pointer_overflow"]
+    empty = v.VVoxelVolume(5, 50.0)
+    empty.fill(lambda X, Y, Z: 7.0 + 0 * X)
+    sc = v.VScene(Camera=v.look_minus_x_camera(10.0), DirectionalLight=v.demo_light(), Objects=[v.VVoxelObject(Volume=empty)])  # inside the box
+    oe = OracleScene(sc)
+    ie = oe.octree_info(0)
+    assert ie["nodes"] == 1 and ie["leaves_at_depth"][0] == 1 and ie["texture_edge"] == 2
+    q = v.default_params(32, 18, empty.GetCellSize(), 255, shadow=False)
+    img, t, st = oe.ref_literal_render(q)
+    assert (t < 0).all() and st["iterations"] == st["rays"] > 0  # the root leaf is crossed in ONE step (Voxel.hlsli:309-314)
+    ob, pb, _, _ = cases("ref_c3vox256_texel16_320x180")
+    ib = ob.octree_info(0)
+    assert ib["texture_edge"] <= 256 and not ib["pointer_overflow"] and ib["nodes"] > 400000
+
+
+def test_literal_budget_exhaustion_paints_the_reference_s_red_pixel():
+    """Raytracing.hlsl:229,325-334: 255 leaves, then an unlit red hit at t = 10.  A ray that grazes a flat surface inside the layer of
+    surface cells of a 256^3 volume crosses 256 one-cell leaves: the reference's pixel is red where the idealisation (and the product,
+    which counts an exhausted march as a miss) see the sky.  One of the reference's artefacts the product declines."""
+    vol = v.VVoxelVolume(8, 100.0)
+    vol.fill(lambda X, Y, Z: Z - 0.3 + 0 * X)
+    sc = v.VScene(Camera=v.VCamera(Position=(-150.0, 0.3, 0.5)), DirectionalLight=v.demo_light(), Objects=[v.VVoxelObject(Volume=vol)],
+                  EnvironmentMap=v.procedural_skybox(4))
+    p = v.default_params(1, 1, vol.GetCellSize(), 255, shadow=False)
+    o = OracleScene(sc)
+    img, t, st = o.ref_literal_render(p)
+    assert st["red_hits"] == 1 and st["iterations"] == 255 and t[0, 0] == 10.0
+    assert abs(img[0, 0, 0] - 0.5 ** (1 / 2.2)) < 1e-6 and img[0, 0, 1] == 0 and img[0, 0, 2] == 0
+    ide, ti = o.ref_render(p)
+    assert ti[0, 0] < 0 and ide[0, 0, 1] > 0.3  # the idealisation: sky
+    # the product's march on the same ray (constant hit threshold: a 1x1 frame's pixel footprint is the whole view): its budget of 255
+    # positions runs out inside the volume too — a COUNTED miss, the sky
+    q = v.default_params(1, 1, vol.GetCellSize(), 255, shadow=False, cone=False)
+    own, stats = o.render(q)
+    assert np.array_equal(own, ide) and stats["exhausted_rays"] == 1
+
+
+def test_literal_camera_inside_the_volume_box(cases):
+    """The origin-inside start (Raytracing.hlsl:185-196; ReverseRay returns its argument, Ray.hlsli:50-58): the surface is still found where
+    the idealisation finds it."""
+    from volumetricraytracer_amd import workloads as scenes
+
+    sc = scenes.config2_sphere(6, 16)
+    sc.Camera = v.look_minus_x_camera(70.0)
+    p = v.default_params(64, 36, scenes.min_cell(sc), 255, shadow=False)
+    o = OracleScene(sc)
+    _, tl, st = o.ref_literal_render(p)
+    _, ti = o.ref_render(p)
+    assert np.array_equal(tl > 0, ti > 0) and (tl > 0).sum() > 1000
+    assert np.abs(tl - ti)[tl > 0].max() < 0.05 and st["rejected_reports"] == 0

@@ -38,6 +38,7 @@ MODE_CUBE_UNLIT = 5
 MODE_CUBE_NOTEX = 6
 MODE_CUBE_NOTEX_UNLIT = 7
 
+FORM_FULL, FORM_PASSES, FORM_TEXTURED, FORM_MAY_BOUNCE, FORM_LEAN_REF = 1, 2, 4, 8, 16  # vrt_debug_last_kernel_form
 FLAG_DIAG_TIMELINE = 4
 FLAG_OUTPUT_RGBA8 = 8
 FLAG_NO_TIMING = 16
@@ -46,6 +47,8 @@ FLAG_NO_CULL_RECT = 128
 FLAG_FULL_ONE_KERNEL = 256   # full closest hit of a block of frames as ONE kernel (default: three passes)
 FLAG_FULL_THREE_PASS = 512   # ... and three passes even for a lone frame
 FLAG_OUTPUT_BGRA8 = 2048       # with FLAG_OUTPUT_RGBA8: B8G8R8A8 byte order, the reference's back buffer (DXConstants.cpp:21)
+FLAG_REFERENCE_VIEW_VECTOR = 4096      # shade the camera ray's hit with the reference's un-normalised wo, back its secondary rays off 0.1 |dir|
+FLAG_REFERENCE_BOUNDARY_TEXELS = 8192  # normal taps beyond the grid read texel 0 (the reference's out-of-bounds Load) instead of the clamped cell
 FLAG_NO_HIT_POLISH = 1024     # closest hits stay at the cone threshold's stop point (rounds 1-3) instead of moving on to the crossing
 HIT_POLISH_SAMPLES = 2
 MAX_BLOCK_FRAMES = 48  # frames one march launch covers with their cameras in the kernarg segment (csrc/vrt_device.h kMaxBlockFrames)
@@ -209,6 +212,7 @@ SYMBOLS = {
     "vrt_timing_history": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "vrt_launch_history": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "vrt_debug_wave_records": (C.c_longlong, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]),
+    "vrt_debug_last_kernel_form": (C.c_int, [C.c_void_p]),
     "vrt_strerror": (C.c_char_p, [C.c_int]),
     "vrt_version": (C.c_char_p, []),
 }

@@ -104,6 +104,7 @@ struct HostVolume {
 struct HostTexture {
     bool used = false;
     int width = 0, height = 0;
+    uint8_t first[4] = {0, 0, 0, 0}; /* texel (0,0): a 1x1 image is a constant (DVolume::tex_const) */
 };
 
 struct DeviceVolume {
@@ -196,6 +197,7 @@ struct DeviceState {
     int last_blocks = 0;         /* workgroups per frame of the last launch */
     int last_frames = 1;         /* frames of the last launch: vrt_last_timing / vrt_debug_wave_records read its LAST frame's records */
     bool last_diag = false;
+    int last_form = 0;           /* vrt_debug_last_kernel_form */
     hipEvent_t joined = nullptr; /* multi-device vrt_render: this device's strips have arrived in device 0's frame */
     hipEvent_t ev0[kRing];
     hipEvent_t ev1[kRing];
@@ -420,6 +422,10 @@ void fill_dvolume(const vrt_ctx* ctx, const DeviceState& D, const HostVolume& h,
             out.tex_px[i] = D.tex[id];
             out.tex_w[i] = ctx->tex[id].width;
             out.tex_h[i] = ctx->tex[id].height;
+            if (ctx->tex[id].width == 1 && ctx->tex[id].height == 1) {
+                out.tex_const_mask |= 1 << i;
+                for (int c = 0; c < 3; c++) out.tex_const[3 * i + c] = (float)ctx->tex[id].first[c] / 255.0f; /* what tex_point_wrap decodes */
+            }
         }
     }
     out.tex_scale[0] = h.tex_scale[0];
@@ -784,13 +790,9 @@ int check_params(const vrt_ctx* ctx, const vrt_params* p, bool own_scenes = fals
     if (p->mode < VRT_MODE_INTERP || p->mode > VRT_MODE_CUBE_NOTEX_UNLIT) return VRT_ERR_INVALID;
     if (p->path < VRT_PATH_AUTO || p->path > VRT_PATH_CELLS) return VRT_ERR_INVALID;
     /* (bit 5 was round 1's VRT_FLAG_SKIP_EMPTY: empty-space skipping is always on now; the bit is accepted and ignored) */
-#ifdef VRT_AB_TSTART
-    const int ab_bits = 3 << 20; /* A/B build: bit 20 record, bit 21 use (tools/beam_upper_bound.py) */
-#else
-    const int ab_bits = 0;
-#endif
-    if ((p->flags & ~ab_bits & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_NO_TIMING | 32 | VRT_FLAG_BLOCK_PER_FRAME | VRT_FLAG_NO_CULL_RECT |
-                      VRT_FLAG_FULL_ONE_KERNEL | VRT_FLAG_FULL_THREE_PASS | VRT_FLAG_NO_HIT_POLISH | VRT_FLAG_OUTPUT_BGRA8)) != 0 || (p->flags & 3) == 3 ||
+    if ((p->flags & ~(3 | VRT_FLAG_DIAG_TIMELINE | VRT_FLAG_OUTPUT_RGBA8 | VRT_FLAG_NO_TIMING | 32 | VRT_FLAG_BLOCK_PER_FRAME | VRT_FLAG_NO_CULL_RECT |
+                      VRT_FLAG_FULL_ONE_KERNEL | VRT_FLAG_FULL_THREE_PASS | VRT_FLAG_NO_HIT_POLISH | VRT_FLAG_OUTPUT_BGRA8 |
+                      VRT_FLAG_REFERENCE_VIEW_VECTOR | VRT_FLAG_REFERENCE_BOUNDARY_TEXELS)) != 0 || (p->flags & 3) == 3 ||
         ((p->flags & VRT_FLAG_OUTPUT_BGRA8) && !(p->flags & VRT_FLAG_OUTPUT_RGBA8)) ||
         ((p->flags & VRT_FLAG_FULL_ONE_KERNEL) && (p->flags & VRT_FLAG_FULL_THREE_PASS)))
         return VRT_ERR_INVALID;
@@ -918,23 +920,31 @@ struct ClosestHitForm {
 ClosestHitForm form_of_scene(const vrt_ctx* ctx, const vrt_params* p, const vrt_scene& sc) {
     /* the lean kernel covers directional light + shadow; the full closest hit is only launched when the
        frame can need it: extra lights, or bounces allowed and some instanced material mirrors (roughness < 0.3) */
-    bool smooth = false;
-    for (int i = 0; i < sc.n_instances; i++) {
-        const HostVolume& hv = ctx->vol[sc.instances[i].volume_slot];
-        smooth = smooth || std::min(std::max(hv.mat.roughness, 0.0f), 1.0f) < 0.3f;
-    }
     /* textured modes read the material textures; a frame needs that code only when a bound texture is in sight */
     const bool tex_mode = p->mode == VRT_MODE_INTERP || p->mode == VRT_MODE_INTERP_UNLIT || p->mode == VRT_MODE_CUBE ||
                           p->mode == VRT_MODE_CUBE_UNLIT;
-    bool textured = false;
-    for (int i = 0; tex_mode && i < sc.n_instances; i++) {
+    bool smooth = false;
+    bool textured = false, images = false; /* a bound texture in sight; one that is more than a single texel */
+    for (int i = 0; i < sc.n_instances; i++) {
         const HostVolume& hv = ctx->vol[sc.instances[i].volume_slot];
-        for (int k = 0; k < 3; k++) textured = textured || (hv.tex[k] >= 0 && ctx->tex[hv.tex[k]].used);
+        float rough = hv.mat.roughness;
+        for (int k = 0; tex_mode && k < 3; k++) {
+            if (hv.tex[k] < 0 || !ctx->tex[hv.tex[k]].used) continue;
+            const HostTexture& t = ctx->tex[hv.tex[k]];
+            textured = true;
+            if (t.width != 1 || t.height != 1) images = true;
+            /* a constant RM texel scales the roughness by its red channel — times a tri-planar blend sum that is 1 to a few ulp: the
+               lower bound decides whether the material can mirror */
+            else if (k == 2) rough = hv.mat.roughness * ((float)t.first[0] / 255.0f) * (hv.mat.roughness >= 0.0f ? 0.99999f : 1.00001f);
+        }
+        smooth = smooth || std::min(std::max(rough, 0.0f), 1.0f) < 0.3f;
     }
+    /* A 1x1 texture is a constant (the reference's default normal texel on every material without a normal map, RDXScene.cpp:241-260):
+       folded into the lean kernel's REF instantiation — no fetch, no full closest hit.  Only real images need the texture code. */
     ClosestHitForm f;
     f.textured = textured;
-    f.full = sc.n_point_lights > 0 || sc.n_spot_lights > 0 || (p->max_bounces > 0 && smooth) || textured;
-    f.may_bounce = p->max_bounces > 0 && (smooth || textured); /* (a roughness texture can make any material mirror) */
+    f.full = sc.n_point_lights > 0 || sc.n_spot_lights > 0 || (p->max_bounces > 0 && smooth) || images;
+    f.may_bounce = p->max_bounces > 0 && (smooth || images); /* (a roughness IMAGE can make any material mirror) */
     return f;
 }
 /* ... of a launch: the scene of vrt_scene_set, or — a block over per-frame scenes (vrt_block::scenes) — the union of what its frames
@@ -985,6 +995,8 @@ void build_frame(const vrt_ctx* ctx, const DeviceState& D, const vrt_params* p, 
     F.diag = (p->flags & VRT_FLAG_DIAG_TIMELINE) ? 1 : 0;
     F.rgba8 = (p->flags & VRT_FLAG_OUTPUT_RGBA8) ? ((p->flags & VRT_FLAG_OUTPUT_BGRA8) ? 2 : 1) : 0;
     F.polish = (p->flags & VRT_FLAG_NO_HIT_POLISH) ? 0 : VRT_HIT_POLISH_SAMPLES;
+    F.view_vec = (p->flags & VRT_FLAG_REFERENCE_VIEW_VECTOR) ? 1 : 0;
+    F.zero_outside = (p->flags & VRT_FLAG_REFERENCE_BOUNDARY_TEXELS) ? 1 : 0;
     F.strip_rows = rs.strip_rows;
     F.strip_first = rs.strip_first;
     F.strip_stride = rs.strip_stride;
@@ -1145,22 +1157,9 @@ int enqueue_rows(vrt_ctx* ctx, DeviceState& D, const vrt_params* p, const RowSet
         F.hit_aux = reinterpret_cast<unsigned*>(base + D.pass_cap[slot] * sizeof(HitRecord) + D.pass_cap[slot] / 64 * sizeof(unsigned long long));
         F.rec_stride = (uint32_t)per_frame;
     }
-#ifdef VRT_AB_TSTART
-    {
-        static float* ab_buf = nullptr;
-        static size_t ab_cap = 0;
-        const size_t need = (size_t)n_frames * (size_t)D.last_blocks * 256;
-        if (ab_cap < need) {
-            if (ab_buf) (void)hipFree(ab_buf);
-            HIP_TRY(hipMalloc(&ab_buf, need * sizeof(float)));
-            HIP_TRY(hipMemset(ab_buf, 0, need * sizeof(float)));
-            ab_cap = need;
-        }
-        F.ab_tstart = ab_buf;
-        F.ab_mode = (p->flags >> 20) & 3;
-    }
-#endif
     D.last_diag = F.diag != 0;
+    D.last_form = (F.full ? VRT_FORM_FULL : 0) | (passes ? VRT_FORM_PASSES : 0) | (F.textured ? VRT_FORM_TEXTURED : 0) |
+                  (F.may_bounce ? VRT_FORM_MAY_BOUNCE : 0) | ((!F.full && (F.textured || F.view_vec || F.zero_outside)) ? VRT_FORM_LEAN_REF : 0);
     if (F.diag) {
         if (stat_blocks > (size_t)kMaxBlocks) return VRT_ERR_INVALID; /* the timeline buffer holds kMaxBlocks workgroups */
         if (!D.d_diag) HIP_TRY(hipMalloc(&D.d_diag, sizeof(unsigned) * kDiagRecord * 4 * (size_t)kMaxBlocks));
@@ -1343,6 +1342,7 @@ int vrt_texture_upload(vrt_ctx* ctx, int id, int width, int height, const uint8_
     ctx->tex[id].used = true;
     ctx->tex[id].width = width;
     ctx->tex[id].height = height;
+    memcpy(ctx->tex[id].first, rgba8, 4);
     return sync_volume_table(ctx);
 }
 
@@ -1955,6 +1955,11 @@ int vrt_launch_history(vrt_ctx* ctx, int n, float* kernel_ms_out, int* frames_ou
     const DeviceState& D = ctx->dev[0];
     for (int i = 0; i < m; i++) frames_out[i] = D.ring_frames[(int)((ctx->launches - (uint64_t)m + (uint64_t)i) % kRing)];
     return m;
+}
+
+int vrt_debug_last_kernel_form(vrt_ctx* ctx) {
+    if (!ctx || ctx->dev.empty()) return VRT_ERR_INVALID;
+    return ctx->dev[0].last_form;
 }
 
 long long vrt_debug_wave_records(vrt_ctx* ctx, int which, uint32_t* out, long long max_words) {

@@ -77,7 +77,12 @@ struct DVolume {
                                  (density <= 0 at a cell-origin voxel); the Cube modes' octree stand-in */
     float abox_lo[3], abox_hi[3]; /* with skip: object-space bounding box of the near bricks, (float)(cell index) * cell - extent
                                      per axis; the sphere-trace is clipped to it.  lo > hi: no near brick, every ray misses */
-    float pad2_[2];
+    /* 1x1 material textures — the reference binds a 1x1 default to every unbound slot (VRDXScene::AllocateDefaultTextures,
+       RDXScene.cpp:241-260) — are constants: bit i of tex_const_mask says slot i's image is one texel, whose channels (byte / 255, the
+       value a fetch would decode) are tex_const[3*i ..]; the tri-planar code then runs on the constant without a fetch (same arithmetic,
+       same result), and a scene whose bound textures are all constants keeps the lean kernel */
+    int32_t tex_const_mask;
+    float tex_const[9];
 };
 
 struct DInstance {
@@ -200,11 +205,9 @@ struct DFrame {
     const DCam* cams;          /* launches of more than kMaxBlockFrames frames: the frames' camera records in device memory (null: DBlock::cam) */
     uint32_t rec_stride;       /* records between the frames of a launch (= workgroups per frame * 256: four waves of 64 lanes) */
     int32_t may_bounce;        /* 1: bounces allowed and some material can mirror (smooth, or roughness from a texture) */
-#ifdef VRT_AB_TSTART           /* A/B build only (tools/beam_upper_bound.py): the upper bound of what ANY beam pre-pass could gain */
-    float* ab_tstart;          /* per lane of the launch: the ray parameter of the camera ray's first SAMPLED position */
-    int32_t ab_mode;           /* 1: record it; 2: start the camera ray's march there (its leading skips cost nothing) */
-    int32_t ab_pad_;
-#endif
+    int32_t view_vec;          /* VRT_FLAG_REFERENCE_VIEW_VECTOR: the camera ray's hit is shaded with wo = -L d and its secondary rays start back * L
+                                  back, L = the camera direction's length before normalisation (the reference's WorldRayDirection()) */
+    int32_t zero_outside;      /* VRT_FLAG_REFERENCE_BOUNDARY_TEXELS: normal taps beyond the grid read 0 (the reference's out-of-bounds Load) */
     const void* dyn;           /* per-frame scene state (vrt_block::scenes): n_frames sections of kDynStride bytes in device memory, each a
                                   DDyn record followed by the frame's instances, BVH nodes, point and spot lights; null: every frame of the
                                   launch renders the scene in this struct.  Read by the DYN instantiations of the march kernels only */

@@ -521,10 +521,13 @@ __device__ __forceinline__ float polish_hit(const DFrame& F, const VolRef& V, co
 }
 
 /* World-space normal at a hit found in cell c after `iter` march iterations.  Taps always come from
- * global memory here (once per hit, 24 independent loads in flight). */
-template <int PATH, bool EXACT = false>
+ * global memory here (once per hit).  ZO: the kernel honours VRT_FLAG_REFERENCE_BOUNDARY_TEXELS (zero_outside at run time): a neighbour
+ * cell beyond the grid is then the reference's — its samples outside the volume texture read 0 (GetDensity, Voxel.hlsli:607-617), so its
+ * interpolant is the boundary plane's times the in-texture side's weight: cell N-1 = (1 - f) x cell N-2 at fraction 1, cell -1 = f x cell 0
+ * at fraction 0 (oracle: the same products).  Default: the neighbour cell clamped to the grid. */
+template <int PATH, bool EXACT = false, bool ZO = false>
 __device__ __forceinline__ F3 hit_normal(const DInstance* __restrict__ I, const VolRef& V, const RaySeg& R, const Cell& c,
-                                         int iter) {
+                                         int iter, bool zero_outside = false) {
     F3 n;
     if (iter == 0 && R.t_enter >= 0.0f && !R.clipped) {
         /* surface cut by the volume boundary: AABB-face normal (Raytracing.hlsl:198-226) */
@@ -542,11 +545,10 @@ __device__ __forceinline__ F3 hit_normal(const DInstance* __restrict__ I, const 
         int xp = c.cx + 1 > N2 ? N2 : c.cx + 1, xm = c.cx - 1 < 0 ? 0 : c.cx - 1;
         int yp = c.cy + 1 > N2 ? N2 : c.cy + 1, ym = c.cy - 1 < 0 ? 0 : c.cy - 1;
         int zp = c.cz + 1 > N2 ? N2 : c.cz + 1, zm = c.cz - 1 < 0 ? 0 : c.cz - 1;
-#ifdef VRT_AB_NORMAL_ALL_AT_ONCE
-        n.x = trilinear<PATH>(V, xp, c.cy, c.cz, c.fx, c.fy, c.fz) - trilinear<PATH>(V, xm, c.cy, c.cz, c.fx, c.fy, c.fz);
-        n.y = trilinear<PATH>(V, c.cx, yp, c.cz, c.fx, c.fy, c.fz) - trilinear<PATH>(V, c.cx, ym, c.cz, c.fx, c.fy, c.fz);
-        n.z = trilinear<PATH>(V, c.cx, c.cy, zp, c.fx, c.fy, c.fz) - trilinear<PATH>(V, c.cx, c.cy, zm, c.fx, c.fy, c.fz);
-#else
+        const bool zo = ZO && zero_outside;
+        const bool hx = zo && c.cx + 1 > N2, hy = zo && c.cy + 1 > N2, hz = zo && c.cz + 1 > N2; /* the +1 neighbour lies beyond the grid */
+        const bool lx = zo && c.cx - 1 < 0, ly = zo && c.cy - 1 < 0, lz = zo && c.cz - 1 < 0;    /* the -1 neighbour */
+        const float spx = 1.0f - c.fx, spy = 1.0f - c.fy, spz = 1.0f - c.fz;
         /* one axis at a time (a real loop): the six interpolations' 24 tap loads all in flight at once were the register peak of the
            whole kernel (48 registers of taps); a hit happens once per ray, its latency is not what the kernel waits for */
         n = f3(0.0f, 0.0f, 0.0f);
@@ -555,12 +557,23 @@ __device__ __forceinline__ F3 hit_normal(const DInstance* __restrict__ I, const 
             const int px_ = a == 0 ? xp : c.cx, mx_ = a == 0 ? xm : c.cx;
             const int py_ = a == 1 ? yp : c.cy, my_ = a == 1 ? ym : c.cy;
             const int pz_ = a == 2 ? zp : c.cz, mz_ = a == 2 ? zm : c.cz;
-            const float v = trilinear<PATH>(V, px_, py_, pz_, c.fx, c.fy, c.fz) - trilinear<PATH>(V, mx_, my_, mz_, c.fx, c.fy, c.fz);
+            float v;
+            if constexpr (ZO) {
+                const bool hi_out = a == 0 ? hx : a == 1 ? hy : hz, lo_out = a == 0 ? lx : a == 1 ? ly : lz;
+                float vp = trilinear<PATH>(V, px_, py_, pz_, (a == 0 && hi_out) ? 1.0f : c.fx, (a == 1 && hi_out) ? 1.0f : c.fy, (a == 2 && hi_out) ? 1.0f : c.fz);
+                float vm = trilinear<PATH>(V, mx_, my_, mz_, (a == 0 && lo_out) ? 0.0f : c.fx, (a == 1 && lo_out) ? 0.0f : c.fy, (a == 2 && lo_out) ? 0.0f : c.fz);
+                /* (products and differences of this iteration, selected by axis: a select chain over the cell's own fields would be
+                   turned into an indexed load from a stack copy of the cell) */
+                const float vps = a == 0 ? spx * vp : a == 1 ? spy * vp : spz * vp;
+                const float vms = a == 0 ? c.fx * vm : a == 1 ? c.fy * vm : c.fz * vm;
+                v = (hi_out ? vps : vp) - (lo_out ? vms : vm);
+            } else {
+                v = trilinear<PATH>(V, px_, py_, pz_, c.fx, c.fy, c.fz) - trilinear<PATH>(V, mx_, my_, mz_, c.fx, c.fy, c.fz);
+            }
             n.x = a == 0 ? v : n.x;
             n.y = a == 1 ? v : n.y;
             n.z = a == 2 ? v : n.z;
         }
-#endif
     }
     float l2 = dot3(n, n);
     if (!(l2 > 0.0f)) {
@@ -683,9 +696,6 @@ struct MarchState {
     float chk;             /* over-relaxation (k_relax > 1): s_prev when the step that led to the current position was a stretched
                               one (the next sample checks the overlap of the two empty spheres), else +inf */
     Cell c;
-#ifdef VRT_AB_TSTART
-    float ab_first;        /* A/B build: t of the first sampled position, -1 = none yet */
-#endif
 };
 
 /*
@@ -708,9 +718,6 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
     Cell c = st.c;
     const bool tables = V.skip != nullptr;
     unsigned last_brick = 0xffffffffu, nibw = 0u;
-#ifdef VRT_AB_TSTART
-    float ab_first = st.ab_first;
-#endif
     while (i < limit && !(t > t_end)) {
         unsigned long long st0 = 0, st1 = 0;
         if constexpr (DIAG) st0 = stamp();
@@ -751,9 +758,6 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
             }
             const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
             steps++;
-#ifdef VRT_AB_TSTART
-            ab_first = ab_first < 0.0f ? t : ab_first;
-#endif
             /* Over-relaxation (k_relax > 1): when the step that led here was a stretched one (chk = the previous sample's
                empty radius, else +inf), the empty spheres around the two samples must overlap; if they do not, something
                may have been jumped over and the ray goes BACK to the previous sample's plain step (that sample stays the
@@ -783,9 +787,6 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
         }
         if constexpr (DIAG) dg->loop += stamp() - st0;
     }
-#ifdef VRT_AB_TSTART
-    st.ab_first = ab_first;
-#endif
     st.hit = t_end < R.t_end;
     st.t = t;
     st.t_prev = t_prev;
@@ -800,7 +801,8 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
  * true on hit and the ray parameter (shared by world and object space — the object-space direction
  * is not re-normalised, DXR semantics).  NORMAL: also produce the world-space normal.
  */
-template <int PATH, int NORMAL /* 0 none, 1 fast length, 2 exact length */, bool DIAG = false, bool DIR_SHADOW = false>
+template <int PATH, int NORMAL /* 0 none, 1 fast length, 2 exact length */, bool DIAG = false, bool DIR_SHADOW = false,
+          bool REF = false /* the kernel honours the reference-artefact flags (DFrame::zero_outside); false: compiled out */>
 __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance* __restrict__ I,
                                                const DVolume* __restrict__ Vd, F3 o, F3 d, float t_cur, float t_base,
                                                float& t_hit, F3& n_world, unsigned& steps, unsigned& ex, DiagAcc* dg = nullptr) {
@@ -822,15 +824,7 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     st.hit = false;
     st.chk = __builtin_inff();
     st.c = Cell{0, 0, 0, 0.0f, 0.0f, 0.0f};
-#ifdef VRT_AB_TSTART
-    st.ab_first = -1.0f;
-    const size_t ab_idx = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-    if (NORMAL != 0 && F.ab_mode == 2) st.t = st.t_prev = vmax(R.t0, F.ab_tstart[ab_idx]);
-#endif
     march_lane<DP, DIAG>(F, V, R, st, F.max_steps, steps, dg);
-#ifdef VRT_AB_TSTART
-    if (NORMAL != 0 && F.ab_mode == 1) F.ab_tstart[ab_idx] = st.ab_first >= 0.0f ? st.ab_first : st.t;
-#endif
     if (!st.hit) {
         if (F.max_steps > 0 && st.i >= F.max_steps && !(st.t > R.t_end)) ex += kExhaustedOne; /* budget ran out inside the volume: reported, treated as a miss */
         return false;
@@ -840,20 +834,20 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     if (st.s_hit < 0.0f && st.i > 0) t = refine_hit<DP>(V, R, st.t_prev, st.s_prev, t, st.s_hit, c, steps);
     else if (NORMAL != 0 && F.polish > 0 && st.i > 0) t = polish_hit<DP>(F, V, R, t, st.s_hit, st.t_prev, st.s_prev, F.polish, c, steps);
     t_hit = t;
-    if constexpr (NORMAL == 1) n_world = hit_normal<DP, false>(I, V, R, c, st.i);
-    if constexpr (NORMAL == 2) n_world = hit_normal<DP, true>(I, V, R, c, st.i);
+    if constexpr (NORMAL == 1) n_world = hit_normal<DP, false, REF>(I, V, R, c, st.i, REF && F.zero_outside != 0);
+    if constexpr (NORMAL == 2) n_world = hit_normal<DP, true, REF>(I, V, R, c, st.i, REF && F.zero_outside != 0);
     return true;
     }
 }
 
 /* Closest hit over the scene.  SINGLE: exactly one instance, no BVH, all scene data wave-uniform. */
-template <int PATH, bool SINGLE, bool DIAG = false, int NORMAL = 1>
+template <int PATH, bool SINGLE, bool DIAG = false, int NORMAL = 1, bool REF = false>
 __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float t_max, float t_base, float& t_best,
                                               int& inst_best, F3& n_best, unsigned& steps, unsigned& ex, DiagAcc* dg = nullptr) {
     if constexpr (SINGLE) {
         float t;
         F3 n;
-        if (march_instance<PATH, NORMAL, DIAG>(F, F.inst, F.vol0, o, d, t_max, t_base, t, n, steps, ex, dg)) {
+        if (march_instance<PATH, NORMAL, DIAG, false, REF>(F, F.inst, F.vol0, o, d, t_max, t_base, t, n, steps, ex, dg)) {
             t_best = t;
             inst_best = 0;
             n_best = n;
@@ -887,7 +881,7 @@ __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float
                        fall depends on the interval's end: cut at `best` the result would depend on the visiting order); the
                        cell walk of the Cube modes has no such state and stops at the closest hit so far */
                     constexpr bool kCube = PATH == kPathCube || PATH == kPathCube16;
-                    if (march_instance<PATH, NORMAL, DIAG>(F, I, F.vols + I->slot, o, d, kCube ? best : t_max, t_base, t, n, steps, ex, dg)) {
+                    if (march_instance<PATH, NORMAL, DIAG, false, REF>(F, I, F.vols + I->slot, o, d, kCube ? best : t_max, t_base, t, n, steps, ex, dg)) {
                         if (!any || t < best || (t == best && ii < inst_best)) {
                             any = true;
                             best = t;
@@ -1039,19 +1033,10 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
  * a launch independently, each through its own eighth of the workgroups, and the launch ends with the slowest: with a fixed map one
  * XCD carries 10 % (config 3) to 18 % (config 5) more marching than the mean, frame after frame (an orbiting camera moves the object
  * slowly); rotated, every XCD has rendered every class after 8 frames.  Config 3: 61.0 -> 64.4 Grays/s (per frame; 63.8 with 8 phases
- * per block, which keeps more of an XCD's L2 warm — balance matters more).  -DVRT_AB_XCD_ROT=0: the fixed map. */
-#ifndef VRT_AB_XCD_ROT
-#define VRT_AB_XCD_ROT 1
-#endif
+ * per block, which keeps more of an XCD's L2 warm — balance matters more). */
 __device__ __forceinline__ void tile_of_block(const DFrame& F, int b, int nblk, int& tile_x, int& tile_y) {
     if (F.tile_map == kMapSupertile) {
-#if VRT_AB_XCD_ROT == 0
-        const int rot = 0;
-#elif VRT_AB_XCD_ROT == 1
         const int rot = (int)blockIdx.y;
-#else
-        const int rot = ((int)blockIdx.y * 8) / F.n_frames;
-#endif
         const int xcd = (b + rot) & 7, q = b >> 3;
         const int st = (q >> 4) * 8 + xcd;      /* supertile index, row-major over st_x columns */
         const int within = q & 15;
@@ -1072,9 +1057,8 @@ __device__ __forceinline__ void tile_of_block(const DFrame& F, int b, int nblk, 
 
 /* Workgroup shape of the per-lane march kernels: one wave = one 8x8-pixel tile per workgroup; four consecutive workgroups OF
  * THE SAME XCD (blockIdx % 8) cover a 16x16 tile, so the tile -> XCD map is the one described above while the dispatcher
- * refills single wave slots (waves of a tile retire at very different times).  VRT_AB_QUAD_BLOCKS (A/B build): round 1's four
- * waves per workgroup; measured 3.5 % (two frames in flight) to 5 % (one) slower, profiles/r02_ab_march_variants.txt. */
-#ifndef VRT_AB_QUAD_BLOCKS
+ * refills single wave slots (waves of a tile retire at very different times).  (Round 1's four waves per workgroup measured
+ * 3.5 % (two frames in flight) to 5 % (one) slower, profiles/r02_ab_march_variants.txt.) */
 constexpr int kMarchThreads = 64;
 constexpr int kMarchGridMul = 4;
 __device__ __forceinline__ void block_and_wave(int& b, int& wave) {
@@ -1082,14 +1066,6 @@ __device__ __forceinline__ void block_and_wave(int& b, int& wave) {
     wave = q & 3;
     b = ((q >> 2) << 3) | xcd;
 }
-#else
-constexpr int kMarchThreads = kBlockThreads;
-constexpr int kMarchGridMul = 1;
-__device__ __forceinline__ void block_and_wave(int& b, int& wave) {
-    b = (int)blockIdx.x;
-    wave = (int)threadIdx.x >> 6;
-}
-#endif
 
 /* False for a whole wave when none of its pixels lies inside the frame's cull rectangle (DFrame::cull_*): its primary rays
  * cannot reach any instance, so the scene is never looked at — no instance / volume record loaded, no slab test.  Four out
@@ -1158,6 +1134,17 @@ __device__ __forceinline__ void camera_ray(const DFrame& F, const DCam& C, int p
     d = normalize3(f3((tx * C.r0[0] + ty * C.r1[0]) - C.r2[0], (tx * C.r0[1] + ty * C.r1[1]) - C.r2[1],
                       (tx * C.r0[2] + ty * C.r1[2]) - C.r2[2]));
     o = f3(C.cam_o[0], C.cam_o[1], C.cam_o[2]);
+}
+
+/* Length of the camera direction of pixel (px,py) BEFORE its normalisation: what the reference's WorldRayDirection() is long
+   (VRT_FLAG_REFERENCE_VIEW_VECTOR; oracle: camera_ray's len).  Recomputed behind the march rather than kept in a register across it. */
+__device__ __forceinline__ float camera_len(const DFrame& F, const DCam& C, int px, int py) {
+    float sx = (((float)px + 0.5f) * F.inv_w) * 2.0f - 1.0f;
+    float sy = (((float)py + 0.5f) * F.inv_h) * 2.0f - 1.0f;
+    float tx = sx * C.cx;
+    float ty = (-sy) * C.cy;
+    const F3 a = f3((tx * C.r0[0] + ty * C.r1[0]) - C.r2[0], (tx * C.r0[1] + ty * C.r1[1]) - C.r2[1], (tx * C.r0[2] + ty * C.r1[2]) - C.r2[2]);
+    return sqrtf(dot3(a, a));
 }
 
 struct Counters {
@@ -1255,12 +1242,31 @@ __device__ __forceinline__ F3 shade_hit(const DFrame& F, const DVolume* __restri
     }
     return color;
 }
+/* ... with the surface given (constant material textures folded in) and the reference's view vector wo = -vs d. */
+__device__ __forceinline__ F3 shade_hit_surface(const DFrame& F, const DVolume* __restrict__ V, F3 d, float vs, F3 n, F3 albedo, float rough, float metal,
+                                                bool shadowed) {
+    if (F.unlit) return albedo;
+    F3 color = f3(0.0f, 0.0f, 0.0f);
+    if (!shadowed) {
+        F3 wo = f3(-d.x * vs, -d.y * vs, -d.z * vs);
+        F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
+        F3 Li = f3(F.light_strength, F.light_strength, F.light_strength);
+        color = color + radiance(Li, ld, wo, n, albedo, rough, metal, V->k);
+    }
+    return color;
+}
 
 /* Shadow-ray origin: the hit point pulled 0.1 back along the ray (Raytracing.hlsl:51-52); 0.2 in the Cube
    modes (Raytracing_Cube.hlsl:52). */
 __device__ __forceinline__ F3 shadow_origin(const DFrame& F, F3 o, F3 d, float t_hit) {
     F3 hp = f3(__builtin_fmaf(d.x, t_hit, o.x), __builtin_fmaf(d.y, t_hit, o.y), __builtin_fmaf(d.z, t_hit, o.z));
     return f3(hp.x - d.x * F.back, hp.y - d.y * F.back, hp.z - d.z * F.back);
+}
+/* ... vs x as far back: the reference's offset is in units of its un-normalised ray direction (VRT_FLAG_REFERENCE_VIEW_VECTOR) */
+__device__ __forceinline__ F3 shadow_origin(const DFrame& F, F3 o, F3 d, float t_hit, float vs) {
+    F3 hp = f3(__builtin_fmaf(d.x, t_hit, o.x), __builtin_fmaf(d.y, t_hit, o.y), __builtin_fmaf(d.z, t_hit, o.z));
+    const float back = F.back * vs;
+    return f3(hp.x - d.x * back, hp.y - d.y * back, hp.z - d.z * back);
 }
 
 /* UNORM8 of a tone-mapped channel in [0,1]: round to nearest, the D3D float→UNORM rule (the reference's
@@ -1285,12 +1291,6 @@ __device__ __forceinline__ void store_pixel(const DFrame& F, int frame, unsigned
     }
 }
 
-/* The lane's index in its wave from the execution-mask counters (v_mbcnt), for code behind the march that would otherwise keep
- * threadIdx.x alive across it. */
-__device__ __forceinline__ unsigned late_lane_id() {
-    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-}
-
 /* Frame row of local row pyl of this launch's tile (contiguous rows, or interleaved strips). */
 __device__ __forceinline__ int frame_row(const DFrame& F, int pyl) {
     if (F.strip_rows > 0) {
@@ -1298,84 +1298,6 @@ __device__ __forceinline__ int frame_row(const DFrame& F, int pyl) {
         return (s * F.strip_stride + F.strip_first) * F.strip_rows + (pyl - s * F.strip_rows);
     }
     return F.row0 + pyl;
-}
-
-/* (Round 3 experiment, removed: ONE wave rendering a whole 16x16 sky tile — four pixels per lane — while the tile's other three
- * waves end at once.  Letting three out of four sky waves end at once changes nothing (41.1 against 41.0 us per frame: the sky
- * waves only fill wave slots the marching waves leave empty), and the four-pixel sky wave made the frame 20 % slower:
- * profiles/r03_sky_tile_and_occupancy_experiments.txt.) */
-template <int PATH, bool SINGLE, bool DIAG, bool DYN = false>
-/* The multi-instance (BVH) instantiations on brick / cell-record paths are asked to fit 7 waves per SIMD (72 VGPRs instead of the 78 the
- * register allocator settles for; 3 registers and 10 scalars spilled outside the march loop): config 5 68.6 -> 70.9 Grays/s.  The
- * single-instance ones sit at the hardware's 8 waves per SIMD anyway. */
-#ifndef VRT_BVH_WAVES
-#define VRT_BVH_WAVES 7
-#endif
-__global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu((!SINGLE && !DIAG && PATH != VRT_PATH_DENSE) ? VRT_BVH_WAVES : 1))) void march_kernel(const DBlock B) {
-    unsigned long long t_start = 0;
-    if constexpr (DIAG) t_start = __builtin_amdgcn_s_memrealtime(); /* 100 MHz; diagnostic build only */
-    const int frame = (int)blockIdx.y;
-    DFrame Fd;
-    const DFrame& F = frame_view<DYN>(B, frame, Fd);
-    const DCam C = load_cam(B, frame);
-    int b, wave;
-    block_and_wave(b, wave);
-    int tile_x, tile_y;
-    tile_of_block(F, b, (int)gridDim.x / kMarchGridMul, tile_x, tile_y);
-    const int lane = (int)threadIdx.x & 63;
-    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const int py = frame_row(F, pyl);
-    const bool valid = tile_x < F.tiles_x && tile_y < F.tiles_y && px < F.width && pyl < F.rows && py < F.height;
-
-    Counters k;
-    DiagAcc dg;
-    const bool reach = wave_can_reach(C, valid, px, py);
-
-    if (valid) {
-        F3 o, d;
-        camera_ray(F, C, px, py, o, d);
-        k.n_primary = 1;
-        float t_hit = 0.0f;
-        int inst = 0;
-        F3 n = f3(0.0f, 0.0f, 0.0f);
-        F3 color;
-        /* the sky texel is asked for before the march (one register across it): four out of five waves of a frame see only
-           sky, and for them it is the last link of a chain of dependent loads (kernarg -> instance / volume -> texel -> store) */
-        const unsigned sky = env_fetch(F.env, F.env_size, d);
-        /* the normal's length is the correctly rounded one: its dot product with the light decides whether a shadow ray is cast */
-        if (reach && trace_closest<PATH, SINGLE, DIAG, 2>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, k.s_primary, k.n_hits, &dg)) {
-            k.n_hits += 1; /* (its upper bits count exhausted marches) */
-            bool shadowed = false;
-            const F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
-            /* A surface facing away from the light gets a contribution <= 0 from it, blocked or not, and this kernel has no
-               other term: the tone-map clamps the pixel to 0 either way, so that shadow ray is not cast (oracle: same rule) */
-            if (F.shadow && !F.unlit && dot3(n, ld) > 0.0f) {
-                k.n_shadow = 1;
-                shadowed = trace_any<PATH, SINGLE, DIAG, true>(F, shadow_origin(F, o, d, t_hit), ld, 5000.0f, t_hit, k.s_shadow, k.n_hits, &dg);
-            }
-            color = shade_hit(F, SINGLE ? F.vol0 : F.vols + F.inst[inst].slot, d, n, shadowed);
-        } else {
-            color = env_decode(sky);
-        }
-        /* VRT_AB_LATE_PIX (A/B build): the pixel's offset derived again from the lane id (mbcnt) and the wave-uniform tile origin, so
-           that no register holds the pixel coordinates or threadIdx across the march: 60 instead of 64 VGPRs — and 5 % SLOWER: with
-           the tighter allocation the table-word loads of the march loop reuse their own address register and wait for vmcnt(0)
-           (profiles/r03_ab_fused_variants.txt) */
-#ifdef VRT_AB_LATE_PIX
-        const unsigned lane_late = late_lane_id();
-#else
-        const unsigned lane_late = (unsigned)lane;
-#endif
-        const unsigned pix = ((unsigned)(tile_y * 16 + (wave >> 1) * 8) + (lane_late >> 3)) * (unsigned)F.width +
-                             ((unsigned)(tile_x * 16 + (wave & 1) * 8) + (lane_late & 7u));
-        store_pixel(F, frame, pix, color);
-    }
-#ifdef VRT_AB_LATE_PIX
-    write_records<DIAG, true>(F, frame, b, wave, (int)late_lane_id(), k, dg, t_start);
-#else
-    write_records<DIAG, true>(F, frame, b, wave, lane, k, dg, t_start);
-#endif
 }
 
 /* ---- tri-planar material textures (SH/Include/Textures.hlsli:16-59, Quaternion.hlsli:18-82) ----------
@@ -1392,13 +1314,21 @@ __device__ __forceinline__ F3 tex_point_wrap(const uint8_t* __restrict__ px, int
     return f3((float)(t & 0xffu) / 255.0f, (float)((t >> 8) & 0xffu) / 255.0f, (float)((t >> 16) & 0xffu) / 255.0f);
 }
 
+/* CONST_ONLY: every bound texture of the launch is a 1x1 image (DVolume::tex_const_mask), e.g. the reference's default normal texel:
+   no fetch is compiled in.  A constant slot's three planar samples are the one texel; the arithmetic behind them is the fetch path's. */
+template <bool CONST_ONLY>
 __device__ __forceinline__ F3 tri_sample(const DVolume* __restrict__ V, int which, F3 op, F3 blend, bool as_normal) {
-    const uint8_t* px = V->tex_px[which];
-    const int W = V->tex_w[which], H = V->tex_h[which];
-    const float su = V->tex_scale[0], sv = V->tex_scale[1];
-    F3 tx = tex_point_wrap(px, W, H, op.z / su, op.y / sv);
-    F3 ty = tex_point_wrap(px, W, H, op.x / su, op.z / sv);
-    F3 tz = tex_point_wrap(px, W, H, op.x / su, op.y / sv);
+    F3 tx, ty, tz;
+    if (CONST_ONLY || ((V->tex_const_mask >> which) & 1) != 0) {
+        tx = ty = tz = f3(V->tex_const[3 * which], V->tex_const[3 * which + 1], V->tex_const[3 * which + 2]);
+    } else {
+        const uint8_t* px = V->tex_px[which];
+        const int W = V->tex_w[which], H = V->tex_h[which];
+        const float su = V->tex_scale[0], sv = V->tex_scale[1];
+        tx = tex_point_wrap(px, W, H, op.z / su, op.y / sv);
+        ty = tex_point_wrap(px, W, H, op.x / su, op.z / sv);
+        tz = tex_point_wrap(px, W, H, op.x / su, op.y / sv);
+    }
     if (as_normal) {
         tx = f3(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f);
         ty = f3(ty.x * 2.0f - 1.0f, ty.y * 2.0f - 1.0f, ty.z * 2.0f - 1.0f);
@@ -1441,6 +1371,7 @@ __device__ __forceinline__ F3 rotate_vector(F3 v, Q4 r) {
 }
 
 /* Material at a hit in the textured modes (unbound slots are exact identities). */
+template <bool CONST_ONLY = false>
 __device__ __forceinline__ void textured_surface(const DVolume* __restrict__ V, const DInstance* __restrict__ I, F3 hit_world,
                                                  F3& albedo, F3& n, float& rough, float& metal) {
     const F3 op = mul33(I->w2o, f3(hit_world.x - I->pos[0], hit_world.y - I->pos[1], hit_world.z - I->pos[2]));
@@ -1449,19 +1380,105 @@ __device__ __forceinline__ void textured_surface(const DVolume* __restrict__ V, 
     const float sum = (an.x + an.y) + an.z;
     const F3 blend = f3(an.x / sum, an.y / sum, an.z / sum);
     if (V->tex_px[0] != nullptr) {
-        const F3 t = tri_sample(V, 0, op, blend, false);
+        const F3 t = tri_sample<CONST_ONLY>(V, 0, op, blend, false);
         albedo = f3(albedo.x * t.x, albedo.y * t.y, albedo.z * t.z);
     }
     if (V->tex_px[2] != nullptr) {
-        const F3 t = tri_sample(V, 2, op, blend, false);
+        const F3 t = tri_sample<CONST_ONLY>(V, 2, op, blend, false);
         rough = minf_(maxf_(V->roughness_raw * t.x, 0.0f), 1.0f);
         metal = minf_(maxf_(V->metallic_raw * t.y, 0.0f), 1.0f);
     }
     if (V->tex_px[1] != nullptr) {
-        F3 t = tri_sample(V, 1, op, blend, true);
+        F3 t = tri_sample<CONST_ONLY>(V, 1, op, blend, true);
         t = normalize3(t);
         n = mul33(I->o2w, rotate_vector(f3(t.z, t.x, t.y), quat_from_x(no)));
     }
+}
+
+/* (Round 3 experiment, removed: ONE wave rendering a whole 16x16 sky tile — four pixels per lane — while the tile's other three
+ * waves end at once.  Letting three out of four sky waves end at once changes nothing (41.1 against 41.0 us per frame: the sky
+ * waves only fill wave slots the marching waves leave empty), and the four-pixel sky wave made the frame 20 % slower:
+ * profiles/r03_sky_tile_and_occupancy_experiments.txt.) */
+template <int PATH, bool SINGLE, bool DIAG, bool DYN = false,
+          bool REF = false /* "what the DXR backend renders": constant (1x1) material textures in the textured modes, the reference's view
+                              vector and boundary texels (DFrame::textured / view_vec / zero_outside).  A separate instantiation, so that the
+                              plain kernel's code and registers stay what they are; launched when a frame needs any of the three */>
+/* The multi-instance (BVH) instantiations on brick / cell-record paths are asked to fit 7 waves per SIMD (72 VGPRs instead of the 78 the
+ * register allocator settles for; 3 registers and 10 scalars spilled outside the march loop): config 5 68.6 -> 70.9 Grays/s.  The
+ * single-instance ones sit at the hardware's 8 waves per SIMD anyway. */
+#ifndef VRT_BVH_WAVES
+#define VRT_BVH_WAVES 7
+#endif
+__global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu((!SINGLE && !DIAG && PATH != VRT_PATH_DENSE) ? VRT_BVH_WAVES : (REF && SINGLE) ? 8 : 1))) void march_kernel(const DBlock B) {
+    unsigned long long t_start = 0;
+    if constexpr (DIAG) t_start = __builtin_amdgcn_s_memrealtime(); /* 100 MHz; diagnostic build only */
+    const int frame = (int)blockIdx.y;
+    DFrame Fd;
+    const DFrame& F = frame_view<DYN>(B, frame, Fd);
+    const DCam C = load_cam(B, frame);
+    int b, wave;
+    block_and_wave(b, wave);
+    int tile_x, tile_y;
+    tile_of_block(F, b, (int)gridDim.x / kMarchGridMul, tile_x, tile_y);
+    const int lane = (int)threadIdx.x & 63;
+    const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int pyl = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int py = frame_row(F, pyl);
+    const bool valid = tile_x < F.tiles_x && tile_y < F.tiles_y && px < F.width && pyl < F.rows && py < F.height;
+
+    Counters k;
+    DiagAcc dg;
+    const bool reach = wave_can_reach(C, valid, px, py);
+
+    if (valid) {
+        F3 o, d;
+        camera_ray(F, C, px, py, o, d);
+        k.n_primary = 1;
+        float t_hit = 0.0f;
+        int inst = 0;
+        F3 n = f3(0.0f, 0.0f, 0.0f);
+        F3 color;
+        /* the sky texel is asked for before the march (one register across it): four out of five waves of a frame see only
+           sky, and for them it is the last link of a chain of dependent loads (kernarg -> instance / volume -> texel -> store) */
+        const unsigned sky = env_fetch(F.env, F.env_size, d);
+        /* the normal's length is the correctly rounded one: its dot product with the light decides whether a shadow ray is cast */
+        if (reach && trace_closest<PATH, SINGLE, DIAG, 2, REF>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, k.s_primary, k.n_hits, &dg)) {
+            k.n_hits += 1; /* (its upper bits count exhausted marches) */
+            bool shadowed = false;
+            const F3 ld = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
+            if constexpr (REF) {
+                const DVolume* V = SINGLE ? F.vol0 : F.vols + F.inst[inst].slot;
+                /* the hit's surface first (a constant normal texel tilts the normal the shadow decision looks at), then as below */
+                F3 albedo = f3(V->tint[0], V->tint[1], V->tint[2]);
+                float rough = V->roughness, metal = V->metallic;
+                if (F.textured) {
+                    const F3 hp = f3(__builtin_fmaf(d.x, t_hit, o.x), __builtin_fmaf(d.y, t_hit, o.y), __builtin_fmaf(d.z, t_hit, o.z));
+                    textured_surface<true>(V, SINGLE ? F.inst : F.inst + inst, hp, albedo, n, rough, metal);
+                }
+                if (F.shadow && !F.unlit && dot3(n, ld) > 0.0f) {
+                    k.n_shadow = 1;
+                    const float vs = F.view_vec ? camera_len(F, C, px, py) : 1.0f;
+                    shadowed = trace_any<PATH, SINGLE, DIAG, true>(F, shadow_origin(F, o, d, t_hit, vs), ld, 5000.0f, t_hit, k.s_shadow, k.n_hits, &dg);
+                }
+                const float vs = F.view_vec ? camera_len(F, C, px, py) : 1.0f;
+                color = shade_hit_surface(F, V, d, vs, n, albedo, rough, metal, shadowed);
+            } else {
+            /* A surface facing away from the light gets a contribution <= 0 from it, blocked or not, and this kernel has no
+               other term: the tone-map clamps the pixel to 0 either way, so that shadow ray is not cast (oracle: same rule) */
+            if (F.shadow && !F.unlit && dot3(n, ld) > 0.0f) {
+                k.n_shadow = 1;
+                shadowed = trace_any<PATH, SINGLE, DIAG, true>(F, shadow_origin(F, o, d, t_hit), ld, 5000.0f, t_hit, k.s_shadow, k.n_hits, &dg);
+            }
+            color = shade_hit(F, SINGLE ? F.vol0 : F.vols + F.inst[inst].slot, d, n, shadowed);
+            }
+        } else {
+            color = env_decode(sky);
+        }
+        /* (The pixel's offset derived again from the lane id (mbcnt) behind the march, so that no register holds pixel coordinates
+           across it, gave 60 instead of 64 VGPRs and measured 5 % SLOWER: profiles/r03_ab_fused_variants.txt.) */
+        store_pixel(F, frame, (unsigned)pyl * (unsigned)F.width + (unsigned)px, color);
+    }
+    write_records<DIAG, true>(F, frame, b, wave, lane, k, dg, t_start);
 }
 
 /*
@@ -1581,7 +1598,7 @@ __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(V
                 inst = (int)(aux & 0xffffu);
                 shadow_bits = aux;
             } else {
-                if ((level == 1 && !reach) || !trace_closest<PATH, SINGLE, false, 2>(F, o, d, 10000.0f, t_base, t_hit, inst, n, k.s_primary, k.n_hits)) {
+                if ((level == 1 && !reach) || !trace_closest<PATH, SINGLE, false, 2, true>(F, o, d, 10000.0f, t_base, t_hit, inst, n, k.s_primary, k.n_hits)) {
                     color = env_lookup(F.env, F.env_size, d);
                     break;
                 }
@@ -1600,8 +1617,10 @@ __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(V
                 break;
             }
             const float kk = V->k;
-            const F3 so = shadow_origin(F, o, d, t_hit);
-            const F3 wo = f3(-d.x, -d.y, -d.z);
+            /* the camera ray is the one ray whose direction the reference leaves un-normalised (VRT_FLAG_REFERENCE_VIEW_VECTOR) */
+            const float vs = (level == 1 && F.view_vec) ? camera_len(F, C, px, py) : 1.0f;
+            const F3 so = shadow_origin(F, o, d, t_hit, vs);
+            const F3 wo = f3(-d.x * vs, -d.y * vs, -d.z * vs);
             const float tb = t_base + t_hit;
             const bool shadows = F.shadow && level < kMaxDepth;
             const bool bounce = rough < 0.3f && level <= F.max_bounces && level < kMaxDepth;
@@ -1740,7 +1759,7 @@ void primary_pass_kernel(const DBlock B) {
         int inst = 0;
         F3 n = f3(0.0f, 0.0f, 0.0f);
         const unsigned sky = env_fetch(F.env, F.env_size, d);
-        if (reach && trace_closest<PATH, SINGLE, false, 2>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, k.s_primary, k.n_hits)) {
+        if (reach && trace_closest<PATH, SINGLE, false, 2, true>(F, o, d, 10000.0f, 0.0f, t_hit, inst, n, k.s_primary, k.n_hits)) {
             k.n_hits += 1;
             hit = true;
             const size_t r = pass_record(F, frame, b, wave, lane);
@@ -1756,7 +1775,7 @@ void primary_pass_kernel(const DBlock B) {
 }
 
 template <int PATH, bool SINGLE, bool DYN = false>
-__global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(VRT_SHADOW_PASS_WAVES))) void light_pass_kernel(const DBlock B) {
+__global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(SINGLE ? 8 : VRT_SHADOW_PASS_WAVES))) void light_pass_kernel(const DBlock B) {
     const int frame = (int)blockIdx.y;
     DFrame Fd;
     const DFrame& F = frame_view<DYN>(B, frame, Fd);
@@ -1781,7 +1800,7 @@ __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(V
         unsigned bits = 0u;
         if (F.shadow && !F.unlit) {
             const HitRecord h = F.hit_rec[r];
-            const F3 so = shadow_origin(F, o, d, h.t);
+            const F3 so = shadow_origin(F, o, d, h.t, F.view_vec ? camera_len(F, C, px, py) : 1.0f);
             const float tb = 0.0f + h.t;
             const F3 sun = f3(F.light_dir[0], F.light_dir[1], F.light_dir[2]);
             /* the directional light's ray is left out where the one-kernel form leaves it out: it is this hit's only term and the
@@ -1854,8 +1873,10 @@ __global__ __launch_bounds__(kMarchThreads) __attribute__((amdgpu_waves_per_eu(V
                 F.hit_aux[r] = aux | bits; /* the third pass shades this hit and follows its mirror ray */
             } else {
                 F3 color = albedo;
-                if (!F.unlit)
-                    color = direct_light_from_bits(F, shadow_origin(F, o, d, h.t), f3(-d.x, -d.y, -d.z), n, albedo, rough, metal, V->k, F.shadow != 0, false, bits);
+                if (!F.unlit) {
+                    const float vs = F.view_vec ? camera_len(F, C, px, py) : 1.0f;
+                    color = direct_light_from_bits(F, shadow_origin(F, o, d, h.t, vs), f3(-d.x * vs, -d.y * vs, -d.z * vs), n, albedo, rough, metal, V->k, F.shadow != 0, false, bits);
+                }
                 store_pixel(F, frame, (unsigned)pyl * (unsigned)F.width + (unsigned)px, color);
             }
         }
@@ -2010,9 +2031,6 @@ __device__ __forceinline__ bool march_hybrid(const DFrame& F, const VolRef& V, c
     st.hit = false;
     st.chk = __builtin_inff();
     st.c = Cell{0, 0, 0, 0.0f, 0.0f, 0.0f};
-#ifdef VRT_AB_TSTART
-    st.ab_first = -1.0f;
-#endif
     const int max_steps = F.max_steps;
     const int head = max_steps < kHeadSteps ? max_steps : kHeadSteps;
     if (act) march_lane<VRT_PATH_BRICK, false>(F, V, R, st, head, steps, nullptr);
@@ -2412,15 +2430,9 @@ __global__ void split_voxels_kernel(const uint2* __restrict__ voxels, float* __r
 
 /* ---- launch wrappers (host) -------------------------------------------------------------- */
 
-/* A/B only (VRT_AB_LDS_BYTES in the environment): dynamic LDS per one-wave workgroup that the kernel never touches, to cap the
- * number of resident waves per CU (160 KB of LDS per CU) without changing a line of kernel code. */
-static unsigned ab_lds_bytes() {
-    static const unsigned v = [] {
-        const char* e = getenv("VRT_AB_LDS_BYTES");
-        return e ? (unsigned)strtoul(e, nullptr, 10) : 0u;
-    }();
-    return v;
-}
+/* The lean kernel's REF instantiation is the one that reads DFrame::textured (constant textures only: anything else makes the launch
+   a full closest hit), view_vec and zero_outside. */
+static bool needs_ref_kernel(const DFrame& F) { return F.textured != 0 || F.view_vec != 0 || F.zero_outside != 0; }
 
 template <int PATH, bool SINGLE>
 static hipError_t launch_t(const DBlock& B, hipStream_t stream) {
@@ -2428,9 +2440,9 @@ static hipError_t launch_t(const DBlock& B, hipStream_t stream) {
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
     if (F.diag)
-        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, true>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), ab_lds_bytes(), stream, B);
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, true>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), 0, stream, B);
     else
-        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), ab_lds_bytes(), stream, B);
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), 0, stream, B);
     return hipGetLastError();
 }
 
@@ -2440,10 +2452,15 @@ static hipError_t launch_nodiag_t(const DBlock& B, hipStream_t stream) {
     const DFrame& F = B.f;
     const int grid = grid_blocks(F.tiles_x, F.tiles_y, F.tile_map);
     if (grid <= 0) return hipSuccess;
-    if (F.dyn != nullptr)
-        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false, true>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), ab_lds_bytes(), stream, B);
-    else
-        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), dim3((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), dim3(kMarchThreads), ab_lds_bytes(), stream, B);
+    const dim3 g((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), t(kMarchThreads);
+    if (needs_ref_kernel(F)) { /* constant material textures / the reference's view vector / boundary texels: the REF instantiation */
+        if (F.dyn != nullptr) hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false, true, true>), g, t, 0, stream, B);
+        else hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false, false, true>), g, t, 0, stream, B);
+    } else if (F.dyn != nullptr) {
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false, true>), g, t, 0, stream, B);
+    } else {
+        hipLaunchKernelGGL((march_kernel<PATH, SINGLE, false>), g, t, 0, stream, B);
+    }
     return hipGetLastError();
 }
 
@@ -2466,21 +2483,21 @@ static hipError_t launch_full_t(const DBlock& B, hipStream_t stream) {
     const dim3 g((unsigned)(grid * kMarchGridMul), (unsigned)F.n_frames), t(kMarchThreads);
     if (F.dyn != nullptr) { /* per-frame scene state: the DYN instantiations */
         if (F.hit_rec != nullptr) {
-            hipLaunchKernelGGL((primary_pass_kernel<PATH, SINGLE, true>), g, t, ab_lds_bytes(), stream, B);
-            hipLaunchKernelGGL((light_pass_kernel<PATH, SINGLE, true>), g, t, ab_lds_bytes(), stream, B);
-            if (F.may_bounce) hipLaunchKernelGGL((march_kernel_full<PATH, false, true, true>), g, t, ab_lds_bytes(), stream, B);
+            hipLaunchKernelGGL((primary_pass_kernel<PATH, SINGLE, true>), g, t, 0, stream, B);
+            hipLaunchKernelGGL((light_pass_kernel<PATH, SINGLE, true>), g, t, 0, stream, B);
+            if (F.may_bounce) hipLaunchKernelGGL((march_kernel_full<PATH, false, true, true>), g, t, 0, stream, B);
             return hipGetLastError();
         }
-        hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE, false, true>), g, t, ab_lds_bytes(), stream, B);
+        hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE, false, true>), g, t, 0, stream, B);
         return hipGetLastError();
     }
     if (F.hit_rec != nullptr) { /* three passes, see primary_pass_kernel */
-        hipLaunchKernelGGL((primary_pass_kernel<PATH, SINGLE>), g, t, ab_lds_bytes(), stream, B);
-        hipLaunchKernelGGL((light_pass_kernel<PATH, SINGLE>), g, t, ab_lds_bytes(), stream, B);
-        if (F.may_bounce) hipLaunchKernelGGL((march_kernel_full<PATH, false, true>), g, t, ab_lds_bytes(), stream, B);
+        hipLaunchKernelGGL((primary_pass_kernel<PATH, SINGLE>), g, t, 0, stream, B);
+        hipLaunchKernelGGL((light_pass_kernel<PATH, SINGLE>), g, t, 0, stream, B);
+        if (F.may_bounce) hipLaunchKernelGGL((march_kernel_full<PATH, false, true>), g, t, 0, stream, B);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE>), g, t, ab_lds_bytes(), stream, B);
+    hipLaunchKernelGGL((march_kernel_full<PATH, SINGLE>), g, t, 0, stream, B);
     return hipGetLastError();
 }
 
@@ -2496,7 +2513,10 @@ static hipError_t launch_path(const DBlock& B, bool single, bool diag_build, hip
         return launch_full_t<PATH, false>(B, stream);
     }
     if constexpr (PATH == VRT_PATH_DENSE || PATH == VRT_PATH_BRICK || PATH == kPathBrick16 || PATH == kPathCells16) {
-        if (diag_build) return single ? launch_t<PATH, true>(B, stream) : launch_t<PATH, false>(B, stream);
+        if (diag_build) {
+            if (needs_ref_kernel(F)) return hipErrorInvalidValue; /* (the diagnostic build has no REF instantiation) */
+            return single ? launch_t<PATH, true>(B, stream) : launch_t<PATH, false>(B, stream);
+        }
     }
     return single ? launch_nodiag_t<PATH, true>(B, stream) : launch_nodiag_t<PATH, false>(B, stream);
 }
@@ -2512,7 +2532,7 @@ hipError_t launch_march(const DBlock& B, int path, bool single, hipStream_t stre
         case kPathCells16: return launch_path<kPathCells16>(B, single, F.diag != 0, stream);
         case VRT_PATH_DENSE: return launch_path<VRT_PATH_DENSE>(B, single, F.diag != 0, stream);
         case VRT_PATH_BRICK_LDS:
-            if (single && !F.full && F.dyn == nullptr) return launch_coop(B, stream);
+            if (single && !F.full && F.dyn == nullptr && !needs_ref_kernel(F)) return launch_coop(B, stream);
             return launch_path<VRT_PATH_BRICK>(B, single, F.diag != 0, stream);
         default: return launch_path<VRT_PATH_BRICK>(B, single, F.diag != 0, stream);
     }

@@ -367,6 +367,14 @@ class VHipRenderer:
             _abi.check(m, "vrt_launch_history")
         return [(ms[i], fr[i]) for i in range(m)]
 
+    def last_kernel_form(self) -> int:
+        """Bit set of _abi.FORM_* naming the closest-hit kernel form the last march launch ran (vrt_debug_last_kernel_form)."""
+        self._require()
+        f = self._lib.vrt_debug_last_kernel_form(self._ctx)
+        if f < 0:
+            _abi.check(f, "vrt_debug_last_kernel_form")
+        return int(f)
+
     def wave_records(self, which: int = 0) -> np.ndarray:
         """Per-wave records of the last launch, [waves, 8] uint32 (vrt_debug_wave_records):
         which=0 counters, which=1 diagnostic timeline (after a FLAG_DIAG_TIMELINE launch)."""

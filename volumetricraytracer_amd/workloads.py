@@ -185,6 +185,39 @@ def full_closest_hit_scene(resolution: int = 6, env: int = 32) -> v.VScene:
                     PointLights=[point], SpotLights=[spot], EnvironmentMap=v.procedural_skybox(env))
 
 
+def boundary_box_scene(resolution: int = 4, env: int = 16, inset_cells: float = 0.6) -> v.VScene:
+    """A box whose faces lie `inset_cells` cells inside its volume's own boundary (16^3 cells by default): every hit's cell is the first
+    or the last of its axis, so the normal's central difference reaches for a neighbour cell BEYOND the grid — where the reference's
+    texture Load returns 0 (Voxel.hlsli:607-617) and this build's default repeats the boundary cell (VRT_FLAG_REFERENCE_BOUNDARY_TEXELS
+    selects the reference's rule).  Three faces in view, the object rotated and scaled anisotropically."""
+    vol = v.VVoxelVolume(resolution, 100.0)
+    gen = v.VDensityGenerator()
+    half = 100.0 - inset_cells * vol.GetCellSize()
+    gen.GetRootShape().AddChild(v.VBox((half, half, half)))
+    vol.fill(gen.Evaluate)
+    vol.Material = v.VMaterial((0.7, 0.75, 0.9, 1.0), 0.5, 0.1)
+    q = v.quat_mul(v.quat_from_axis_angle(v.UP, math.radians(33.0)), v.quat_from_axis_angle(v.RIGHT, math.radians(-21.0)))
+    obj = v.VVoxelObject(Rotation=tuple(q), Scale=(1.0, 0.8, 0.6), Volume=vol)
+    return v.VScene(Camera=v.look_minus_x_camera(380.0, 60.0), DirectionalLight=v.demo_light(), Objects=[obj],
+                    EnvironmentMap=v.procedural_skybox(env))
+
+
+def reference_default_normal_texel() -> np.ndarray:
+    """The 1x1 normal texture the reference binds to every material without a normal map: VColor(0.5, 0.5, 1) stored as 8 bits
+    (VRDXScene::AllocateDefaultTextures, RDXScene.cpp:241-260) = (127, 127, 255) — a 0.3-degree tilt of every normal in its
+    default render mode.  What the C++ adaptor binds by default (VHipRenderer::ReferenceDefaultTextures)."""
+    return np.array([[[127, 127, 255, 255]]], np.uint8)
+
+
+def with_reference_default_textures(scene: v.VScene) -> v.VScene:
+    """`scene` with the reference's default normal texel on every material that has no normal map (in place; returns it)."""
+    tex = reference_default_normal_texel()
+    for vol in scene.volumes():
+        if vol.Material.NormalTexture is None:
+            vol.Material.NormalTexture = tex
+    return scene
+
+
 def procedural_textures(seed: int = 5):
     """Seeded stand-ins for the reference's material texture files (none ship with it): an albedo checker with
     per-texel jitter (13x8), a bumpy normal map (16x16, z-dominant) and a roughness/metal map (4x6)."""
