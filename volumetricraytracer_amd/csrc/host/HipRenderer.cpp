@@ -319,6 +319,56 @@ namespace Renderer {
 
 std::shared_ptr<VRenderer> VRendererFactory::NewRenderer() { return std::make_shared<Hip::VHipRenderer>(); }
 
+/* ---- VTextureFactory (Renderer/Public/TextureFactory.h:32-41) over the build's own file readers ------------------------- */
+namespace {
+/* the reference's asset paths are std::wstring (Windows); file names here are UTF-8 */
+std::string narrow(const std::wstring& w) {
+    std::string out;
+    for (wchar_t wc : w) {
+        unsigned long c = (unsigned long)wc;
+        if (c < 0x80) out.push_back((char)c);
+        else if (c < 0x800) { out.push_back((char)(0xC0 | (c >> 6))); out.push_back((char)(0x80 | (c & 0x3F))); }
+        else if (c < 0x10000) { out.push_back((char)(0xE0 | (c >> 12))); out.push_back((char)(0x80 | ((c >> 6) & 0x3F))); out.push_back((char)(0x80 | (c & 0x3F))); }
+        else { out.push_back((char)(0xF0 | (c >> 18))); out.push_back((char)(0x80 | ((c >> 12) & 0x3F))); out.push_back((char)(0x80 | ((c >> 6) & 0x3F))); out.push_back((char)(0x80 | (c & 0x3F))); }
+    }
+    return out;
+}
+template <typename T>
+VObjectPtr<T> initialized(std::weak_ptr<VRenderer> renderer, VObjectPtr<T> texture) {
+    if (texture)
+        if (const std::shared_ptr<VRenderer> r = renderer.lock()) r->InitializeTexture(texture); /* TextureFactory.cpp:58,114,125,134,143 */
+    return texture;
+}
+}  // namespace
+
+VObjectPtr<VTextureCube> VTextureFactory::LoadTextureCubeFromFile(std::weak_ptr<VRenderer> renderer, const std::wstring& path) {
+    const std::string file = narrow(path);
+    /* the reference reads a .dds cube map (TextureFactory.cpp:28-67); a folder of six face images (its Resources/Skybox/ layout) is accepted too */
+    VObjectPtr<VTextureCube> t = VTextureCube::IsDDSPath(file) ? VTextureCube::LoadFromDDSFile(file) : VTextureCube::LoadFromFaceDirectory(file);
+    if (!t) V_LOG_ERROR(("Texture loading failed! " + file).c_str());
+    return initialized(renderer, t);
+}
+
+VObjectPtr<VTexture2D> VTextureFactory::LoadTexture2DFromFile(std::weak_ptr<VRenderer> renderer, const std::wstring& path) {
+    const std::string file = narrow(path);
+    VObjectPtr<VTexture2D> t = VTexture2D::LoadFromFile(file); /* R8G8B8A8, one mip (TextureFactory.cpp:69-119 forces RGB and rejects other formats) */
+    if (!t) V_LOG_ERROR(("Texture loading failed! " + file).c_str());
+    return initialized(renderer, t);
+}
+
+VObjectPtr<VTexture3D> VTextureFactory::CreateTexture3D(std::weak_ptr<VRenderer> renderer, const size_t& width, const size_t& height, const size_t& depth, const size_t& mipLevels) {
+    return initialized(renderer, std::make_shared<VTexture3D>(width, height, depth, mipLevels));
+}
+
+VObjectPtr<VTexture2D> VTextureFactory::CreateTexture2D(std::weak_ptr<VRenderer> renderer, const size_t& width, const size_t& height, const size_t& mipLevels) {
+    (void)mipLevels; /* one mip: what the closest-hit shader samples (SampleLevel(.., 0)) */
+    return initialized(renderer, std::make_shared<VTexture2D>(width, height, std::vector<uint8_t>(width * height * 4)));
+}
+
+VObjectPtr<VTexture3DFloat> VTextureFactory::CreateTexture3DFloat(std::weak_ptr<VRenderer> renderer, const size_t& width, const size_t& height, const size_t& depth, const size_t& mipLevels) {
+    return initialized(renderer, std::make_shared<VTexture3DFloat>(width, height, depth, mipLevels));
+}
+
 namespace Hip {
 
 namespace {
@@ -362,7 +412,17 @@ void VHipRenderer::ResizeRenderOutput(unsigned int width, unsigned int height) {
     Height = height;
 }
 
-void VHipRenderer::InitializeTexture(VObjectPtr<VTextureCube>) { /* nothing to create ahead of the upload */ }
+/* VRenderer::InitializeTexture (Renderer.h:56): the DX backend creates the texture's GPU resource and descriptors here
+   (DXRenderer.cpp:115-143); this backend allocates at upload time, so there is nothing to create ahead of it. */
+void VHipRenderer::InitializeTexture(VObjectPtr<VTexture>) {}
+
+/* VRenderer::UploadToGPU (Renderer.h:57): by dynamic type, as VDXRenderer::UploadToGPU queues its VDXTexture* kinds (DXRenderer.cpp:145-160). */
+void VHipRenderer::UploadToGPU(VObjectPtr<VTexture> texture) {
+    if (!texture) return;
+    if (auto cube = std::dynamic_pointer_cast<VTextureCube>(texture)) return UploadToGPU(cube);
+    if (auto tex2d = std::dynamic_pointer_cast<VTexture2D>(texture)) return UploadToGPU(tex2d);
+    /* VTexture3D / VTexture3DFloat: host containers only (volumes reach the device through vrt_volume_upload*) */
+}
 
 void VHipRenderer::UploadToGPU(VObjectPtr<VTextureCube> texture) {
     if (!Ctx) {
@@ -379,8 +439,6 @@ void VHipRenderer::UploadToGPU(VObjectPtr<VTextureCube> texture) {
     }
     if (ok(vrt_env_upload(Ctx, (int)texture->GetWidth(), texture->GetPixels().data()), "vrt_env_upload")) UploadedEnv = texture.get();
 }
-
-void VHipRenderer::InitializeTexture(VObjectPtr<VTexture2D>) { /* nothing to create ahead of the upload */ }
 
 void VHipRenderer::UploadToGPU(VObjectPtr<VTexture2D> texture) {
     if (!Ctx) {
@@ -557,6 +615,8 @@ vrt_params VHipRenderer::MakeParams(Scene::VScene& scene) const {
     p.cone_eps = std::tan((cam ? cam->FOVAngle : 60.f) * (3.14159265358979323846f / 180.0f) * 0.5f) / (float)Height;
     if (FrameFormat != EFrameFormat::Float4) p.flags |= VRT_FLAG_OUTPUT_RGBA8;
     if (FrameFormat == EFrameFormat::BGRA8) p.flags |= VRT_FLAG_OUTPUT_BGRA8;
+    if (ReferenceViewVector) p.flags |= VRT_FLAG_REFERENCE_VIEW_VECTOR;
+    if (ReferenceBoundaryTexels) p.flags |= VRT_FLAG_REFERENCE_BOUNDARY_TEXELS;
     return p;
 }
 

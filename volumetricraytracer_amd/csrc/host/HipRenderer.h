@@ -29,10 +29,12 @@ public:
     bool Start() override;
     void Stop() override;
     bool IsActive() const override { return Ctx != nullptr; }
-    void InitializeTexture(VObjectPtr<VTextureCube> texture) override;
-    void UploadToGPU(VObjectPtr<VTextureCube> texture) override;
-    void InitializeTexture(VObjectPtr<VTexture2D> texture) override;
-    void UploadToGPU(VObjectPtr<VTexture2D> texture) override;
+    /* Renderer.h:56-57: dispatch on the texture's dynamic type (cube map -> the sky, 2D -> the material-texture table; the 3D kinds
+       carry no device state in this backend).  The typed overloads below are what they call. */
+    void InitializeTexture(VObjectPtr<VTexture> texture) override;
+    void UploadToGPU(VObjectPtr<VTexture> texture) override;
+    void UploadToGPU(VObjectPtr<VTextureCube> texture);
+    void UploadToGPU(VObjectPtr<VTexture2D> texture);
     void ResizeRenderOutput(unsigned int width, unsigned int height) override;
 
     /* Material textures are looked up by the path a VMaterial names (the reference's path-keyed table,
@@ -72,6 +74,13 @@ public:
        pixels by more than one 8-bit step.  true (default): materials without a normal map get that texel, so that
        the frames are the reference's; false: unbound slots are exact identities (and a scene without textures keeps the lean kernel). */
     bool ReferenceDefaultTextures = true;
+    /* Two more of the reference's artefacts, on by default for the same reason (measured against the literal restatement of its shaders,
+       DESIGN.md section 5.0): it never normalises its camera direction, so its closest-hit shader evaluates the BRDF with a view vector of
+       length 1 ... 1.55 and backs the camera ray's secondary rays off by 0.1 times that (VRT_FLAG_REFERENCE_VIEW_VECTOR: 9.5 % of a mirror
+       scene's surface pixels by more than one 8-bit step); and its normal's taps beyond the volume texture read 0
+       (VRT_FLAG_REFERENCE_BOUNDARY_TEXELS: surfaces within a cell of their volume's box).  false: unit view vector / clamped cell. */
+    bool ReferenceViewVector = true;
+    bool ReferenceBoundaryTexels = true;
     float Relaxation = 1.7f;  /* vrt_params::k_relax: over-relaxed sphere-trace with the sphere-overlap fallback; 1 = plain */
     bool Shadows = true;      /* the reference always casts the directional shadow ray */
     int MaxBounces = 2;       /* MAX_RAY_RECURSION_DEPTH 3 = primary + 2 mirror bounces (RaytracingHlsl.h:32) */

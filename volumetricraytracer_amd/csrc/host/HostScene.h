@@ -22,10 +22,26 @@ namespace VolumeRaytracer {
 
 template <typename T> using VObjectPtr = std::shared_ptr<T>;
 
-/* VTextureCube reduced to what the miss shader reads: 6 faces (+X,-X,+Y,-Y,+Z,-Z) of RGBA8. */
-class VTextureCube {
+/* VTexture: the base every texture handed to VRenderer::InitializeTexture / UploadToGPU derives from
+   (Core/Public/Textures/Texture.h:22-35; the renderer dispatches on the dynamic type, as VDXRenderer does with its VDXTexture* classes,
+   DXRenderer.cpp:115-143). */
+class VTexture {
+public:
+    virtual ~VTexture() = default;
+    size_t GetMipCount() const { return MipCount; }
+    virtual size_t GetPixelCount() = 0;
+    virtual void Commit() {} /* Texture.h:31: the DX textures copy their CPU pixels into an upload heap here; host vectors need nothing */
+
+protected:
+    std::wstring AssetPath;
+    size_t MipCount = 1;
+};
+
+/* VTextureCube reduced to what the miss shader reads: 6 faces (+X,-X,+Y,-Y,+Z,-Z) of RGBA8 (Core/Public/Textures/TextureCube.h:21-38). */
+class VTextureCube : public VTexture {
 public:
     VTextureCube(size_t faceSize, std::vector<uint8_t> rgba8) : Width(faceSize), Height(faceSize), Pixels(std::move(rgba8)) {}
+    size_t GetPixelCount() override { return Width * Height * 6; }
     size_t GetWidth() const { return Width; }
     size_t GetHeight() const { return Height; }
     size_t GetArraySize() const { return 6; }
@@ -56,9 +72,15 @@ private:
    (Renderer/DX/Private/DXTexture2D.cpp:63-81).  The reference decodes image files with WIC/DDS
    (Renderer/Private/TextureFactory.cpp:58-125); here PNG (zlib), JPEG and binary PPM are read directly,
    anything else is the application's job (RegisterTexture). */
-class VTexture2D {
+class VTexture2D : public VTexture {
 public:
     VTexture2D(size_t width, size_t height, std::vector<uint8_t> rgba8) : Width(width), Height(height), Pixels(std::move(rgba8)) {}
+    size_t GetPixelCount() override { return Width * Height; }
+    /* Texture2D.h:26: the CPU pixel array of a mip level, for callers that fill a created texture in place */
+    void GetPixels(const size_t& mipLevel, uint8_t*& outPixelArray, size_t* outArraySize) {
+        outPixelArray = mipLevel == 0 ? Pixels.data() : nullptr;
+        if (outArraySize) *outArraySize = mipLevel == 0 ? Pixels.size() : 0;
+    }
     size_t GetWidth() const { return Width; }
     size_t GetHeight() const { return Height; }
     const std::vector<uint8_t>& GetPixels() const { return Pixels; }
@@ -74,6 +96,43 @@ public:
 private:
     size_t Width, Height;
     std::vector<uint8_t> Pixels;
+};
+
+/* VTexture3D / VTexture3DFloat (Core/Public/Textures/Texture3D.h, Texture3DFloat.h): host containers with the reference's surface.  The DX
+   backend keeps its volume and octree-traversal textures in these (RDXVoxelVolume.cpp:156-213); this backend re-tiles volumes on the device
+   itself (vrt_volume_upload*), so they exist for VTextureFactory's callers and carry no device state. */
+class VTexture3D : public VTexture {
+public:
+    VTexture3D(size_t width, size_t height, size_t depth, size_t mipLevels) : Width(width), Height(height), Depth(depth), Pixels(width * height * depth * 4) { MipCount = mipLevels; }
+    size_t GetPixelCount() override { return Width * Height * Depth; }
+    void GetPixels(const size_t& mipLevel, uint8_t*& outPixelArray, size_t* outArraySize) {
+        outPixelArray = mipLevel == 0 ? Pixels.data() : nullptr;
+        if (outArraySize) *outArraySize = mipLevel == 0 ? Pixels.size() : 0;
+    }
+    size_t GetWidth() const { return Width; }
+    size_t GetHeight() const { return Height; }
+    size_t GetDepth() const { return Depth; }
+
+private:
+    size_t Width, Height, Depth;
+    std::vector<uint8_t> Pixels;
+};
+
+class VTexture3DFloat : public VTexture {
+public:
+    VTexture3DFloat(size_t width, size_t height, size_t depth, size_t mipLevels) : Width(width), Height(height), Depth(depth), Pixels(width * height * depth) { MipCount = mipLevels; }
+    size_t GetPixelCount() override { return Width * Height * Depth; }
+    void GetPixels(const size_t& mipLevel, float*& outPixelArray, size_t* outArraySize) {
+        outPixelArray = mipLevel == 0 ? Pixels.data() : nullptr;
+        if (outArraySize) *outArraySize = mipLevel == 0 ? Pixels.size() : 0;
+    }
+    size_t GetWidth() const { return Width; }
+    size_t GetHeight() const { return Height; }
+    size_t GetDepth() const { return Depth; }
+
+private:
+    size_t Width, Height, Depth;
+    std::vector<float> Pixels;
 };
 
 namespace Scene {

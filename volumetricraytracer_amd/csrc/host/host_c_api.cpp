@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../../include/vrt.h"
+#include "HostRenderer.h"
 #include "HostSerialization.h"
 #include "SceneConverter.h"
 #include "VolumeConverter.h"
@@ -141,6 +142,56 @@ int vrh_cubemap_load(const char* dir, int* face_size, uint8_t* out, size_t cap) 
         }
         memcpy(out, t->GetPixels().data(), t->GetPixels().size());
     }
+    return 0;
+}
+
+/* The texture side of the drop-in boundary without a GPU: a renderer from VRendererFactory::NewRenderer() (not started), the five
+   VTextureFactory functions (Renderer/Public/TextureFactory.h:32-41) through it, and VRenderer::InitializeTexture / UploadToGPU with
+   base-typed arguments (Renderer.h:56-57).  dims_out[8]: 2D file w, h; cube face size; created 2D w, h; 3D depth; 3D-float depth; how many
+   InitializeTexture calls the renderer saw.  0 / -1. */
+namespace {
+struct CountingRenderer : Renderer::VRenderer {
+    int initialized = 0, uploaded = 0;
+    void Render() override {}
+    bool Start() override { return false; }
+    void Stop() override {}
+    bool IsActive() const override { return false; }
+    void InitializeTexture(VObjectPtr<VTexture>) override { initialized++; }
+    void UploadToGPU(VObjectPtr<VTexture>) override { uploaded++; }
+    void ResizeRenderOutput(unsigned int, unsigned int) override {}
+};
+}  // namespace
+
+int vrh_texture_factory_probe(const char* image_path, const char* cube_path, int* dims_out) {
+    using Renderer::VTextureFactory;
+    if (!dims_out) return -1;
+    for (int i = 0; i < 8; i++) dims_out[i] = 0;
+    auto counting = std::make_shared<CountingRenderer>();
+    std::weak_ptr<Renderer::VRenderer> r = counting;
+    const std::string ip = image_path ? image_path : "", cp = cube_path ? cube_path : "";
+    if (!ip.empty()) {
+        VObjectPtr<VTexture2D> t = VTextureFactory::LoadTexture2DFromFile(r, std::wstring(ip.begin(), ip.end()));
+        if (!t) { g_error = "LoadTexture2DFromFile failed"; return -1; }
+        dims_out[0] = (int)t->GetWidth();
+        dims_out[1] = (int)t->GetHeight();
+    }
+    if (!cp.empty()) {
+        VObjectPtr<VTextureCube> t = VTextureFactory::LoadTextureCubeFromFile(r, std::wstring(cp.begin(), cp.end()));
+        if (!t) { g_error = "LoadTextureCubeFromFile failed"; return -1; }
+        dims_out[2] = (int)t->GetWidth();
+    }
+    VObjectPtr<VTexture2D> c2 = VTextureFactory::CreateTexture2D(r, 3, 2, 1);
+    uint8_t* px = nullptr;
+    size_t n = 0;
+    c2->GetPixels(0, px, &n);
+    dims_out[3] = (int)c2->GetWidth();
+    dims_out[4] = n == 3 * 2 * 4 && px ? (int)c2->GetHeight() : -1;
+    dims_out[5] = (int)VTextureFactory::CreateTexture3D(r, 4, 5, 6, 1)->GetDepth();
+    dims_out[6] = (int)VTextureFactory::CreateTexture3DFloat(r, 2, 3, 7, 1)->GetDepth();
+    dims_out[7] = counting->initialized;
+    /* the HIP renderer's own overrides take base-typed textures too (inactive: UploadToGPU warns and returns) */
+    std::shared_ptr<Renderer::VRenderer> hip = Renderer::VRendererFactory::NewRenderer();
+    hip->InitializeTexture(std::static_pointer_cast<VTexture>(c2));
     return 0;
 }
 
