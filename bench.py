@@ -54,7 +54,24 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
 # 4 x dwordx2 taps per lane at random cells, by where the bricks live; l1_coherent_lanes: the same with the 64 lanes of a wave on the 3x3 cells
 # an 8x8-pixel tile covers (lanes that share a cell share its lines; 552 / 561 / 540 from L1 / L2 / the 256^3 pool)
 NATIVE_PROBE_DEADLINE_S = float(os.environ.get("VRT_BENCH_NATIVE_PROBE_DEADLINE_S", "120"))  # vrt_comm_init + a 64-byte exchange and gather; RCCL's bootstrap takes a few seconds
+# FALLBACK only (a library without vrt_debug_gather_ceiling): since round 5 the ceilings are measured in the run itself, on the run's own box
 GATHER_CEILING_GSAMPLES = {"l1": 264.0, "l2": 209.0, "mall_hbm": 126.0, "l1_int16": 298.0, "l1_coherent_lanes": 552.0}
+
+
+def measure_gather_ceilings(r, _abi):
+    """The march's inner operation in isolation on THIS box and build (vrt_debug_gather_ceiling, ~10 ms each): G trilinear samples per second
+    for independent cells from an L1- / L2-resident pool and from the pool of a 256^3 volume (fp32 bricks), for int16 bricks, and with the 64
+    lanes of a wave on the 3x3 cells of an 8x8-pixel tile.  Returns (table, True) or (the round-4 constants, False)."""
+    try:
+        return {"l1": round(r.gather_ceiling(_abi.FORMAT_F32, False, 32), 1),
+                "l2": round(r.gather_ceiling(_abi.FORMAT_F32, False, 4096), 1),
+                "mall_hbm": round(r.gather_ceiling(_abi.FORMAT_F32, False, 262144), 1),
+                "l1_int16": round(r.gather_ceiling(_abi.FORMAT_TEXEL16, False, 32), 1),
+                "l1_coherent_lanes": round(r.gather_ceiling(_abi.FORMAT_F32, True, 32), 1),
+                "l1_int16_coherent_lanes": round(r.gather_ceiling(_abi.FORMAT_TEXEL16, True, 32), 1)}, True
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] vrt_debug_gather_ceiling unavailable ({e!r}): round-4 constants", file=sys.stderr)
+        return dict(GATHER_CEILING_GSAMPLES), False
 
 
 def parse_args(argv=None):
@@ -250,6 +267,7 @@ class Pipeline:
         self.copy_stream = torch.cuda.Stream(device=dev) if self.unshuffle else None
         self.unshuffled = [None] * K
         self.blocks = 0
+        self.xchg_events = []  # native exchange only: (before, after) timing events around every block's collective on its march stream
         self.last = (0, 0)  # (buffer, frame within the block) of the last frame issued
         # the batch's cameras, twice over (a block may wrap around the end of the batch): frame i uses camera i % n_cameras
         self.cameras, self.n_cameras, self.frame_no = cameras, n_cameras, 0
@@ -280,7 +298,13 @@ class Pipeline:
                     fg.tiles[b].copy_(self.march_tiles[b])
                 if self.world > 1:
                     if self.native:  # ncclGather right behind the block's marches on the same stream; "pending" = an event after it
+                        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        ea.record(st)
                         fg.native_gather(r, b, st.cuda_stream)
+                        eb.record(st)
+                        self.xchg_events.append((ea, eb))
+                        if len(self.xchg_events) > 4096:
+                            del self.xchg_events[:2048]
                         self.pending[b] = _StreamEvent(torch, st)
                     else:
                         self.pending[b] = fg.gather(b, async_op=True)  # RCCL gather over xGMI, overlaps the other streams' marches
@@ -293,6 +317,13 @@ class Pipeline:
                     self.unshuffled[b].record(self.copy_stream)
             self.last = (b, n - 1)
             self.blocks += 1
+
+    def exchange_ms(self, last_n: int):
+        """Mean duration (ms) of the last `last_n` blocks' native collectives on this rank (call after drain()); None without them."""
+        ev = self.xchg_events[-max(last_n, 1):]
+        if not ev:
+            return None
+        return float(sum(a.elapsed_time(b) for a, b in ev) / len(ev))
 
     def last_frame(self):
         """The assembled last frame issued, on the rank that assembles it (rank 0, or the frame's root with rotating roots);
@@ -521,7 +552,7 @@ def main() -> None:
     r.ResizeRenderOutput(W, H)
     r.SyncWithScene()
 
-    native_ready, native_error = False, None
+    native_ready, native_error, probe_abandoned = False, None, False
     # VRT_BENCH_NATIVE_PROBE=1 runs this block in a rehearsal too: two ranks on ONE GPU is something RCCL refuses or waits on for
     # ever, which is exactly the failure the deadline below exists for (tests/test_parity_gpu.py walks it)
     if world > 1 and (not rehearsal or os.environ.get("VRT_BENCH_NATIVE_PROBE") == "1"):
@@ -530,21 +561,33 @@ def main() -> None:
         # torch.distributed carries it to the others
         # ... inside a thread with a deadline: a bootstrap that never returns (it has never run on N > 1 GPUs) must cost the run its
         # native path, not the run — ctypes drops the GIL in the call, every rank times out alike, and the flag below agrees on it
-        idt = torch.zeros(_abi.VRT_COMM_ID_BYTES, dtype=torch.uint8, device=cdev)
-        try:
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(v.VHipRenderer.comm_unique_id()), dtype=torch.uint8))
-        except Exception as e:  # noqa: BLE001
-            native_error = repr(e)
-        dist.broadcast(idt, 0)
-        id_bytes = bytes(idt.cpu().numpy().tobytes())
+        # ... and on a CONTEXT OF ITS OWN: a probe that is abandoned at its deadline leaves its thread inside vrt_comm_init or
+        # the probe exchange for good; that thread must not share a vrt_ctx with the measurement (vrt_destroy under it = use after free).
+        # The probe context is never stopped once abandoned; the main context only initialises its communicator after the probe has
+        # come back.  If the probe's GPU collective itself is stuck, no device-wide synchronize would ever return: the run then prints
+        # what it knows and leaves with os._exit (no destructors over a thread that is still inside RCCL).
+        def fresh_id():
+            idt = torch.zeros(_abi.VRT_COMM_ID_BYTES, dtype=torch.uint8, device=cdev)
+            err = None
+            try:
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(v.VHipRenderer.comm_unique_id()), dtype=torch.uint8))
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+            dist.broadcast(idt, 0)
+            return bytes(idt.cpu().numpy().tobytes()), err
+
+        id_bytes, native_error = fresh_id()
         probe_stream = torch.cuda.Stream(device=dev)
         probe_result = {}
+        probe_ctx = v.VHipRenderer(devices=(local_rank,))
 
         def native_probe():
             try:
                 torch.cuda.set_device(dev)
-                r.comm_init(world, rank, id_bytes)
+                if not probe_ctx.Start():
+                    raise RuntimeError("probe context: Start() failed")
+                probe_ctx.comm_init(world, rank, id_bytes)
                 # the product's exchange on a few bytes before the run stands on it: chunk d of my buffer goes to rank d
                 # (vrt_exchange_tiles), every rank's tile lands rank-major on rank 0 (vrt_gather_tiles)
                 cb = 64
@@ -554,8 +597,8 @@ def main() -> None:
                     tile = torch.full((cb,), 100 + rank, dtype=torch.uint8, device=dev)
                     got = torch.zeros((world, cb), dtype=torch.uint8, device=dev)
                     st0 = probe_stream.cuda_stream
-                    r.exchange_tiles(snd.data_ptr(), rcv.data_ptr(), cb, st0)
-                    r.gather_tiles(tile.data_ptr(), got.data_ptr() if rank == 0 else 0, cb, 0, st0)
+                    probe_ctx.exchange_tiles(snd.data_ptr(), rcv.data_ptr(), cb, st0)
+                    probe_ctx.gather_tiles(tile.data_ptr(), got.data_ptr() if rank == 0 else 0, cb, 0, st0)
                     probe_stream.synchronize()
                     want = (16 * torch.arange(world, dtype=torch.int32)[:, None] + rank).to(torch.uint8).expand(world, cb)
                     ok_x = bool((rcv.cpu() == want).all())
@@ -572,12 +615,30 @@ def main() -> None:
             th.start()
             th.join(NATIVE_PROBE_DEADLINE_S)
             if th.is_alive():
+                probe_abandoned = True
                 native_error = f"vrt_comm_init / the probe exchange did not return within {NATIVE_PROBE_DEADLINE_S} s"
+                if not probe_stream.query():
+                    # the probe's collective sits on the device and does not finish: nothing that synchronises the device can return
+                    print(json.dumps({"error": "native exchange probe hung ON THE DEVICE: " + native_error, "n_gpus": world, "rank": rank}), flush=True)
+                    os._exit(3)
             else:
                 native_ready, native_error = bool(probe_result.get("ok")), probe_result.get("error")
+                probe_ctx.Stop()  # the probe came back: its context (and communicator) can go
         flag = torch.tensor([1 if native_ready else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         native_ready = bool(flag.item()) and not rehearsal
+        if native_ready:
+            # the measurement's own communicator, on the context the measurement uses: the same call sequence just worked on this box
+            try:
+                id2, err2 = fresh_id()
+                if err2:
+                    raise RuntimeError(err2)
+                r.comm_init(world, rank, id2)
+            except Exception as e:  # noqa: BLE001
+                native_ready, native_error = False, repr(e)
+            flag = torch.tensor([1 if native_ready else 0], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            native_ready = bool(flag.item())
     use_native = args.gather == "native" and native_ready
     native_fallback = None
     if args.gather == "native" and world > 1 and not native_ready and (not rehearsal or native_error):
@@ -630,8 +691,10 @@ def main() -> None:
         return Pipeline(r, pp, w, h, world, rank, dev, rgba8, strip_rows, k, rehearsal, native=native, block_frames=g or G, cameras=cam_arr,
                         n_cameras=B, rotate=rotate if rot is None else rot)
 
+    ceilings, ceilings_measured = measure_gather_ceilings(r, _abi) if rank == 0 else (dict(GATHER_CEILING_GSAMPLES), False)
     pipe = pipeline(p, W, H, K, use_native)
     elapsed = timed_run(pipe, args.steps, args.warmup, world, cdev, B * L)
+    xchg_ms = pipe.exchange_ms(n_timed_blocks := len(list(block_plan(args.steps * B * L, G, K)))) if world > 1 else None
     # the event-timed march launches of the timed region: (ms, frames the launch covered); only whole blocks count
     n_timed = len(list(block_plan(args.steps * B * L, G, K)))  # launches of the timed region (the warm-up's come before them)
     hist = [(ms, fr) for ms, fr in r.launch_history(min(max(n_timed, 1), 200)) if ms > 0.0]
@@ -680,6 +743,18 @@ def main() -> None:
         if not verified:
             raise SystemExit("[bench] the assembled frame differs from the single-GPU frame")
 
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([float(np.mean(kms)) if kms else 0.0, xchg_ms if xchg_ms is not None else -1.0], dtype=torch.float64, device=cdev)
+        hi, lo = mine.clone(), mine.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        per_rank = {"march_ms_per_launch": {"rank0": round(float(mine[0]), 4), "max": round(float(hi[0]), 4), "min": round(float(lo[0]), 4)},
+                    "exchange_ms_per_block": ({"rank0": round(float(mine[1]), 4), "max": round(float(hi[1]), 4), "min": round(float(lo[1]), 4)}
+                                              if float(lo[1]) >= 0.0 else None),
+                    "frames_per_launch": G, "streams": K,
+                    "note": "event-timed on each rank's march stream over the timed region; exchange: the native collective only (vrt_exchange_tiles / "
+                            "vrt_gather_tiles on the march stream); with two streams a block's collective overlaps the other stream's march"}
     cnt = batch_counts(p, W, H)  # whole job, one batch
     rays_per_batch = cnt["primary_rays"] + cnt["shadow_rays"]
     rays_per_step = rays_per_batch * L
@@ -867,6 +942,63 @@ def main() -> None:
         r.SetSceneToRender(sc)
         r.SyncWithScene()
 
+    dropin_leg = None
+    if not args.no_extra_legs and args.steps > 0 and world == 1 and args.workload == "c3":
+        # What a drop-in user gets: the C++ adaptor's DEFAULTS — render mode Interp (the reference's default),
+        # the volume as the reference's 16-bit texel, its 1x1 default normal texel on the material, B8G8R8A8 frames, the two reference-artefact
+        # flags, MaxBounces 2 — on the benchmark's frames, as a block (one launch per 96 frames) and as a lone frame (one frame per launch, one
+        # in flight).  Next to it, on the same box: the lean kernel in the same pixel and volume format (NoTex mode, no texel, no flags) and the
+        # form round 4 ran this state in (the texel as an IMAGE: the full closest hit).  A 1x1 texture is a constant folded into the lean
+        # kernel's REF instantiation: `kernel_form` says which kernel ran.
+        def run_dropin(_):
+            for vol in sc.volumes():
+                vol.set_device_format(_abi.FORMAT_TEXEL16)
+            mat = sc.volumes()[0].Material
+            out_fmt = _abi.FLAG_OUTPUT_RGBA8 | _abi.FLAG_OUTPUT_BGRA8
+            sd = max(min(args.steps, 10), 1)
+
+            def one(label, mode, flags, normal_tex, g, steps_):
+                mat.NormalTexture = normal_tex
+                r.SetSceneToRender(sc)
+                r.SyncWithScene()
+                pd = params(W, H, as_rgba8=True)
+                pd.mode, pd.max_bounces = mode, 2
+                pd.flags |= out_fmt | flags
+                pl = Pipeline(r, pd, W, H, 1, 0, dev, True, 0, 1, False, block_frames=g, cameras=cam_arr, n_cameras=B)
+                e = timed_run(pl, steps_, 1, 1, cdev, B)
+                form = r.last_kernel_form()
+                c = batch_counts(pd, W, H, alone=True)
+                del pl
+                return {"what": label, "frames_per_launch": g, "ms_per_frame": round(e / (steps_ * B) * 1e3, 4),
+                        "value": round((c["primary_rays"] + c["shadow_rays"] + c["bounce_rays"]) * steps_ / e / 1e6, 2), "unit": "Mrays/s",
+                        "kernel_form": {"full_closest_hit": bool(form & _abi.FORM_FULL), "passes": bool(form & _abi.FORM_PASSES),
+                                        "lean_ref_instantiation": bool(form & _abi.FORM_LEAN_REF), "textured": bool(form & _abi.FORM_TEXTURED)}}
+
+            ref_flags = _abi.FLAG_REFERENCE_VIEW_VECTOR | _abi.FLAG_REFERENCE_BOUNDARY_TEXELS
+            texel = workloads.reference_default_normal_texel()
+            image = np.ascontiguousarray(np.tile(texel, (2, 2, 1)))  # the same texel as a 2x2 IMAGE: what round 4's host made of it
+            try:
+                od = {"settings": "mode Interp, VRT_FORMAT_TEXEL16, the reference's 1x1 default normal texel bound, B8G8R8A8 frames, "
+                                  "VRT_FLAG_REFERENCE_VIEW_VECTOR | _BOUNDARY_TEXELS, max_bounces 2 (VHipRenderer's defaults)",
+                      "block": one("adaptor defaults, one launch per batch", _abi.MODE_INTERP, ref_flags, texel, B, sd),
+                      "lone_frame": one("adaptor defaults, one frame per launch, one in flight", _abi.MODE_INTERP, ref_flags, texel, 1, max(sd // 3, 1)),
+                      "lean_same_formats": {"block": one("lean kernel: Interp_NoTex, no texel, no flags; same volume and pixel formats", _abi.MODE_INTERP_NOTEX, 0, None, B, sd),
+                                            "lone_frame": one("the same, one frame per launch", _abi.MODE_INTERP_NOTEX, 0, None, 1, max(sd // 3, 1))},
+                      "round4_form": {"block": one("the texel as a 2x2 image: full closest hit in passes (round 4's path for this state)", _abi.MODE_INTERP, ref_flags, image, B, sd),
+                                      "lone_frame": one("the same, one frame per launch (one kernel)", _abi.MODE_INTERP, ref_flags, image, 1, max(sd // 3, 1))}}
+                od["block_over_lean"] = round(od["block"]["value"] / od["lean_same_formats"]["block"]["value"], 3)
+                od["lone_frame_over_lean"] = round(od["lean_same_formats"]["lone_frame"]["ms_per_frame"] / od["lone_frame"]["ms_per_frame"], 3)
+                od["block_over_round4_form"] = round(od["block"]["value"] / od["round4_form"]["block"]["value"], 3)
+            finally:
+                mat.NormalTexture = None
+                for vol in sc.volumes():
+                    vol.set_device_format(fmt)
+                r.SetSceneToRender(sc)
+                r.SyncWithScene()
+            return od
+
+        dropin_leg = leg(lambda: None, run_dropin)
+
     dynamic_leg = None
     if not args.no_extra_legs and args.steps > 0 and world == 1 and args.workload == "c3":
         # Per-frame scene state (vrt_block::scenes): BASELINE config 5's 8 instances ALL moving from frame to frame — the reference moves
@@ -961,8 +1093,8 @@ def main() -> None:
                 gs = samples_c / (float(np.mean(kc)) * 1e-3) / 1e9
                 ge = (samples_c + 6.0 * tot["hits"]) / (float(np.mean(kc)) * 1e-3) / 1e9  # + the 6 trilinear evaluations of every hit's normal
                 outc.update({"kernel_ms_per_launch": round(float(np.mean(kc)), 4), "gsamples_per_s": round(gs, 2), "gevaluations_per_s": round(ge, 2),
-                             "limiter_frac": round(ge / GATHER_CEILING_GSAMPLES["l1_int16" if fmt == _abi.FORMAT_TEXEL16 else "l1"], 4),
-                             "limiter_frac_coherent_lanes": round(ge / GATHER_CEILING_GSAMPLES["l1_coherent_lanes"], 4),
+                             "limiter_frac": round(ge / ceilings["l1_int16" if fmt == _abi.FORMAT_TEXEL16 else "l1"], 4),
+                             "limiter_frac_coherent_lanes": round(ge / ceilings["l1_coherent_lanes"], 4),
                              "roofline_frac_algorithmic": round(v.algorithmic_bytes({k: tot[k] for k in KEYS}, 16) / (float(np.mean(kc)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
             return outc
 
@@ -984,48 +1116,60 @@ def main() -> None:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(sc, p, args.cpu_seconds)
+        coherent_key = "l1_int16_coherent_lanes" if (fmt == _abi.FORMAT_TEXEL16 and "l1_int16_coherent_lanes" in ceilings) else "l1_coherent_lanes"
         roofline = {
-            # What the counters say the kernel is on: vector-instruction issue while the chip is full, the latency of dependent
-            # position chains when it is not (a lone frame); HBM carries a few per cent of its peak (the bricks are served by L1 /
-            # L2), MFMA is not used (gather-type lookups).  The contract's fields stay what the contract defines: ALGORITHMIC bytes
-            # (32 B per trilinear sample + 192 B per hit + the pixel store) of one launch / its mean event-timed
-            # duration / the HBM peak
-            "bound": "vector-memory (texture) pipeline (td_busy_frac / ta_busy_frac below) and the latency of dependent loads at the hardware's 8 waves "
-                     "per SIMD, ahead of vector issue (valu_issue_frac) -- PMC counters; not hbm (hbm_measured_frac), not mfma (unused)",
+            # The contract's fields are what the contract defines: ALGORITHMIC bytes (32 B per trilinear sample + 192 B per hit +
+            # the pixel store) of one launch / its mean event-timed duration / the HBM peak.  Everything in `measured_in_run` was measured by
+            # THIS process on THIS box; everything in `replayed_from_profiles` comes from the committed PMC passes of tools/r05_profile.sh
+            # (keyed by the kernel sources' hash and the run's settings) and was NOT measured by this run.
+            "bound": "vector-memory (texture) pipeline (replayed_from_profiles.td_busy_frac / ta_busy_frac) and the latency of dependent loads at the "
+                     "hardware's 8 waves per SIMD, ahead of vector issue -- PMC counters; not hbm (hbm_measured_frac), not mfma (unused)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_key": key,
-            "kernel": "primary_pass_kernel + light_pass_kernel (the full closest hit of a block of frames in passes; one duration per launch = both)" if args.workload == "c3light" else "march_kernel", "kernel_ms": round(k_ms, 4), "frames_per_launch": fpl, "algorithmic_bytes_per_launch": int(alg_bytes),
+            "frac_note": "frac = algorithmic bytes (32 B per sample, cache-served or not) / launch time / 8 TB/s: an accounting of samples, not of bytes that "
+                         "cross the HBM interface (96 % of the taps are L1 hits); it MAY EXCEED 1.  The roof the kernel is under is measured_in_run.limiter_*; "
+                         "the physical HBM share is replayed_from_profiles.hbm_measured_frac",
+            "kernel": "primary_pass_kernel + light_pass_kernel (the full closest hit of a block of frames in passes; one duration per launch = both)" if args.workload == "c3light" else "march_kernel",
+            "kernel_ms": round(k_ms, 4), "frames_per_launch": fpl, "algorithmic_bytes_per_launch": int(alg_bytes),
             "samples_per_launch": samples,
-            "gsamples_per_s": round(samples / (k_ms * 1e-3) / 1e9, 2) if kms else None,
-            "gather_ceiling_gsamples_per_s": GATHER_CEILING_GSAMPLES,
-            # The roof the kernel is actually under: its trilinear samples per second against the rate the chip
-            # sustains for this very access pattern served from L1 (tools/microbench/gather.hip, profiles/r04_gather_microbench.txt) —
-            # 96 % of the march's taps are L1 hits.  `frac` above counts cache-served taps as HBM bytes (the contract's algorithmic
-            # bytes): it says how many samples the kernel takes, not how many bytes cross the HBM interface, and MAY EXCEED 1.
-            "limiter": "L1-served trilinear gather (texture path: td_busy_frac is its busy fraction from the PMC counters)",
-            # every trilinear evaluation the launch makes — march and polish samples AND the 6 of every hit's normal (SURVEY §8d counts them:
-            # 192 B per hit) — per second, against the ceiling
-            "trilinear_evaluations_per_launch": evals,
-            "gevaluations_per_s": round(evals / (k_ms * 1e-3) / 1e9, 2) if kms else None,
-            "limiter_frac": round(evals / (k_ms * 1e-3) / 1e9 / GATHER_CEILING_GSAMPLES[gather_key], 4) if kms else None,
-            # ... and against the ceiling of a gather whose 64 lanes sit on the 3x3 cells of an 8x8-pixel tile (the march's lanes lie between the two)
-            "limiter_frac_coherent_lanes": round(evals / (k_ms * 1e-3) / 1e9 / GATHER_CEILING_GSAMPLES["l1_coherent_lanes"], 4) if kms else None,
-            "limiter_ceiling_gsamples_per_s": GATHER_CEILING_GSAMPLES[gather_key],
-            "frac_note": "frac = algorithmic bytes (32 B per sample, cache-served or not) / launch time / 8 TB/s: an accounting of samples; it may exceed 1. "
-                         "limiter_frac = trilinear evaluations (samples + 6 per hit normal) per second / the measured L1 gather ceiling; hbm_measured_frac the physical HBM share",
-            # measured in round 4 (profiles/r04_ab_cell_activity_mask.txt): the evaluation RATE is how the texture path's load is counted, not
-            # what its time is made of — a build that takes a third fewer samples for bit-identical frames is 3.4 % faster
-            "limiter_note": "the texture path is busy with cache-line look-ups per wave instruction (l1_cache_line_accesses_per_cu_cycle of 1 per CU and cycle, "
-                            "td_busy_frac), which lanes of one 8x8-pixel tile share: an A/B that removed 33 % of the samples with bit-identical frames "
-                            "gained 3.4 % (profiles/r04_ab_cell_activity_mask.txt) -- limiter_frac counts lane-level evaluations and overstates what fewer samples would buy",
+            "measured_in_run": {
+                "kernel_ms": round(k_ms, 4),
+                "gsamples_per_s": round(samples / (k_ms * 1e-3) / 1e9, 2) if kms else None,
+                # every trilinear evaluation the launch makes — march and polish samples AND the 6 of every hit's normal (SURVEY §8d counts
+                # them: 192 B per hit) — per second
+                "trilinear_evaluations_per_launch": evals,
+                "gevaluations_per_s": round(evals / (k_ms * 1e-3) / 1e9, 2) if kms else None,
+                # the march's inner operation in isolation, on this box, right before the timed region (vrt_debug_gather_ceiling):
+                # independent cells per lane (by where the bricks live; fp32 and int16 bricks) and the 64 lanes of a wave on the 3x3 cells
+                # of an 8x8-pixel tile
+                "gather_ceiling_gsamples_per_s": ceilings, "gather_ceiling_measured_in_run": ceilings_measured,
+                "limiter": "L1-served trilinear gather (the texture path)",
+                "limiter_ceiling_gsamples_per_s": ceilings[gather_key],
+                "limiter_frac": round(evals / (k_ms * 1e-3) / 1e9 / ceilings[gather_key], 4) if kms else None,
+                # ... and against a gather whose 64 lanes are tile-coherent (the march's lanes lie between the two)
+                "limiter_ceiling_coherent_lanes_gsamples_per_s": ceilings[coherent_key],
+                "limiter_frac_coherent_lanes": round(evals / (k_ms * 1e-3) / 1e9 / ceilings[coherent_key], 4) if kms else None,
+                # measured in round 4 (profiles/r04_ab_cell_activity_mask.txt): the evaluation RATE is how the texture path's load is counted,
+                # not what its time is made of — a build that takes a third fewer samples for bit-identical frames is 3.4 % faster
+                "limiter_note": "the texture path is busy with cache-line look-ups per wave instruction (replayed_from_profiles.lines_per_vmem_instr: 19 "
+                                "where a tile-coherent wave needs ~4), which lanes of one 8x8-pixel tile share: limiter_frac counts lane-level evaluations "
+                                "and overstates what fewer samples would buy",
+            },
         }
+        # (kept at the top level too: the driver's records of earlier rounds read them there)
+        roofline["limiter_frac"] = roofline["measured_in_run"]["limiter_frac"]
+        roofline["limiter_ceiling_gsamples_per_s"] = roofline["measured_in_run"]["limiter_ceiling_gsamples_per_s"]
+        roofline["limiter_frac_coherent_lanes"] = roofline["measured_in_run"]["limiter_frac_coherent_lanes"]
         if pmc and kms:
-            # physical picture, from the keyed PMC passes (profiles/counters_latest.json: tools/r03_profile.sh on this kernel source
-            # with these settings): what really crosses the HBM interface, and how busy the vector issue is
+            # physical picture, from the keyed PMC passes (profiles/counters_latest.json): what really crosses the HBM interface, how busy
+            # the texture path and the vector issue are.  REPLAYED: taken by the profiler on this kernel source with these settings, not by this run
             cyc = pmc.get("gpu_cycles_per_launch")  # GRBM_GUI_ACTIVE / 8 XCDs, taken under the counters' own (serialised) run
             clock = float(pmc.get("clock_ghz") or 2.4)
             valu = pmc.get("SQ_INSTS_VALU")
-            roofline.update({
+            roofline["replayed_from_profiles"] = {
+                "tag": pmc.get("tag"), "file": "profiles/counters_latest.json", "kernel_source_sha": key["kernel_source_sha"],
+                "what": "rocprofv3 --pmc passes of this very command on this kernel source (tools/r05_profile.sh); combined with THIS run's kernel_ms where a rate is formed",
+                "hbm_bytes_per_launch": traffic,
                 "hbm_measured_GBps": round(traffic / (k_ms * 1e-3) / 1e9, 2) if traffic else None,
                 "hbm_measured_frac": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "hbm_floor_us_per_frame": round(traffic / fpl / (HBM_PEAK_GBS * 1e9) * 1e6, 2) if traffic else None,
@@ -1036,12 +1180,13 @@ def main() -> None:
                 "occupancy_mean_waves_per_cu": pmc.get("occupancy_mean_waves_per_cu"),
                 # busy cycles of the texture path's two units summed over the CUs / 256 / the launch's GPU cycles (in the counters' own run)
                 "td_busy_frac": pmc.get("td_busy_frac"), "ta_busy_frac": pmc.get("ta_busy_frac"),
-                # cache-line accesses the L1 (TCP) serves per CU and cycle (TCP_TOTAL_CACHE_ACCESSES_sum / 256 CUs / GPU cycles): the
-                # vector L1 looks up about one line per cycle — 0.82 on config 3, 0.89 with every wave marching — and its share that goes on to L2
+                # cache-line accesses the L1 (TCP) serves per CU and cycle (TCP_TOTAL_CACHE_ACCESSES_sum / 256 CUs / GPU cycles) and per
+                # wave-level vector-memory read instruction (.. / SQ_INSTS_VMEM_RD): ~4 if the 64 lanes of a load read one brick
                 "l1_cache_line_accesses_per_cu_cycle": pmc.get("l1_cache_line_accesses_per_cu_cycle"),
+                "lines_per_vmem_instr": pmc.get("lines_per_vmem_instr"),
                 "valu_lane_utilisation": pmc.get("valu_lane_utilisation"),
-                "counters_from": pmc.get("tag"),
-            })
+                "gpu_cycles_per_launch": cyc,
+            }
         if latency and latency.get("kernel_ms_per_frame") and cpu and cpu.get("chain_positions_max"):
             # the lone frame: its longest chain of dependent positions (oracle, same frame) x the time a position takes
             roofline["latency_model"] = {"chain_positions_max": cpu["chain_positions_max"],
@@ -1070,7 +1215,7 @@ def main() -> None:
                        "samples_per_ray": round((psteps + ssteps) / max(rays_per_batch, 1), 2)},
             "roofline": roofline, "cpu_baseline": cpu,
             "latency": latency, "scale_anchor": scale_anchor, "end_to_end": end_to_end, "config4": config4, "reference_texel_format": texel_leg, "full_closest_hit": full_leg,
-            "no_cull_rect": no_cull, "dynamic_scene": dynamic_leg, "full_coverage": coverage_leg,
+            "no_cull_rect": no_cull, "dynamic_scene": dynamic_leg, "full_coverage": coverage_leg, "drop_in_defaults": dropin_leg,
         }
         if world > 1:
             out["speedup_vs_anchor"] = round(value / scale_anchor["value"], 3) if scale_anchor and scale_anchor.get("value") else None
@@ -1084,13 +1229,24 @@ def main() -> None:
                 out["collective_fallback"] = native_fallback
             out.update(multi_gpu_summary(value, scale_anchor.get("value") if scale_anchor else None, rotate, exchange_other, world, W, H,
                                          4 if rgba8 else 16, rays_per_frame, max(min(args.steps, 3), 1)))
+            # what the block's time is made of on a rank, to be read against the link model at a glance: this rank's event-timed march per
+            # launch (max / min over the ranks), and — native exchange only: it runs on the march stream — the collective's own duration
+            out["per_rank"] = per_rank
+            out["scaling_curve"] = ("this line is ONE point: a 1 -> N curve exists only where the driver's SCALE record measured N = 1, 2, 4, 8 back to back; "
+                                    "no round of this build has had more than one physical GPU")
         if verified is not None:
             out["assembled_frame_equals_single_gpu_frame"] = verified
+        if probe_abandoned:
+            out["native_probe_abandoned"] = True  # its thread is still inside vrt_comm_init / RCCL on a context of its own: the process leaves without destructors
         print(json.dumps(out), flush=True)
 
     r.Stop()
     if world > 1:
         dist.destroy_process_group()
+    if probe_abandoned:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 MULTI_STREAMS = 2          # N > 1: streams per rank (a block's collective overlaps the next block's march)

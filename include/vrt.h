@@ -446,6 +446,13 @@ long long vrt_debug_wave_records(vrt_ctx* ctx, int which, uint32_t* out, long lo
                                   VRT_FLAG_REFERENCE_VIEW_VECTOR / _BOUNDARY_TEXELS */
 int vrt_debug_last_kernel_form(vrt_ctx* ctx);
 
+/* Diagnostics: the rate (G trilinear samples per second) the chip sustains for the march's inner operation in isolation — the 8 taps of a
+ * sample from a pool of n_bricks (a power of two) brick records of `format` plus the lerp tree, at full occupancy, every lane on an
+ * independent pseudo-random sequence of cells (coherent_lanes = 0) or the 64 lanes of a wave on the 3x3 cells an 8x8-pixel tile covers
+ * (1).  32 bricks stay in L1, 4096 in L2, 262144 are the pool of a 256^3 volume.  The roof bench.py's roofline.limiter_frac is measured
+ * against, taken on the box and build of the run itself.  About 10 ms per call; synchronous; not for use while frames are in flight. */
+int vrt_debug_gather_ceiling(vrt_ctx* ctx, int format, int coherent_lanes, unsigned n_bricks, float* gsamples_per_s_out);
+
 const char* vrt_strerror(int status);
 /* "x.y.z gfx950" */
 const char* vrt_version(void);

@@ -125,6 +125,9 @@ if c.get("GRBM_GUI_ACTIVE"):
     if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
         res["l1_cache_line_accesses_per_cu_cycle"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0 / cyc, 3)
         lines.append(f"== L1 (TCP): {res['l1_cache_line_accesses_per_cu_cycle']} cache-line accesses per CU and cycle; {c.get('TCP_TCC_READ_REQ_sum', 0) / max(c['TCP_TOTAL_CACHE_ACCESSES_sum'], 1):.3f} of them go on to L2 ==")
+    if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") and c.get("SQ_INSTS_VMEM_RD"):
+        res["lines_per_vmem_instr"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["SQ_INSTS_VMEM_RD"], 2)
+        lines.append(f"== cache lines per wave-level vector-memory read instruction: {res['lines_per_vmem_instr']} (TCP_TOTAL_CACHE_ACCESSES_sum / SQ_INSTS_VMEM_RD; ~4 if the 64 lanes of a load read one brick) ==")
     if c.get("SQ_INSTS_VALU"):
         res["valu_issue_frac_in_sq_pass"] = round(c["SQ_INSTS_VALU"] * 2.0 / 1024.0 / cyc, 4)
         lines.append(f"== vector-instruction issue: {c['SQ_INSTS_VALU']:.0f} wave-instructions x 2 cycles / 1024 SIMDs / {cyc:.0f} cycles = {res['valu_issue_frac_in_sq_pass']} (in the SQ pass itself) ==")

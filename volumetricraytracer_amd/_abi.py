@@ -213,6 +213,7 @@ SYMBOLS = {
     "vrt_launch_history": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "vrt_debug_wave_records": (C.c_longlong, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]),
     "vrt_debug_last_kernel_form": (C.c_int, [C.c_void_p]),
+    "vrt_debug_gather_ceiling": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_float)]),
     "vrt_strerror": (C.c_char_p, [C.c_int]),
     "vrt_version": (C.c_char_p, []),
 }

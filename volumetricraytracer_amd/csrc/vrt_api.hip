@@ -1957,6 +1957,38 @@ int vrt_launch_history(vrt_ctx* ctx, int n, float* kernel_ms_out, int* frames_ou
     return m;
 }
 
+int vrt_debug_gather_ceiling(vrt_ctx* ctx, int format, int coherent_lanes, unsigned n_bricks, float* gsamples_per_s_out) {
+    if (!ctx || ctx->dev.empty() || !gsamples_per_s_out || (format != VRT_FORMAT_F32 && format != VRT_FORMAT_TEXEL16)) return VRT_ERR_INVALID;
+    if (n_bricks < 1 || n_bricks > (1u << 22) || (n_bricks & (n_bricks - 1)) != 0) return VRT_ERR_INVALID;
+    DeviceState& D = ctx->dev[0];
+    HIP_TRY(hipSetDevice(D.ordinal));
+    const int blocks = 256 * 8 * 4, iters = 256; /* 8192 workgroups of 4 waves: every CU at its occupancy limit */
+    const size_t pool_bytes = (size_t)n_bricks * (format == VRT_FORMAT_TEXEL16 ? 256 : 512);
+    void* pool = nullptr;
+    float* out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = VRT_OK;
+    float best = 1e30f;
+    do {
+        if (hipMalloc(&pool, pool_bytes) != hipSuccess || hipMalloc(&out, sizeof(float) * (size_t)blocks * 256) != hipSuccess) { rc = VRT_ERR_OOM; break; }
+        if (hipMemset(pool, 0, pool_bytes) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = VRT_ERR_HIP; break; }
+        for (int rep = 0; rep < 5 && rc == VRT_OK; rep++) { /* the first repetition warms the caches and the clocks */
+            float ms = 0.f;
+            if (hipEventRecord(e0, nullptr) != hipSuccess || launch_gather_ceiling(pool, n_bricks, format, coherent_lanes != 0, iters, out, blocks, nullptr) != hipSuccess ||
+                hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                rc = VRT_ERR_HIP;
+            else if (rep > 0 && ms < best) best = ms;
+        }
+    } while (false);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (pool) (void)hipFree(pool);
+    if (out) (void)hipFree(out);
+    if (rc != VRT_OK) return rc;
+    *gsamples_per_s_out = (float)((double)blocks * 256.0 * iters / ((double)best * 1e6));
+    return VRT_OK;
+}
+
 int vrt_debug_last_kernel_form(vrt_ctx* ctx) {
     if (!ctx || ctx->dev.empty()) return VRT_ERR_INVALID;
     return ctx->dev[0].last_form;

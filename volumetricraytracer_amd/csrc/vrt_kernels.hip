@@ -2428,7 +2428,50 @@ __global__ void split_voxels_kernel(const uint2* __restrict__ voxels, float* __r
     }
 }
 
+/* ---- the march's inner operation in isolation (vrt_debug_gather_ceiling) -------------------------------------
+ * The 8 taps of a trilinear sample from a brick pool (fetch8_at: 4 x dwordx2 of fp32 bricks, or 4 x dword of int16 bricks) + the lerp tree
+ * (lerp8), every lane on its own pseudo-random INDEPENDENT sequence of cells (no dependence on the loaded values), at full occupancy: the
+ * rate the texture path (TA / L1 / L2 / HBM) sustains for this access pattern — the roof the march kernel's busy phase is under, measured on
+ * the very box and build a bench runs on (bench.py roofline.limiter_ceiling_*).  COHERENT: the 64 lanes of a wave on the 3x3 cells an
+ * 8x8-pixel tile covers (one wave-uniform base cell per iteration; lanes that share a cell share its lines) instead of a cell each.
+ * (tools/microbench/gather.hip is the same measurement as a stand-alone program.) */
+template <int DP, bool COHERENT>
+__global__ __launch_bounds__(256) void gather_ceiling_kernel(const char* __restrict__ pool, unsigned nbricks_mask, int iters, float* __restrict__ out) {
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned state = (COHERENT ? (gid >> 6) : gid) * 2654435761u + 12345u;
+    unsigned brick = (gid >> 6) * 97u;
+    const unsigned ox = ((lane & 7u) * 3u) >> 3, oz = ((lane >> 3) * 3u) >> 3;
+    VolRef V = {};
+    V.p = (gchar_p)pool;
+    float acc = 0.0f;
+    for (int i = 0; i < iters; i++) {
+        state = state * 1664525u + 1013904223u;
+        const unsigned bx = (state >> 8) & 3u, ly = (state >> 12) & 3u, bz = (state >> 16) & 3u;
+        if (((state >> 20) & 7u) == 0u) brick += 1u + ((state >> 24) & 3u); /* change brick every ~8 samples */
+        const unsigned cx = COHERENT ? bx + ox : bx, cz = COHERENT ? bz + oz : bz;
+        const unsigned b = (brick + (cx >> 2) * 17u + (cz >> 2) * 5u) & nbricks_mask; /* a neighbouring brick past the edge */
+        const Taps t = fetch8_at<DP>(V, b, (int)(cx & 3u), (int)ly, (int)(cz & 3u));
+        acc += lerp8(t, 0.3f, 0.6f, 0.2f);
+    }
+    out[gid] = acc;
+}
+
 /* ---- launch wrappers (host) -------------------------------------------------------------- */
+
+hipError_t launch_gather_ceiling(const void* pool, unsigned n_bricks, int format, bool coherent, int iters, float* out, int blocks, hipStream_t stream) {
+    const dim3 g((unsigned)blocks), t(256);
+    const char* p = static_cast<const char*>(pool);
+    if (format == VRT_FORMAT_TEXEL16) {
+        if (coherent) hipLaunchKernelGGL((gather_ceiling_kernel<kPathBrick16, true>), g, t, 0, stream, p, n_bricks - 1, iters, out);
+        else hipLaunchKernelGGL((gather_ceiling_kernel<kPathBrick16, false>), g, t, 0, stream, p, n_bricks - 1, iters, out);
+    } else {
+        if (coherent) hipLaunchKernelGGL((gather_ceiling_kernel<VRT_PATH_BRICK, true>), g, t, 0, stream, p, n_bricks - 1, iters, out);
+        else hipLaunchKernelGGL((gather_ceiling_kernel<VRT_PATH_BRICK, false>), g, t, 0, stream, p, n_bricks - 1, iters, out);
+    }
+    return hipGetLastError();
+}
+
 
 /* The lean kernel's REF instantiation is the one that reads DFrame::textured (constant textures only: anything else makes the launch
    a full closest hit), view_vec and zero_outside. */

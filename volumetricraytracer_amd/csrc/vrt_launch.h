@@ -33,6 +33,9 @@ hipError_t launch_cube_table(const float* dense, uint8_t* table, uint8_t* scratc
 /* Device Voxelizer: frames = n_frames vrt_vox::TriangleFrame records (device memory); writes N^3 densities + materials. */
 hipError_t launch_voxelize(const void* frames, size_t n_frames, float* density, uint8_t* material, int N, float cell, float extent,
                            float threshold, hipStream_t stream);
+/* vrt_debug_gather_ceiling: `blocks` workgroups of 256 lanes, `iters` trilinear samples per lane from a pool of n_bricks (a power of two)
+   brick records of `format`; out: blocks * 256 floats. */
+hipError_t launch_gather_ceiling(const void* pool, unsigned n_bricks, int format, bool coherent, int iters, float* out, int blocks, hipStream_t stream);
 hipError_t launch_split_voxels(const void* voxels, float* density, uint8_t* material, size_t count,
                                hipStream_t stream);
 

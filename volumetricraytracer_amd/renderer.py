@@ -367,6 +367,13 @@ class VHipRenderer:
             _abi.check(m, "vrt_launch_history")
         return [(ms[i], fr[i]) for i in range(m)]
 
+    def gather_ceiling(self, fmt: int = _abi.FORMAT_F32, coherent_lanes: bool = False, n_bricks: int = 32) -> float:
+        """G trilinear samples per second the chip sustains for the march's inner operation in isolation (vrt_debug_gather_ceiling)."""
+        self._require()
+        out = C.c_float()
+        _abi.check(self._lib.vrt_debug_gather_ceiling(self._ctx, int(fmt), 1 if coherent_lanes else 0, int(n_bricks), C.byref(out)), "vrt_debug_gather_ceiling")
+        return float(out.value)
+
     def last_kernel_form(self) -> int:
         """Bit set of _abi.FORM_* naming the closest-hit kernel form the last march launch ran (vrt_debug_last_kernel_form)."""
         self._require()
