@@ -267,6 +267,11 @@ class Pipeline:
         self.copy_stream = torch.cuda.Stream(device=dev) if self.unshuffle else None
         self.unshuffled = [None] * K
         self.blocks = 0
+        if self.native:
+            # the byte counts this pipeline's collectives are going to carry, agreed on by all ranks up front (a rank with another block size
+            # would otherwise hang the first collective inside RCCL)
+            tb = self.fg.tiles[0].numel() * self.fg.tiles[0].element_size()
+            r.comm_expect_sizes(0 if self.fg.rotate else tb, tb // world if self.fg.rotate else 0)
         self.xchg_events = []  # native exchange only: (before, after) timing events around every block's collective on its march stream
         self.last = (0, 0)  # (buffer, frame within the block) of the last frame issued
         # the batch's cameras, twice over (a block may wrap around the end of the batch): frame i uses camera i % n_cameras

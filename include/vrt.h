@@ -348,7 +348,9 @@ typedef struct vrt_camera {
  * DXRenderer.cpp:809-825, RDXScene.cpp:454-545) — still with ONE march launch for the block: per frame the host packs the
  * instances, builds the instance BVH and the cull rectangle, and the records travel to the device ahead of the launch on its
  * stream (<= 12 KB per frame).  cameras must then be NULL (every scene carries its camera); the scene set by vrt_scene_set is
- * neither used nor changed.  Volumes, materials, textures and the sky box are the resident ones, the same for every frame. */
+ * neither used nor changed.  Volumes, materials, textures and the sky box are the resident ones, the same for every frame.
+ * A block with scenes != NULL cannot be captured into a hipGraph (VRT_ERR_INVALID on a capturing stream): its per-frame records are
+ * staged in pinned memory and copied ahead of the launch, and a replay would copy whatever they hold by then. */
 typedef struct vrt_block {
     int32_t n_frames;                 /* 1 .. 256 */
     int32_t strip_rows, first_strip, strip_stride, n_strips;
@@ -393,6 +395,8 @@ int vrt_render_block_host(vrt_ctx* ctx, const vrt_params* params, const vrt_bloc
  *   vrt_gather_tiles     asynchronously on hip_stream: every rank contributes tile_bytes from device_tile; on `root`,
  *                        device_frame receives world x tile_bytes, rank-major (other ranks pass NULL).  In-order with the
  *                        march launches of the same stream: no host synchronisation
+ *   vrt_comm_expect_sizes  the ranks agree on the byte counts of the two calls below once, so that a wrong block size on one rank is an error
+ *                        code instead of a hang inside RCCL
  *   vrt_exchange_tiles   the all-to-all form of the same exchange, for frames that are assembled on DIFFERENT ranks (frame g of a
  *                        block on rank g / m): device_tiles holds world chunks of chunk_bytes, chunk d goes to rank d;
  *                        device_recv receives world chunks, chunk s from rank s.  One group of ncclSend / ncclRecv
@@ -404,6 +408,12 @@ int vrt_render_block_host(vrt_ctx* ctx, const vrt_params* params, const vrt_bloc
 int vrt_comm_unique_id(void* id_out);
 int vrt_comm_init(vrt_ctx* ctx, int world, int rank, const void* id);
 int vrt_comm_destroy(vrt_ctx* ctx);
+/* Collective, synchronous: the ranks agree on the sizes they are going to pass to vrt_gather_tiles (tile_bytes) and vrt_exchange_tiles
+ * (chunk_bytes) — a collective whose ranks disagree about its size does not fail inside RCCL, it waits for ever.  Every rank's pair travels
+ * to every rank in one group of fixed-size messages; a disagreement returns VRT_ERR_INVALID on every rank.  Afterwards a call with any
+ * other size is refused with VRT_ERR_INVALID before it reaches RCCL (0: that collective is not going to be used).  Optional (without it the
+ * sizes are unchecked, as before); call again to change the sizes. */
+int vrt_comm_expect_sizes(vrt_ctx* ctx, size_t gather_tile_bytes, size_t exchange_chunk_bytes);
 int vrt_gather_tiles(vrt_ctx* ctx, const void* device_tile, void* device_frame_or_null, size_t tile_bytes, int root, void* hip_stream);
 int vrt_exchange_tiles(vrt_ctx* ctx, const void* device_tiles, void* device_recv, size_t chunk_bytes, void* hip_stream);
 

@@ -1198,6 +1198,22 @@ def test_native_tile_gather_with_one_rank(oracle_lib):
             r.exchange_tiles(block.data_ptr(), recv.data_ptr(), block.numel(), stream.cuda_stream)
         torch.cuda.synchronize()
         assert torch.equal(recv, block) and torch.equal(recv[2], frame)
+        # vrt_comm_expect_sizes (round 5): once the ranks have agreed on the byte counts, any other count is an error code BEFORE RCCL is
+        # entered (a size mismatch between ranks would otherwise wait for ever)
+        r.comm_expect_sizes(tile.numel(), block.numel())
+        with torch.cuda.stream(stream):
+            r.gather_tiles(tile.data_ptr(), frame.data_ptr(), tile.numel(), 0, stream.cuda_stream)
+            r.exchange_tiles(block.data_ptr(), recv.data_ptr(), block.numel(), stream.cuda_stream)
+            with pytest.raises(RuntimeError, match="vrt_gather_tiles"):
+                r.gather_tiles(tile.data_ptr(), frame.data_ptr(), tile.numel() // 2, 0, stream.cuda_stream)
+            with pytest.raises(RuntimeError, match="vrt_exchange_tiles"):
+                r.exchange_tiles(block.data_ptr(), recv.data_ptr(), block.numel() - 4, stream.cuda_stream)
+        torch.cuda.synchronize()
+        r.comm_expect_sizes(0, block.numel())  # the gather is declared unused: refused; the exchange still runs
+        with pytest.raises(RuntimeError, match="vrt_gather_tiles"):
+            r.gather_tiles(tile.data_ptr(), frame.data_ptr(), tile.numel(), 0, stream.cuda_stream)
+        r.exchange_tiles(block.data_ptr(), recv.data_ptr(), block.numel(), stream.cuda_stream)
+        torch.cuda.synchronize()
     finally:
         r.Stop()
 

@@ -204,6 +204,7 @@ SYMBOLS = {
     "vrt_comm_unique_id": (C.c_int, [C.c_void_p]),
     "vrt_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vrt_comm_destroy": (C.c_int, [C.c_void_p]),
+    "vrt_comm_expect_sizes": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t]),
     "vrt_gather_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "vrt_exchange_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vrt_render_begin": (C.c_int, [C.c_void_p, C.POINTER(vrt_params), C.c_int]),

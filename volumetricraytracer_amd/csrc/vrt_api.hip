@@ -85,6 +85,10 @@ RcclApi* rccl() {
     return api.ok ? &api : nullptr;
 }
 
+/* the per-frame scene sections (vrt_device.h, DDyn) hold what the C-ABI's limits allow */
+static_assert(kDynMaxInstances == VRT_MAX_INSTANCES && kMaxBvhNodes == 2 * VRT_MAX_INSTANCES - 1, "section capacity = VRT_MAX_INSTANCES");
+static_assert(kDynMaxPointLights == VRT_MAX_POINT_LIGHTS && kDynMaxSpotLights == VRT_MAX_SPOT_LIGHTS, "section capacity = VRT_MAX_*_LIGHTS");
+
 constexpr int kStatSlots = 16; /* streams that may have launches in flight at once without sharing a counter buffer */
 constexpr int kRing = 256; /* per-launch event pairs + stat slots kept for vrt_timing_history */
 
@@ -233,6 +237,8 @@ struct vrt_ctx {
     size_t gather_bytes = 0;
     void* comm = nullptr;    /* ncclComm_t of vrt_comm_init (one process per GPU) */
     int comm_world = 0, comm_rank = 0;
+    bool sizes_agreed = false;
+    size_t expect_tile_bytes = 0, expect_chunk_bytes = 0; /* vrt_comm_expect_sizes: what every rank agreed to pass (0: not agreed, unchecked) */
 };
 
 namespace {
@@ -1565,6 +1571,10 @@ int vrt_render_block_host(vrt_ctx* ctx, const vrt_params* params, const vrt_bloc
     const size_t frame_bytes = (size_t)rows * (size_t)params->width * ((params->flags & VRT_FLAG_OUTPUT_RGBA8) ? 4 : 16);
     const size_t need = std::max<size_t>(frame_bytes * (size_t)block->n_frames, 16);
     if (need > ((size_t)4 << 30)) return VRT_ERR_INVALID;
+    { /* refuse bad parameters BEFORE the block buffers are touched */
+        const int rc = check_params(ctx, params, block->scenes != nullptr);
+        if (rc != VRT_OK) return rc;
+    }
     DeviceState& D = ctx->dev[0];
     HIP_TRY(hipSetDevice(D.ordinal));
     if (D.blockfb_bytes < need) {
@@ -1760,7 +1770,53 @@ int vrt_comm_init(vrt_ctx* ctx, int world, int rank, const void* id) {
     ctx->comm = comm;
     ctx->comm_world = world;
     ctx->comm_rank = rank;
+    ctx->expect_tile_bytes = ctx->expect_chunk_bytes = 0;
+    ctx->sizes_agreed = false;
     return VRT_OK;
+}
+
+/* A collective whose ranks disagree about its size does not fail inside RCCL: it waits for ever.  This call (collective, synchronous, a
+   setup call) makes the sizes part of the communicator: every rank sends its pair to every rank in one group of 16-byte messages — whose
+   size cannot disagree — and compares; afterwards vrt_gather_tiles / vrt_exchange_tiles refuse any other size with VRT_ERR_INVALID before
+   they touch RCCL.  0 = that collective is not going to be used (then a call to it is refused).  Call again to change the sizes. */
+int vrt_comm_expect_sizes(vrt_ctx* ctx, size_t gather_tile_bytes, size_t exchange_chunk_bytes) {
+    if (!ctx || !ctx->comm) return VRT_ERR_NOT_READY;
+    RcclApi* R = rccl();
+    if (!R) return VRT_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->dev[0].ordinal));
+    const int W = ctx->comm_world;
+    struct Pair { unsigned long long tile, chunk; };
+    std::vector<Pair> mine((size_t)W, Pair{(unsigned long long)gather_tile_bytes, (unsigned long long)exchange_chunk_bytes}), theirs((size_t)W);
+    Pair* d_send = nullptr;
+    Pair* d_recv = nullptr;
+    hipStream_t st = nullptr;
+    int status = VRT_OK;
+    do {
+        if (hipMalloc(&d_send, sizeof(Pair) * (size_t)W) != hipSuccess || hipMalloc(&d_recv, sizeof(Pair) * (size_t)W) != hipSuccess) { status = VRT_ERR_OOM; break; }
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+            hipMemcpyAsync(d_send, mine.data(), sizeof(Pair) * (size_t)W, hipMemcpyHostToDevice, st) != hipSuccess) { status = VRT_ERR_HIP; break; }
+        int rc = R->GroupStart();
+        for (int peer = 0; rc == 0 && peer < W; peer++) {
+            rc = R->Send(d_send + peer, sizeof(Pair), kNcclUint8, peer, ctx->comm, st);
+            if (rc == 0) rc = R->Recv(d_recv + peer, sizeof(Pair), kNcclUint8, peer, ctx->comm, st);
+        }
+        const int rc_end = R->GroupEnd();
+        if (rc != 0 || rc_end != 0) { status = VRT_ERR_HIP; break; }
+        if (hipMemcpyAsync(theirs.data(), d_recv, sizeof(Pair) * (size_t)W, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { status = VRT_ERR_HIP; break; }
+        for (int peer = 0; peer < W; peer++)
+            if (theirs[(size_t)peer].tile != mine[0].tile || theirs[(size_t)peer].chunk != mine[0].chunk) {
+                fprintf(stderr, "[vrt] vrt_comm_expect_sizes: rank %d expects tile %llu / chunk %llu bytes, rank %d expects %llu / %llu\n", ctx->comm_rank,
+                        mine[0].tile, mine[0].chunk, peer, theirs[(size_t)peer].tile, theirs[(size_t)peer].chunk);
+                status = VRT_ERR_INVALID; /* every rank sees the same disagreement and returns the same status */
+            }
+    } while (false);
+    if (st) (void)hipStreamDestroy(st);
+    if (d_send) (void)hipFree(d_send);
+    if (d_recv) (void)hipFree(d_recv);
+    ctx->expect_tile_bytes = status == VRT_OK ? gather_tile_bytes : 0;
+    ctx->expect_chunk_bytes = status == VRT_OK ? exchange_chunk_bytes : 0;
+    ctx->sizes_agreed = status == VRT_OK;
+    return status;
 }
 
 int vrt_comm_destroy(vrt_ctx* ctx) {
@@ -1781,6 +1837,7 @@ int vrt_gather_tiles(vrt_ctx* ctx, const void* device_tile, void* device_frame_o
     if (root < 0 || root >= ctx->comm_world || (!device_tile && tile_bytes > 0) ||
         (ctx->comm_rank == root && !device_frame_or_null && tile_bytes > 0))
         return VRT_ERR_INVALID;
+    if (ctx->sizes_agreed && tile_bytes != ctx->expect_tile_bytes) return VRT_ERR_INVALID; /* not the size the ranks agreed on: it would wait for ever */
     RcclApi* R = rccl();
     if (!R) return VRT_ERR_UNSUPPORTED;
     HIP_TRY(hipSetDevice(ctx->dev[0].ordinal));
@@ -1795,6 +1852,7 @@ int vrt_gather_tiles(vrt_ctx* ctx, const void* device_tile, void* device_frame_o
 int vrt_exchange_tiles(vrt_ctx* ctx, const void* device_tiles, void* device_recv, size_t chunk_bytes, void* hip_stream) {
     if (!ctx || !ctx->comm) return VRT_ERR_NOT_READY;
     if ((!device_tiles || !device_recv) && chunk_bytes > 0) return VRT_ERR_INVALID;
+    if (ctx->sizes_agreed && chunk_bytes != ctx->expect_chunk_bytes) return VRT_ERR_INVALID; /* not the size the ranks agreed on */
     RcclApi* R = rccl();
     if (!R) return VRT_ERR_UNSUPPORTED;
     HIP_TRY(hipSetDevice(ctx->dev[0].ordinal));

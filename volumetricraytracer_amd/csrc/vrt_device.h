@@ -223,11 +223,17 @@ struct DDyn {                  /* 64 bytes: one s_load_dwordx16 */
     int32_t vol0_slot;         /* single-instance launches: the frame's one instance's volume slot */
     int32_t pad_[7];
 };
+/* capacities of a section (vrt.h is not visible here; vrt_api.hip static_asserts them against VRT_MAX_INSTANCES / VRT_MAX_*_LIGHTS) */
+constexpr int kDynMaxInstances = 64;
+constexpr int kDynMaxNodes = 128;          /* >= kMaxBvhNodes */
+constexpr int kDynMaxPointLights = 5;
+constexpr int kDynMaxSpotLights = 5;
+static_assert(kDynMaxNodes >= kMaxBvhNodes, "a frame's BVH fits its section");
 constexpr uint32_t kDynInstOff = sizeof(DDyn);
-constexpr uint32_t kDynNodesOff = kDynInstOff + 64 /* VRT_MAX_INSTANCES */ * sizeof(DInstance);
-constexpr uint32_t kDynPointOff = kDynNodesOff + 128 * sizeof(DBvhNode);
-constexpr uint32_t kDynSpotOff = kDynPointOff + 5 /* VRT_MAX_POINT_LIGHTS */ * sizeof(DPointLight);
-constexpr uint32_t kDynStride = (kDynSpotOff + 5 /* VRT_MAX_SPOT_LIGHTS */ * sizeof(DSpotLight) + 63u) & ~63u;
+constexpr uint32_t kDynNodesOff = kDynInstOff + kDynMaxInstances * sizeof(DInstance);
+constexpr uint32_t kDynPointOff = kDynNodesOff + kDynMaxNodes * sizeof(DBvhNode);
+constexpr uint32_t kDynSpotOff = kDynPointOff + kDynMaxPointLights * sizeof(DPointLight);
+constexpr uint32_t kDynStride = (kDynSpotOff + kDynMaxSpotLights * sizeof(DSpotLight) + 63u) & ~63u;
 static_assert(sizeof(DDyn) == 64 && kDynStride % 64 == 0, "frame sections stay 64-byte aligned");
 
 /* The kernarg of a march launch: the shared part and one DCam per frame of the block.  The dispatcher walks blockIdx.x

@@ -330,6 +330,12 @@ class VHipRenderer:
         buf = (C.c_uint8 * _abi.VRT_COMM_ID_BYTES).from_buffer_copy(unique_id)
         _abi.check(self._lib.vrt_comm_init(self._ctx, int(world), int(rank), buf), "vrt_comm_init")
 
+    def comm_expect_sizes(self, gather_tile_bytes: int, exchange_chunk_bytes: int) -> None:
+        """Every rank (collective, synchronous): agree on the byte counts gather_tiles / exchange_tiles are going to be called with;
+        a rank that disagrees makes the call fail on every rank instead of hanging the collective later."""
+        self._require()
+        _abi.check(self._lib.vrt_comm_expect_sizes(self._ctx, int(gather_tile_bytes), int(exchange_chunk_bytes)), "vrt_comm_expect_sizes")
+
     def gather_tiles(self, tile_ptr: int, frame_ptr: int, tile_bytes: int, root: int = 0, stream: int = 0) -> None:
         """Asynchronous ncclGather of this rank's device tile into rank `root`'s device frame (rank-major)."""
         self._require()
