@@ -79,7 +79,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3sdf", "c3light", "c3cover", "c4", "c5"],
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3sdf", "c3light", "c3cover", "c3dropin", "c4", "c5"],
                     help="c3 = BASELINE config 3 (the metric); c3light = the same with one point light: the full closest-hit kernel "
                          "(the reference's default render mode once a scene has a point light)")
     ap.add_argument("--path", default="auto", choices=["auto", "dense", "brick", "lds", "cells"])
@@ -163,6 +163,21 @@ def build_workload(name: str):
         sc = copy.copy(workloads.bench_config3())
         sc.PointLights = [v.VPointLight(Position=(120.0, 60.0, 140.0), Color=(1.0, 0.9, 0.8, 1.0), IlluminationStrength=40.0)]
         return sc, 1920, 1080, 255, True, "config3 + one point light: 256^3 voxelized mesh, 1920x1080, directional + point light with their shadow rays (full closest-hit kernel)"
+    if name == "c3dropin":
+        # config 3 as a drop-in user of the C++ adaptor gets it: the reference's 1x1 default normal texel on the material (mode Interp, the
+        # reference's 16-bit volume texel, B8G8R8A8 frames and the two reference-artefact flags are set in main()) — the `drop_in_defaults`
+        # leg as a workload of its own, for the profiler
+        import copy
+
+        base = workloads.bench_config3()
+        sc = copy.copy(base)
+        vol = copy.copy(base.volumes()[0])
+        vol.Material = copy.copy(vol.Material)
+        vol.Material.NormalTexture = workloads.reference_default_normal_texel()
+        sc.Objects = [copy.copy(o) for o in base.Objects]
+        sc.Objects[0].Volume = vol
+        return sc, 1920, 1080, 255, True, ("config3 with the C++ adaptor's defaults: mode Interp, reference 16-bit volume texel, the reference's 1x1 default normal texel, "
+                                          "B8G8R8A8 frames, VRT_FLAG_REFERENCE_VIEW_VECTOR | _BOUNDARY_TEXELS (the lean kernel's REF instantiation)")
     if name == "c3cover":
         # config 3's volume with the camera INSIDE its box, 0.6 extents from the centre: every wave marches (the `full_coverage` leg as a workload
         # of its own, for the profiler)
@@ -505,7 +520,8 @@ def main() -> None:
         label += f" -- weak-scaled to {W}x{H} for {world} GPUs"
     elif world > 1:
         label += f" -- the same {W}x{H} frame split over {world} GPUs (strong scaling)"
-    rgba8 = args.output == "rgba8" or (args.output == "auto" and world > 1)
+    dropin = args.workload == "c3dropin"
+    rgba8 = args.output == "rgba8" or (args.output == "auto" and world > 1) or dropin
     strip_rows = args.strip_rows if world > 1 else 0
     rotate = world > 1 and args.exchange == "rotate"
     exchange_fallback = None
@@ -532,7 +548,7 @@ def main() -> None:
     # next block's march.  (No dependence on how HIP maps streams to hardware queues any more: profiles/r03_fused_launch_sweep.txt.)
     K = args.frames_in_flight or (1 if world == 1 else MULTI_STREAMS)
     path = {"auto": _abi.PATH_AUTO, "dense": _abi.PATH_DENSE, "brick": _abi.PATH_BRICK, "lds": _abi.PATH_BRICK_LDS, "cells": _abi.PATH_CELLS}[args.path]
-    fmt = {"auto": workloads.BENCH_VOLUME_FORMAT, "f32": _abi.FORMAT_F32, "texel16": _abi.FORMAT_TEXEL16}[args.format]
+    fmt = {"auto": _abi.FORMAT_TEXEL16 if dropin else workloads.BENCH_VOLUME_FORMAT, "f32": _abi.FORMAT_F32, "texel16": _abi.FORMAT_TEXEL16}[args.format]
     for vol in sc.volumes():
         vol.set_device_format(fmt)
 
@@ -547,6 +563,9 @@ def main() -> None:
         if args.no_hit_polish:
             q.flags |= _abi.FLAG_NO_HIT_POLISH
         q.flags |= {"supertile": 0, "band": 1, "linear": 2}[args.tile_map]
+        if dropin:  # VHipRenderer's defaults (csrc/host/HipRenderer.h)
+            q.mode, q.max_bounces = _abi.MODE_INTERP, 2
+            q.flags |= _abi.FLAG_OUTPUT_BGRA8 | _abi.FLAG_REFERENCE_VIEW_VECTOR | _abi.FLAG_REFERENCE_BOUNDARY_TEXELS
         return q
 
     p = params(W, H)

@@ -10,7 +10,7 @@
  *   vrt_demo [--frames N] [--size WxH] [--scene file.vox] [--out frame.ppm] [--mode 0..7 (EVRenderMode)] [--in-flight 1..3] [--skybox dir-with-XP..ZM.png | cube.dds]
  *            [--format bgra8|rgba8|float]   frame format handed to the host; default bgra8, the reference's back buffer (DXConstants.cpp:21)
  *            [--volumes texel16|f32]        device format of the volumes; default texel16, the reference's own 16-bit volume texel
- *            [--identity-defaults]          unbound material slots are exact identities instead of the reference's 1x1 default texels (its normal texel tilts by 0.3 degrees)
+ *            [--identity-defaults]          none of the reference's artefacts: unbound material slots are exact identities instead of its 1x1 default texels (its normal texel tilts by 0.3 degrees), unit view vector, clamped normal taps
  *            [--block N]                    N frames of the animation per RenderBlock call (ONE march launch per N frames) instead of one Render() per frame
  */
 #include <chrono>
@@ -125,7 +125,7 @@ int main(int argc, char** argv) {
     if (hip && inFlight >= 1 && inFlight <= 3) hip->FramesInFlight = inFlight;
     if (hip) hip->FrameFormat = format == "float" ? Fmt::Float4 : (format == "rgba8" ? Fmt::RGBA8 : Fmt::BGRA8);
     if (hip) hip->VolumeFormat = volumes == "f32" ? VRT_FORMAT_F32 : VRT_FORMAT_TEXEL16;
-    if (hip) hip->ReferenceDefaultTextures = !identityDefaults;
+    if (hip) hip->ReferenceDefaultTextures = hip->ReferenceViewVector = hip->ReferenceBoundaryTexels = !identityDefaults;
     double kernel_ms = 0.0;
     auto tick = [&](int f) {                                                     /* TickEngineInstance */
         const float dt = 1.f / 60.f, angle = (float)f * dt * 0.5f;

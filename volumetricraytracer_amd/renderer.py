@@ -31,6 +31,10 @@ class VHipRenderer:
         self.Shadows = True
         self.MaxSteps = 255  # Raytracing.hlsl:229
         self.MaxBounces = 2  # MAX_RAY_RECURSION_DEPTH 3 = primary + 2 mirror bounces (RaytracingHlsl.h:32)
+        # the reference's artefacts the C++ adaptor reproduces by default (VHipRenderer::ReferenceViewVector / ReferenceBoundaryTexels); this
+        # mirror, like the C-ABI, leaves them off unless asked
+        self.ReferenceViewVector = False
+        self.ReferenceBoundaryTexels = False
         self._env_id = None
         self._tex_ids: Dict[int, int] = {}   # id(image array) -> texture id on the device
         self._tex_keep: Dict[int, np.ndarray] = {}  # keeps the keyed arrays alive so id() stays unique
@@ -212,6 +216,10 @@ class VHipRenderer:
             res = max((v.Resolution for v in self._scene.volumes()), default=0) if self._scene else 0
             p = default_params(self.Width, self.Height, cell, max_steps=march_budget(res, self.MaxSteps), shadow=self.Shadows)
             p.max_bounces = self.MaxBounces
+            if self.ReferenceViewVector:
+                p.flags |= _abi.FLAG_REFERENCE_VIEW_VECTOR
+            if self.ReferenceBoundaryTexels:
+                p.flags |= _abi.FLAG_REFERENCE_BOUNDARY_TEXELS
         p.width, p.height = self.Width, self.Height
         p.mode = self.RenderMode
         if self.params_override is None:
