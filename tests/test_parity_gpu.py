@@ -1808,6 +1808,41 @@ def test_random_scenes_parity(oracle_lib, seed):
     assert {k: t[k] for k in keys} == {k: st[k] for k in keys}, f"seed {seed}"
 
 
+@pytest.mark.parametrize("seed", range(200, 248))
+def test_random_scenes_parity_with_the_reference_switches(oracle_lib, seed):
+    """The fuzz scenes again (other seeds) with what the C++ adaptor switches on by default: both reference-artefact flags, and the material
+    slots a seed leaves unbound filled with 1x1 CONSTANT textures (the reference's default normal texel; for every third seed a constant
+    albedo / RM texel too) next to whatever images the seed bound — constants and images mix in one material, the lean kernel's REF
+    instantiation, the BVH form, the Cube modes, the passes and the full kernel all see the switches.  GPU = oracle <= 1e-4, counters exact."""
+    sc, p = scenes.random_scene(seed)
+    for k, vol in enumerate(sc.volumes()):
+        m = vol.Material
+        if m.NormalTexture is None:
+            m.NormalTexture = scenes.reference_default_normal_texel()
+        if (seed + k) % 3 == 0:
+            if m.AlbedoTexture is None:
+                m.AlbedoTexture = np.array([[[250 - 9 * k, 200, 120 + 7 * k, 255]]], np.uint8)
+            if m.RMTexture is None:
+                m.RMTexture = np.array([[[255 - 40 * (seed % 5), 128, 0, 255]]], np.uint8)
+    p.flags |= REF_FLAGS
+    r = v.VHipRenderer()
+    assert r.Start()
+    try:
+        img, t = gpu_render(r, sc, p)
+        p3 = _abi.vrt_params.from_buffer_copy(p)
+        p3.flags |= _abi.FLAG_FULL_THREE_PASS
+        img3, t3 = gpu_render(r, sc, p3)
+    finally:
+        r.Stop()
+    assert np.array_equal(img, img3) and {k: t[k] for k in STAT_KEYS} == {k: t3[k] for k in STAT_KEYS}, f"seed {seed}"
+    ref, st = OracleScene(sc).render(p, threads=8)
+    assert not np.isnan(img).any()
+    err = np.abs(img - ref)
+    assert err.max() <= TOL, f"seed {seed}: max abs err {err.max()} at {np.unravel_index(err.argmax(), err.shape)} mode {p.mode}"
+    keys = STAT_KEYS if len(sc.Objects) == 1 else ("primary_rays", "shadow_rays", "bounce_rays", "hits")
+    assert {k: t[k] for k in keys} == {k: st[k] for k in keys}, f"seed {seed}"
+
+
 @pytest.mark.parametrize("seed", [5018, 8081, 13831, 14789])
 def test_specular_highlight_pixels_found_by_the_soak(oracle_lib, seed):
     """Four scenes of tests/soak_random_scenes.py (26 000 seeds) in which ONE pixel was 1.4e-4 ... 4e-4 off: a dark channel of
