@@ -1146,8 +1146,9 @@ def main() -> None:
             # the pixel store) of one launch / its mean event-timed duration / the HBM peak.  Everything in `measured_in_run` was measured by
             # THIS process on THIS box; everything in `replayed_from_profiles` comes from the committed PMC passes of tools/r05_profile.sh
             # (keyed by the kernel sources' hash and the run's settings) and was NOT measured by this run.
-            "bound": "vector-memory (texture) pipeline (replayed_from_profiles.td_busy_frac / ta_busy_frac) and the latency of dependent loads at the "
-                     "hardware's 8 waves per SIMD, ahead of vector issue -- PMC counters; not hbm (hbm_measured_frac), not mfma (unused)",
+            "bound": "vector issue (replayed_from_profiles.valu_issue_frac) plus the latency of a march position's dependent chain (cell -> table word -> "
+                     "taps -> step) at the hardware's 8 waves per SIMD; not hbm (hbm_measured_frac), not mfma (unused), and not the texture units either "
+                     "although their busy counters read high: halving their loads gained 1.5 % (profiles/r05_data_paths.txt)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_key": key,
             "frac_note": "frac = algorithmic bytes (32 B per sample, cache-served or not) / launch time / 8 TB/s: an accounting of samples, not of bytes that "
@@ -1173,11 +1174,13 @@ def main() -> None:
                 # ... and against a gather whose 64 lanes are tile-coherent (the march's lanes lie between the two)
                 "limiter_ceiling_coherent_lanes_gsamples_per_s": ceilings[coherent_key],
                 "limiter_frac_coherent_lanes": round(evals / (k_ms * 1e-3) / 1e9 / ceilings[coherent_key], 4) if kms else None,
-                # measured in round 4 (profiles/r04_ab_cell_activity_mask.txt): the evaluation RATE is how the texture path's load is counted,
-                # not what its time is made of — a build that takes a third fewer samples for bit-identical frames is 3.4 % faster
-                "limiter_note": "the texture path is busy with cache-line look-ups per wave instruction (replayed_from_profiles.lines_per_vmem_instr: 19 "
-                                "where a tile-coherent wave needs ~4), which lanes of one 8x8-pixel tile share: limiter_frac counts lane-level evaluations "
-                                "and overstates what fewer samples would buy",
+                # measured in rounds 4 and 5 (profiles/r04_ab_cell_activity_mask.txt, r05_data_paths.txt, r05_ab_placement.txt): the evaluation
+                # RATE is the march's speed against the gather microbenchmark, not what its time is made of — a third fewer samples for
+                # bit-identical frames: +3.4 %; half the loads per sample: +1.5 %; no re-placement of lanes or bricks changes the 19 lines per load
+                "limiter_note": "limiter_frac is the march's evaluation rate against an L1-served gather of independent cells measured in this run; it is a "
+                                "yardstick, not headroom: fewer samples (+3.4 % for a third fewer), fewer loads (+1.5 % for half) and re-placed lanes or "
+                                "bricks (-0.4 .. -9.5 %) were all measured, and the 19 cache lines per wave-level load come from the depth spread of a "
+                                "wave's lanes, not from their screen footprint",
             },
         }
         # (kept at the top level too: the driver's records of earlier rounds read them there)
