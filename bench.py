@@ -1146,9 +1146,12 @@ def main() -> None:
             # the pixel store) of one launch / its mean event-timed duration / the HBM peak.  Everything in `measured_in_run` was measured by
             # THIS process on THIS box; everything in `replayed_from_profiles` comes from the committed PMC passes of tools/r05_profile.sh
             # (keyed by the kernel sources' hash and the run's settings) and was NOT measured by this run.
-            "bound": "vector issue (replayed_from_profiles.valu_issue_frac) plus the latency of a march position's dependent chain (cell -> table word -> "
-                     "taps -> step) at the hardware's 8 waves per SIMD; not hbm (hbm_measured_frac), not mfma (unused), and not the texture units either "
-                     "although their busy counters read high: halving their loads gained 1.5 % (profiles/r05_data_paths.txt)",
+            "bound": "the L1 texture path on depth-incoherent lanes, reached through a latency-limited pipeline: the march runs at "
+                     "measured_in_run.limiter_frac of a dependency-free gather of the same bricks timed in this run, and what is missing is the latency of "
+                     "a position's dependent chain (cell -> table word -> taps -> step) at the hardware's cap of 8 waves per SIMD.  Sensitivities measured "
+                     "on this kernel: 11 % fewer vector instructions per position +1.2 %, half the loads per sample +1.5 %, a third fewer samples +3.4 %, "
+                     "24 instead of 32 waves per CU -16 % (profiles/r05_ab_step_asm.txt, r05_data_paths.txt, r04_ab_cell_activity_mask.txt, "
+                     "r03_occupancy_sweep_raw.txt); not hbm (replayed_from_profiles.hbm_measured_frac), not mfma (unused)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_key": key,
             "frac_note": "frac = algorithmic bytes (32 B per sample, cache-served or not) / launch time / 8 TB/s: an accounting of samples, not of bytes that "

@@ -1132,7 +1132,7 @@ def test_bench_one_gpu_line_has_the_contract_fields(oracle_lib):
     assert m["gather_ceiling_gsamples_per_s"]["l1_coherent_lanes"] > 1.5 * m["gather_ceiling_gsamples_per_s"]["l1"]
     assert m["gather_ceiling_gsamples_per_s"]["mall_hbm"] < m["gather_ceiling_gsamples_per_s"]["l1"]
     assert 0.3 < m["limiter_frac"] < 1.3 and abs(m["limiter_frac"] - m["gevaluations_per_s"] / m["limiter_ceiling_gsamples_per_s"]) < 1e-3
-    assert r["limiter_frac"] == m["limiter_frac"] and "cache-line" in m["limiter_note"]
+    assert r["limiter_frac"] == m["limiter_frac"] and "yardstick" in m["limiter_note"]
     assert m["trilinear_evaluations_per_launch"] > r["samples_per_launch"]  # + 6 per hit (the normal)
     # ... and what is REPLAYED from the committed PMC passes sits under its own key, tagged, or is absent (another kernel source)
     for k in ("td_busy_frac", "hbm_measured_frac", "valu_issue_frac", "occupancy_mean_waves_per_cu"):

@@ -459,7 +459,6 @@ __device__ __forceinline__ float leap_of(const RaySeg& R, const Cell& c, unsigne
     return (float)((nibw >> (4u * k)) & 15u) * R.cell_unit;
 }
 
-constexpr float kRelaxGate = 0.8f; /* over-relaxation: a step is stretched only when the sample is at least this fraction of the one before */
 constexpr int kRefine = 3; /* secant samples spent on a hit that overshot into the surface */
 
 /*
@@ -687,6 +686,111 @@ __device__ __forceinline__ bool march_cube(const DFrame& F, const DInstance* __r
     return false;
 }
 
+/*
+ * What a lane does with the sample s it just took at t (the oracle's march loop, same operations in the same order):
+ *
+ *     s_clamped = min(s, smax)
+ *     back      = max(s_clamped, 0) + chk < t - t_prev          over-relaxation (k_relax > 1): the step that led here was a
+ *                                                               stretched one (chk = the previous sample's empty radius, else
+ *                                                               +inf) and the two empty spheres do not overlap: something may
+ *                                                               have been jumped over, the ray goes BACK to the previous
+ *                                                               sample's plain step (that sample stays the "previous" one)
+ *     if (!back && s < fma(t, cone_eps, eps_hit)) { s_hit = s; t_end = -inf; }      hit: t, t_prev, s_prev, i stay
+ *     else {
+ *         i++
+ *         s_gate    = 0.8 * s_prev
+ *         from      = back ? t_prev : t                         where the next step starts
+ *         radius    = back ? s_prev : s_clamped                 the empty radius there
+ *         adv_min   = max(fma(from, cone_eps, base_min), back ? 0 : leap)
+ *         plain     = max(radius, adv_min)
+ *         stretched = max(min(s * k_relax, smax_relax), adv_min)
+ *         relax     = !back && stretched > plain && s >= s_gate && t + stretched <= R.t_end
+ *                                                               stretched only while the distance is not falling fast (a ray
+ *                                                               running at a surface would overshoot and come back) and the
+ *                                                               next sample stays inside the interval
+ *         t_prev = from;  s_prev = radius;  chk = relax ? radius : +inf
+ *         t = from + ((relax || k_relax < 1) ? stretched : plain)
+ *     }
+ *
+ * Written out as ISA: the compiler's form of these lines carried 15 more vector instructions per sample (register copies at the
+ * joins of its branches, the second branch's mask bookkeeping) out of ~93 in the loop, and vector issue is what the march is
+ * bound by.  Here the hit lanes and the others are separated by the exec mask once, every state variable is
+ * updated in place, and nothing is copied.  gfx950 hazards kept by hand inside the block: a mask written by a VALU compare is
+ * read by a VALU select no earlier than the third instruction after it (2 wait states), masks that come out of an SALU
+ * instruction need none; t is written three instructions before the block ends (v_pk_* with op_sel reads it in the loop's head).
+ */
+constexpr float kRelaxGate = 0.8f; /* over-relaxation: a step is stretched only when the sample is at least this fraction of the one before */
+/* a frame constant where the assembler wants a scalar register (it is wave-uniform; where the compiler already knows, this folds away) */
+__device__ __forceinline__ float uniform(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
+static_assert(__builtin_bit_cast(unsigned, kRelaxGate) == 0x3f4ccccdu, "the literal in step_from_sample");
+__device__ __forceinline__ void step_from_sample(const DFrame& F, const RaySeg& R, float s, float leap, int relax_always,
+                                                 float& t, float& t_prev, float& s_prev, float& chk, int& i, float& t_end, float& s_hit, unsigned& steps) {
+    float a, b, c;
+    unsigned long long m_back, m_save, m_relax;
+    asm("v_add_u32 %[n], 1, %[n]\n\t"                          /* one more sample taken */
+        "v_min_f32 %[a], %[s], %[smax]\n\t"
+        "v_sub_f32 %[c], %[t], %[tp]\n\t"
+        "v_max_f32 %[b], 0, %[a]\n\t"
+        "v_add_f32 %[b], %[b], %[chk]\n\t"
+        "v_cmp_lt_f32_e64 %[mb], %[b], %[c]\n\t"             /* back */
+        "v_mov_b32 %[b], %[eps]\n\t"
+        "v_fma_f32 %[b], %[t], %[cone], %[b]\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[s], %[b]\n\t"
+        "s_andn2_b64 vcc, vcc, %[mb]\n\t"                      /* hit */
+        "s_and_saveexec_b64 %[ms], vcc\n\t"                    /* the lanes that hit */
+        "v_mov_b32 %[sh], %[s]\n\t"
+        "v_mov_b32 %[te], 0xff800000\n\t"
+        "s_andn2_b64 exec, %[ms], vcc\n\t"                     /* the lanes that go on */
+        "v_mul_f32 %[b], 0x3f4ccccd, %[sp]\n\t"                /* s_gate */
+        "v_cmp_ge_f32_e64 %[mr], %[s], %[b]\n\t"
+        "v_cndmask_b32_e64 %[tp], %[t], %[tp], %[mb]\n\t"      /* from, in place */
+        "v_cndmask_b32_e64 %[sp], %[a], %[sp], %[mb]\n\t"      /* radius, in place */
+        "v_fma_f32 %[b], %[tp], %[cone], %[bmin]\n\t"
+        "v_cndmask_b32_e64 %[c], %[leap], 0, %[mb]\n\t"
+        "v_max_f32 %[b], %[b], %[c]\n\t"                       /* adv_min */
+        "v_max_f32 %[c], %[sp], %[b]\n\t"                      /* plain */
+        "v_mul_f32 %[a], %[krelax], %[s]\n\t"
+        "v_min_f32 %[a], %[a], %[smaxr]\n\t"
+        "v_max_f32 %[a], %[a], %[b]\n\t"                       /* stretched */
+        "v_cmp_gt_f32_e32 vcc, %[a], %[c]\n\t"
+        "s_and_b64 %[mr], %[mr], vcc\n\t"
+        "v_add_f32 %[b], %[t], %[a]\n\t"
+        "v_cmp_le_f32_e32 vcc, %[b], %[rtend]\n\t"
+        "s_and_b64 vcc, %[mr], vcc\n\t"
+        "s_andn2_b64 vcc, vcc, %[mb]\n\t"                      /* relax */
+        "v_cndmask_b32_e32 %[chk], %[inf], %[sp], vcc\n\t"
+        "s_or_b32 vcc_lo, vcc_lo, %[always]\n\t"
+        "s_or_b32 vcc_hi, vcc_hi, %[always]\n\t"
+        "v_cndmask_b32_e32 %[c], %[c], %[a], vcc\n\t"
+        "v_add_f32 %[t], %[tp], %[c]\n\t"
+        "v_add_u32 %[i], 1, %[i]\n\t"
+        "s_mov_b64 exec, %[ms]"
+        : [t] "+v"(t), [tp] "+v"(t_prev), [sp] "+v"(s_prev), [chk] "+v"(chk), [i] "+v"(i), [te] "+v"(t_end), [sh] "+v"(s_hit), [n] "+v"(steps),
+          [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [mb] "=&s"(m_back), [ms] "=&s"(m_save), [mr] "=&s"(m_relax)
+        : [s] "v"(s), [leap] "v"(leap), [smax] "v"(R.smax), [bmin] "v"(R.base_min), [smaxr] "v"(R.smax_relax), [rtend] "v"(R.t_end),
+          [inf] "v"(__builtin_inff()), [cone] "s"(uniform(F.cone_eps)), [eps] "s"(uniform(F.eps_hit)), [krelax] "s"(uniform(F.k_relax)),
+          [always] "s"(relax_always)
+        : "vcc", "scc");
+}
+
+/* ... and with a position whose table entry shows no active cell within the leap (no tap read, no sample counted):
+ *     t_prev = t;  s_prev = smax;  chk = +inf;  t = t + max(fma(t, cone_eps, base_min), leap);  i++
+ * The sample counter is named (and left alone) so that both arms of the branch define it in place: otherwise the compiler carries it
+ * through the join with three register copies per position. */
+__device__ __forceinline__ void step_over_empty_space(const DFrame& F, const RaySeg& R, float leap, float& t, float& t_prev, float& s_prev,
+                                                      float& chk, int& i, unsigned& steps) {
+    float b;
+    asm("v_mov_b32 %[tp], %[t]\n\t"
+        "v_fma_f32 %[b], %[t], %[cone], %[bmin]\n\t"
+        "v_max_f32 %[b], %[b], %[leap]\n\t"
+        "v_mov_b32 %[sp], %[smax]\n\t"
+        "v_mov_b32 %[chk], 0x7f800000\n\t"
+        "v_add_f32 %[t], %[t], %[b]\n\t"
+        "v_add_u32 %[i], 1, %[i]"
+        : [t] "+v"(t), [tp] "+v"(t_prev), [sp] "+v"(s_prev), [chk] "+v"(chk), [i] "+v"(i), [n] "+v"(steps), [b] "=&v"(b)
+        : [leap] "v"(leap), [smax] "v"(R.smax), [bmin] "v"(R.base_min), [cone] "s"(uniform(F.cone_eps)));
+}
+
 /* Per-lane march state.  The per-lane kernels run it from start to end; the hybrid (LDS) march stops it after its head
  * and hands it to the wave-cooperative tail. */
 struct MarchState {
@@ -718,6 +822,10 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
     Cell c = st.c;
     const bool tables = V.skip != nullptr;
     unsigned last_brick = 0xffffffffu, nibw = 0u;
+    float s_hit = st.s_hit;
+    /* k_relax < 1 (wave-uniform): every distance-driven step is scaled down, never stretched */
+    /* ... as a scalar mask word; in integer arithmetic (k_relax > 0: its bits order like its value), so that it stays in a scalar register */
+    const int relax_always = (__builtin_bit_cast(int, F.k_relax) - 0x3f800000) >> 31;
     while (i < limit && !(t > t_end)) {
         unsigned long long st0 = 0, st1 = 0;
         if constexpr (DIAG) st0 = stamp();
@@ -740,11 +848,7 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
             skip = leap >= R.smax && t <= R.t_skip_end;
         }
         if (skip) {
-            t_prev = t;
-            s_prev = R.smax;
-            chk = __builtin_inff();
-            t = t + vmax(__builtin_fmaf(t, F.cone_eps, R.base_min), leap);
-            i++;
+            step_over_empty_space(F, R, leap, t, t_prev, s_prev, chk, i, steps);
             if constexpr (DIAG) dg->iters++;
         } else {
             const Taps taps = fetch8_at<DP>(V, brick, c.cx, c.cy, c.cz);
@@ -757,37 +861,12 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
                 dg->iters++;
             }
             const float s = lerp8(taps, c.fx, c.fy, c.fz) * R.ds;
-            steps++;
-            /* Over-relaxation (k_relax > 1): when the step that led here was a stretched one (chk = the previous sample's
-               empty radius, else +inf), the empty spheres around the two samples must overlap; if they do not, something
-               may have been jumped over and the ray goes BACK to the previous sample's plain step (that sample stays the
-               "previous" one).  Written with selects: the lanes that go back and those that go on run the same code. */
-            const float s_clamped = vmin(s, R.smax);
-            const bool back = vmax(s_clamped, 0.0f) + chk < t - t_prev;
-            if (!back && s < __builtin_fmaf(t, F.cone_eps, F.eps_hit)) {
-                st.s_hit = s;
-                t_end = -__builtin_inff(); /* hit: t, c, t_prev, s_prev and i stay as they are */
-            } else {
-                i++;
-                const float s_gate = kRelaxGate * s_prev;
-                const float from = back ? t_prev : t;           /* where the next step starts */
-                const float radius = back ? s_prev : s_clamped; /* the empty radius there */
-                const float adv_min = vmax(__builtin_fmaf(from, F.cone_eps, R.base_min), back ? 0.0f : leap);
-                const float plain = vmax(radius, adv_min);
-                const float stretched = vmax(vmin(s * F.k_relax, R.smax_relax), adv_min);
-                /* stretched only while the distance is not falling fast (a ray running at a surface would overshoot and come
-                   back) and the next sample stays inside the interval (beyond it nothing checks the overlap) */
-                const bool relax = !back && stretched > plain && s >= s_gate && t + stretched <= R.t_end;
-                t_prev = from;
-                s_prev = radius;
-                chk = relax ? radius : __builtin_inff();
-                /* k_relax < 1 (wave-uniform): every distance-driven step is scaled down, never stretched */
-                t = from + ((relax || F.k_relax < 1.0f) ? stretched : plain);
-            }
+            step_from_sample(F, R, s, leap, relax_always, t, t_prev, s_prev, chk, i, t_end, s_hit, steps);
         }
         if constexpr (DIAG) dg->loop += stamp() - st0;
     }
     st.hit = t_end < R.t_end;
+    st.s_hit = s_hit;
     st.t = t;
     st.t_prev = t_prev;
     st.s_prev = s_prev;
