@@ -712,12 +712,14 @@ __device__ __forceinline__ bool march_cube(const DFrame& F, const DInstance* __r
  *         t = from + ((relax || k_relax < 1) ? stretched : plain)
  *     }
  *
- * Written out as ISA: the compiler's form of these lines carried 15 more vector instructions per sample (register copies at the
- * joins of its branches, the second branch's mask bookkeeping) out of ~93 in the loop, and vector issue is what the march is
- * bound by.  Here the hit lanes and the others are separated by the exec mask once, every state variable is
- * updated in place, and nothing is copied.  gfx950 hazards kept by hand inside the block: a mask written by a VALU compare is
- * read by a VALU select no earlier than the third instruction after it (2 wait states), masks that come out of an SALU
- * instruction need none; t is written three instructions before the block ends (v_pk_* with op_sel reads it in the loop's head).
+ * Written out as ISA: the compiler's form of these lines carried 12 more vector and 7 more scalar instructions per position
+ * (register copies at the joins of its branches, the second branch's mask bookkeeping) out of ~93 + 42 in the loop, and a
+ * position's time is made of the instructions on its wave's in-order path.  Here the hit lanes and the others are
+ * separated by the exec mask once, every state variable is updated in place, nothing is copied, and the relax condition narrows the
+ * exec mask with three v_cmpx instead of combining compare results in scalar registers.  gfx950 hazards kept by hand inside the
+ * block: a mask written by a VALU compare is read by a VALU select no earlier than the third instruction after it (2 wait states),
+ * masks that come out of an SALU instruction need none; an instruction stands between the last write of t and the end of the block
+ * (v_pk_* with op_sel reads t in the loop's head).
  */
 constexpr float kRelaxGate = 0.8f; /* over-relaxation: a step is stretched only when the sample is at least this fraction of the one before */
 /* a frame constant where the assembler wants a scalar register (it is wave-uniform; where the compiler already knows, this folds away) */
@@ -725,8 +727,8 @@ __device__ __forceinline__ float uniform(float x) { return __builtin_bit_cast(fl
 static_assert(__builtin_bit_cast(unsigned, kRelaxGate) == 0x3f4ccccdu, "the literal in step_from_sample");
 __device__ __forceinline__ void step_from_sample(const DFrame& F, const RaySeg& R, float s, float leap, int relax_always,
                                                  float& t, float& t_prev, float& s_prev, float& chk, int& i, float& t_end, float& s_hit, unsigned& steps) {
-    float a, b, c;
-    unsigned long long m_back, m_save, m_relax;
+    float a, b, c, d;
+    unsigned long long m_back, m_save;
     asm("v_add_u32 %[n], 1, %[n]\n\t"                          /* one more sample taken */
         "v_min_f32 %[a], %[s], %[smax]\n\t"
         "v_sub_f32 %[c], %[t], %[tp]\n\t"
@@ -741,8 +743,7 @@ __device__ __forceinline__ void step_from_sample(const DFrame& F, const RaySeg& 
         "v_mov_b32 %[sh], %[s]\n\t"
         "v_mov_b32 %[te], 0xff800000\n\t"
         "s_andn2_b64 exec, %[ms], vcc\n\t"                     /* the lanes that go on */
-        "v_mul_f32 %[b], 0x3f4ccccd, %[sp]\n\t"                /* s_gate */
-        "v_cmp_ge_f32_e64 %[mr], %[s], %[b]\n\t"
+        "v_mul_f32 %[d], 0x3f4ccccd, %[sp]\n\t"                /* s_gate */
         "v_cndmask_b32_e64 %[tp], %[t], %[tp], %[mb]\n\t"      /* from, in place */
         "v_cndmask_b32_e64 %[sp], %[a], %[sp], %[mb]\n\t"      /* radius, in place */
         "v_fma_f32 %[b], %[tp], %[cone], %[bmin]\n\t"
@@ -752,23 +753,24 @@ __device__ __forceinline__ void step_from_sample(const DFrame& F, const RaySeg& 
         "v_mul_f32 %[a], %[krelax], %[s]\n\t"
         "v_min_f32 %[a], %[a], %[smaxr]\n\t"
         "v_max_f32 %[a], %[a], %[b]\n\t"                       /* stretched */
-        "v_cmp_gt_f32_e32 vcc, %[a], %[c]\n\t"
-        "s_and_b64 %[mr], %[mr], vcc\n\t"
-        "v_add_f32 %[b], %[t], %[a]\n\t"
-        "v_cmp_le_f32_e32 vcc, %[b], %[rtend]\n\t"
-        "s_and_b64 vcc, %[mr], vcc\n\t"
-        "s_andn2_b64 vcc, vcc, %[mb]\n\t"                      /* relax */
-        "v_cndmask_b32_e32 %[chk], %[inf], %[sp], vcc\n\t"
-        "s_or_b32 vcc_lo, vcc_lo, %[always]\n\t"
-        "s_or_b32 vcc_hi, vcc_hi, %[always]\n\t"
-        "v_cndmask_b32_e32 %[c], %[c], %[a], vcc\n\t"
-        "v_add_f32 %[t], %[tp], %[c]\n\t"
+        "v_add_f32 %[b], %[t], %[a]\n\t"                       /* t + stretched */
+        "s_mov_b32 vcc_lo, %[always]\n\t"
+        "s_mov_b32 vcc_hi, %[always]\n\t"
+        "v_mov_b32 %[chk], 0x7f800000\n\t"
         "v_add_u32 %[i], 1, %[i]\n\t"
+        "v_cndmask_b32_e32 %[t], %[c], %[a], vcc\n\t"          /* the step unless relaxed: plain (k_relax < 1: the scaled one) */
+        "v_add_f32 %[t], %[tp], %[t]\n\t"
+        "s_andn2_b64 exec, exec, %[mb]\n\t"                    /* relax = !back ... */
+        "v_cmpx_gt_f32_e32 vcc, %[a], %[c]\n\t"                /* ... && stretched > plain */
+        "v_cmpx_ge_f32_e32 vcc, %[s], %[d]\n\t"                /* ... && s >= s_gate */
+        "v_cmpx_le_f32_e32 vcc, %[b], %[rtend]\n\t"            /* ... && t + stretched <= R.t_end */
+        "v_mov_b32 %[chk], %[sp]\n\t"
+        "v_add_f32 %[t], %[tp], %[a]\n\t"
         "s_mov_b64 exec, %[ms]"
         : [t] "+v"(t), [tp] "+v"(t_prev), [sp] "+v"(s_prev), [chk] "+v"(chk), [i] "+v"(i), [te] "+v"(t_end), [sh] "+v"(s_hit), [n] "+v"(steps),
-          [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [mb] "=&s"(m_back), [ms] "=&s"(m_save), [mr] "=&s"(m_relax)
+          [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [mb] "=&s"(m_back), [ms] "=&s"(m_save)
         : [s] "v"(s), [leap] "v"(leap), [smax] "v"(R.smax), [bmin] "v"(R.base_min), [smaxr] "v"(R.smax_relax), [rtend] "v"(R.t_end),
-          [inf] "v"(__builtin_inff()), [cone] "s"(uniform(F.cone_eps)), [eps] "s"(uniform(F.eps_hit)), [krelax] "s"(uniform(F.k_relax)),
+          [cone] "s"(uniform(F.cone_eps)), [eps] "s"(uniform(F.eps_hit)), [krelax] "s"(uniform(F.k_relax)),
           [always] "s"(relax_always)
         : "vcc", "scc");
 }
