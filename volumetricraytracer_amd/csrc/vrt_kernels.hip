@@ -813,16 +813,16 @@ struct MarchState {
  * exit test, and the sample path is written with selects: every instruction taken out of it is ~0.4 % of the frame.
  * Same positions, same values, same counters as the oracle's loop.
  */
-template <int DP, bool DIAG>
-__device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, const RaySeg& R, MarchState& st, int limit, unsigned& steps,
-                                           DiagAcc* dg) {
+template <int DP, bool DIAG, bool TABLES>
+__device__ __forceinline__ void march_lane_on(const DFrame& F, const VolRef& V, const RaySeg& R, MarchState& st, int limit, unsigned& steps,
+                                              DiagAcc* dg) {
     float t = st.t, t_prev = st.t_prev, s_prev = st.s_prev, chk = st.chk;
     /* the lane's own end of the interval: -inf once it has hit, so that the loop has ONE exit test and no break (a divergent
        break costs a handful of mask operations in every iteration of every lane) */
     float t_end = R.t_end;
     int i = st.i;
     Cell c = st.c;
-    const bool tables = V.skip != nullptr;
+    constexpr bool tables = TABLES;
     unsigned last_brick = 0xffffffffu, nibw = 0u;
     float s_hit = st.s_hit;
     /* k_relax < 1 (wave-uniform): every distance-driven step is scaled down, never stretched */
@@ -839,7 +839,7 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
         const unsigned brick = brick_index(V, c.cx, c.cy, c.cz);
         float leap = 0.0f;
         bool skip = false;
-        if (tables) {
+        if constexpr (tables) {
             if (brick != last_brick) { /* the table word is re-read only when the ray changes brick */
                 nibw = V.nib[brick];
                 last_brick = brick;
@@ -875,6 +875,14 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
     st.i = i;
     st.c = c;
     st.chk = chk;
+}
+/* The loop exists twice, with and without the empty-space tables: tested inside it, the (wave-uniform, loop-invariant) question costs
+ * every position two scalar instructions and a taken branch. */
+template <int DP, bool DIAG>
+__device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, const RaySeg& R, MarchState& st, int limit, unsigned& steps,
+                                           DiagAcc* dg) {
+    if (V.skip != nullptr) march_lane_on<DP, DIAG, true>(F, V, R, st, limit, steps, dg);
+    else march_lane_on<DP, DIAG, false>(F, V, R, st, limit, steps, dg);
 }
 
 /*
