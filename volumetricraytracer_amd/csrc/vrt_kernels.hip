@@ -813,7 +813,7 @@ struct MarchState {
  * exit test, and the sample path is written with selects: every instruction taken out of it is ~0.4 % of the frame.
  * Same positions, same values, same counters as the oracle's loop.
  */
-template <int DP, bool DIAG, bool TABLES>
+template <int DP, bool DIAG, bool TABLES, bool RELOAD>
 __device__ __forceinline__ void march_lane_on(const DFrame& F, const VolRef& V, const RaySeg& R, MarchState& st, int limit, unsigned& steps,
                                               DiagAcc* dg) {
     float t = st.t, t_prev = st.t_prev, s_prev = st.s_prev, chk = st.chk;
@@ -840,7 +840,12 @@ __device__ __forceinline__ void march_lane_on(const DFrame& F, const VolRef& V, 
         float leap = 0.0f;
         bool skip = false;
         if constexpr (tables) {
-            if (brick != last_brick) { /* the table word is re-read only when the ray changes brick */
+            if constexpr (RELOAD) {
+                /* the kernels that walk a BVH are short of registers (72, 7 waves per SIMD, spills): there the word is read in
+                   every trip and the "same brick?" test with its two registers goes (config 5 +1.6 %; the single-volume kernel
+                   loses 0.5-2 % that way: profiles/r05_ab_step_asm.txt (e)) */
+                nibw = V.nib[brick];
+            } else if (brick != last_brick) { /* the table word is re-read only when the ray changes brick */
                 nibw = V.nib[brick];
                 last_brick = brick;
             }
@@ -878,11 +883,11 @@ __device__ __forceinline__ void march_lane_on(const DFrame& F, const VolRef& V, 
 }
 /* The loop exists twice, with and without the empty-space tables: tested inside it, the (wave-uniform, loop-invariant) question costs
  * every position two scalar instructions and a taken branch. */
-template <int DP, bool DIAG>
+template <int DP, bool DIAG, bool RELOAD = false>
 __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, const RaySeg& R, MarchState& st, int limit, unsigned& steps,
                                            DiagAcc* dg) {
-    if (V.skip != nullptr) march_lane_on<DP, DIAG, true>(F, V, R, st, limit, steps, dg);
-    else march_lane_on<DP, DIAG, false>(F, V, R, st, limit, steps, dg);
+    if (V.skip != nullptr) march_lane_on<DP, DIAG, true, RELOAD>(F, V, R, st, limit, steps, dg);
+    else march_lane_on<DP, DIAG, false, false>(F, V, R, st, limit, steps, dg);
 }
 
 /*
@@ -891,7 +896,8 @@ __device__ __forceinline__ void march_lane(const DFrame& F, const VolRef& V, con
  * is not re-normalised, DXR semantics).  NORMAL: also produce the world-space normal.
  */
 template <int PATH, int NORMAL /* 0 none, 1 fast length, 2 exact length */, bool DIAG = false, bool DIR_SHADOW = false,
-          bool REF = false /* the kernel honours the reference-artefact flags (DFrame::zero_outside); false: compiled out */>
+          bool REF = false /* the kernel honours the reference-artefact flags (DFrame::zero_outside); false: compiled out */,
+          bool MULTI = false /* called from a BVH walk: the march trades the table word's register pair for a load per trip */>
 __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance* __restrict__ I,
                                                const DVolume* __restrict__ Vd, F3 o, F3 d, float t_cur, float t_base,
                                                float& t_hit, F3& n_world, unsigned& steps, unsigned& ex, DiagAcc* dg = nullptr) {
@@ -913,7 +919,7 @@ __device__ __forceinline__ bool march_instance(const DFrame& F, const DInstance*
     st.hit = false;
     st.chk = __builtin_inff();
     st.c = Cell{0, 0, 0, 0.0f, 0.0f, 0.0f};
-    march_lane<DP, DIAG>(F, V, R, st, F.max_steps, steps, dg);
+    march_lane<DP, DIAG, MULTI>(F, V, R, st, F.max_steps, steps, dg);
     if (!st.hit) {
         if (F.max_steps > 0 && st.i >= F.max_steps && !(st.t > R.t_end)) ex += kExhaustedOne; /* budget ran out inside the volume: reported, treated as a miss */
         return false;
@@ -970,7 +976,7 @@ __device__ __forceinline__ bool trace_closest(const DFrame& F, F3 o, F3 d, float
                        fall depends on the interval's end: cut at `best` the result would depend on the visiting order); the
                        cell walk of the Cube modes has no such state and stops at the closest hit so far */
                     constexpr bool kCube = PATH == kPathCube || PATH == kPathCube16;
-                    if (march_instance<PATH, NORMAL, DIAG, false, REF>(F, I, F.vols + I->slot, o, d, kCube ? best : t_max, t_base, t, n, steps, ex, dg)) {
+                    if (march_instance<PATH, NORMAL, DIAG, false, REF, true>(F, I, F.vols + I->slot, o, d, kCube ? best : t_max, t_base, t, n, steps, ex, dg)) {
                         if (!any || t < best || (t == best && ii < inst_best)) {
                             any = true;
                             best = t;
@@ -1010,7 +1016,7 @@ __device__ __forceinline__ bool trace_any(const DFrame& F, F3 o, F3 d, float t_m
             }
             if (nd.left < 0) {
                 const DInstance* I = F.inst + (-nd.left - 1);
-                if (in && march_instance<PATH, 0, DIAG, DIR_SHADOW>(F, I, F.vols + I->slot, o, d, t_max, t_base, t, n, steps, ex, dg)) found = true;
+                if (in && march_instance<PATH, 0, DIAG, DIR_SHADOW, false, true>(F, I, F.vols + I->slot, o, d, t_max, t_base, t, n, steps, ex, dg)) found = true;
                 ni = nd.right;
             } else {
                 ni = ni + 1;
