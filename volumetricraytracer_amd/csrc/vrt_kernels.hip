@@ -116,6 +116,12 @@ __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
     return r;
 }
 
+/* The table word of a brick: base in scalar registers + a 32-bit byte offset (the tables of a 1024^3 volume are 64 MiB), so that the load needs
+ * one shift, not a 64-bit address. */
+__device__ __forceinline__ unsigned table_word(const VolRef& V, unsigned brick) {
+    return *(guint_p)((gchar_p)V.nib + (brick << 2));
+}
+
 /* Index of the brick that holds cell (cx,cy,cz) — also the index into the brick tables (skip, nib, cube_skip). */
 __device__ __forceinline__ unsigned brick_index(const VolRef& V, int cx, int cy, int cz) {
     const unsigned nb = (unsigned)V.nb;
@@ -219,17 +225,13 @@ __device__ __forceinline__ Taps fetch8(const VolRef& V, int cx, int cy, int cz) 
 }
 
 /* Trilinear interpolant from the taps, lerp by lerp as the oracle does them (each one sub + one fma): over z, over x, then
- * over y.  (v_pk_*_f32 does two fp32 lanes per issue slot, and the march loop is short of issue slots.) */
-typedef float float2v __attribute__((ext_vector_type(2)));
+ * over y.  Scalar instructions on purpose: rounds 2-4 ran the z- and x-lerps on both y values at once with v_pk_add_f32 / v_pk_fma_f32
+ * (6 packed + 2 instead of 14), which is fewer instructions and, measured in round 5, SLOWER: with the packed forms gone from the
+ * march (here and in cell_at) config 3 gains 1.1 %, a frame whose every wave marches 2.4 % (profiles/r05_ab_step_asm.txt (k), (l)). */
 __device__ __forceinline__ float lerp8(const Taps& t, float fx, float fy, float fz) {
-    /* z, then x, then y: a load returns the pair (y, y+1) in adjacent registers, so the z- and x-lerps run on both y values
-       at once — three packed subs and three packed fmas (v_pk_*_f32), then one scalar lerp over y */
-    const float2v p00 = {t.y00a, t.y00b}, p01 = {t.y01a, t.y01b}, p10 = {t.y10a, t.y10b}, p11 = {t.y11a, t.y11b};
-    const float2v wz = {fz, fz}, wx = {fx, fx};
-    const float2v a0 = __builtin_elementwise_fma(wz, p01 - p00, p00); /* x0: lerp over z */
-    const float2v a1 = __builtin_elementwise_fma(wz, p11 - p10, p10); /* x1 */
-    const float2v c = __builtin_elementwise_fma(wx, a1 - a0, a0);     /* lerp over x */
-    return lerp1(c.x, c.y, fy);
+    const float a0a = lerp1(t.y00a, t.y01a, fz), a0b = lerp1(t.y00b, t.y01b, fz); /* x0: lerp over z, for y and y+1 */
+    const float a1a = lerp1(t.y10a, t.y11a, fz), a1b = lerp1(t.y10b, t.y11b, fz); /* x1 */
+    return lerp1(lerp1(a0a, a1a, fx), lerp1(a0b, a1b, fx), fy);                   /* over x, then over y */
 }
 
 template <int DP>
@@ -431,17 +433,14 @@ __device__ __forceinline__ float vmax(float a, float b) {
 }
 
 __device__ __forceinline__ Cell cell_at(const RaySeg& R, float t) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2 uxy = __builtin_elementwise_fma((f2){R.ud.x, R.ud.y}, (f2){t, t}, (f2){R.uo.x, R.uo.y}); /* one v_pk_fma_f32 */
-    const float ux = uxy.x, uy = uxy.y;
+    const float ux = __builtin_fmaf(R.ud.x, t, R.uo.x), uy = __builtin_fmaf(R.ud.y, t, R.uo.y); /* (not packed: see lerp8) */
     const float uz = __builtin_fmaf(R.ud.z, t, R.uo.z);
     const float cxf = __builtin_amdgcn_fmed3f(floorf(ux), 0.0f, R.cmax);
     const float cyf = __builtin_amdgcn_fmed3f(floorf(uy), 0.0f, R.cmax);
     const float czf = __builtin_amdgcn_fmed3f(floorf(uz), 0.0f, R.cmax);
     Cell c;
-    const f2 fxy = uxy - (f2){cxf, cyf}; /* one v_pk_add_f32 */
-    c.fx = fxy.x;
-    c.fy = fxy.y;
+    c.fx = ux - cxf;
+    c.fy = uy - cyf;
     c.fz = uz - czf;
     c.cx = (int)cxf;
     c.cy = (int)cyf;
@@ -718,8 +717,7 @@ __device__ __forceinline__ bool march_cube(const DFrame& F, const DInstance* __r
  * separated by the exec mask once, every state variable is updated in place, nothing is copied, and the relax condition narrows the
  * exec mask with three v_cmpx instead of combining compare results in scalar registers.  gfx950 hazards kept by hand inside the
  * block: a mask written by a VALU compare is read by a VALU select no earlier than the third instruction after it (2 wait states),
- * masks that come out of an SALU instruction need none; an instruction stands between the last write of t and the end of the block
- * (v_pk_* with op_sel reads t in the loop's head).
+ * masks that come out of an SALU instruction need none.
  */
 constexpr float kRelaxGate = 0.8f; /* over-relaxation: a step is stretched only when the sample is at least this fraction of the one before */
 /* a frame constant where the assembler wants a scalar register (it is wave-uniform; where the compiler already knows, this folds away) */
@@ -844,9 +842,9 @@ __device__ __forceinline__ void march_lane_on(const DFrame& F, const VolRef& V, 
                 /* the kernels that walk a BVH are short of registers (72, 7 waves per SIMD, spills): there the word is read in
                    every trip and the "same brick?" test with its two registers goes (config 5 +1.6 %; the single-volume kernel
                    loses 0.5-2 % that way: profiles/r05_ab_step_asm.txt (e)) */
-                nibw = V.nib[brick];
+                nibw = table_word(V, brick);
             } else if (brick != last_brick) { /* the table word is re-read only when the ray changes brick */
-                nibw = V.nib[brick];
+                nibw = table_word(V, brick);
                 last_brick = brick;
             }
             leap = leap_of(R, c, nibw);
